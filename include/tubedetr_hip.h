@@ -1,0 +1,141 @@
+/* C ABI of libtubedetr_hip.so - the MI355X (gfx950) kernels behind the TubeDETR hot path.
+ *
+ * The reference (antoyang/TubeDETR) is pure Python: its hot path has no FFI of its own, it calls
+ * torch / torchvision operators from nn.Modules.  Each entry below therefore names the reference
+ * call site (file:line under the reference tree) whose arithmetic it replaces; the Python modules
+ * in tubedetr_amd/models keep the reference's nn.Module surface and bind these symbols with ctypes
+ * (tubedetr_amd/_hip.py; the stub a reference maintainer would add is in INTEGRATION.md).
+ *
+ * Conventions: raw device pointers borrowed for the call (never retained, never freed); caller
+ * allocates outputs and workspaces; no hidden allocation, no synchronisation, every launch goes to
+ * the `stream` argument (a hipStream_t passed as void*); re-entrant, callable from any thread
+ * (autograd workers).  Return 0 or a negative TD_ERR_* code; td_last_error() gives a thread-local
+ * message.  dtype: TD_F32 (exact fp32 MFMA, parity mode) or TD_BF16 (bf16 MFMA, fp32 accumulate).
+ * Activations are NHWC / row-major [rows][channels]; "T" below = the dtype's element type.
+ */
+#ifndef TUBEDETR_HIP_H
+#define TUBEDETR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TD_F32 0
+#define TD_BF16 1
+#define TD_OK 0
+#define TD_ERR_INVALID (-1)
+#define TD_ERR_LAUNCH (-2)
+
+typedef void* td_stream_t; /* hipStream_t */
+
+const char* td_last_error(void);
+int td_abi_version(void);
+
+/* Geometry of one implicit-GEMM convolution / linear layer.  rows m enumerate (n, ho, wo);
+ * k enumerates (r, s, c) with c fastest; the gathered source is NHWC [N][Hs][Ws][C].
+ * mode 0 (forward):  hs = ho*stride - pad + r
+ * mode 1 (dgrad):    hs = (ho + pad - r) / stride when divisible (source = grad of conv output)
+ * A linear layer is R=S=1, stride=1, pad=0, Hs=Ho, Ws=Wo.                                        */
+typedef struct td_conv_desc {
+  int N, Hs, Ws, C;
+  int Ho, Wo;
+  int R, S, stride, pad;
+  int mode;
+  int Nc;     /* output channels = rows of the weight matrix [Nc][R*S*C] */
+  int ldc;    /* leading dimension (elements) of the output / residual / mask rows */
+  int out_sp; /* 1 = dense rows; >1 = row (n,ho,wo) is written at (n, ho*out_sp, wo*out_sp) of an */
+  int out_H, out_W; /*        [N][out_H][out_W][ldc] tensor (strided 1x1 dgrad scatter)           */
+} td_conv_desc;
+
+/* Fused epilogue: v = acc (+ bias[n]) (+ residual[m][n]); relu; sigmoid; mask (v if mask_src>0 else 0);
+ * dropout (inverted, counter-based hash RNG on element index). */
+typedef struct td_epilogue {
+  const float* bias;
+  const void* residual;
+  const void* mask_src;
+  int relu;
+  int sigmoid;
+  float dropout_p;
+  uint32_t dropout_seed;
+  float alpha; /* scales acc before bias; 0 is treated as 1 */
+} td_epilogue;
+
+/* out[m][n] = epilogue(sum_k gather(src)[m][k] * wmat[n][k]).
+ * Replaces: torch Conv2d/Linear forward + FrozenBatchNorm2d + ReLU + residual
+ * (models/backbone.py:60-70,97-98; torchvision resnet Bottleneck; models/transformer.py:643,748,
+ * 769; models/tubedetr.py:39,80) and, in mode 1 / with transposed weights, their input gradients. */
+int td_conv_gemm(const void* src, const void* wmat, void* out, const td_conv_desc* d, const td_epilogue* e,
+                 int dtype, td_stream_t stream);
+
+/* dw[n][k] += sum_m g[m][n] * gather(src)[m][k]   (fp32 atomics, `splits` partitions of m).
+ * Replaces: autograd weight gradients of Conv2d / Linear on the same call sites. */
+int td_conv_wgrad(const void* g, const void* src, float* dw, const td_conv_desc* d, int ldg, int dtype, int splits,
+                  td_stream_t stream);
+
+/* Fold FrozenBatchNorm2d (models/backbone.py:60-70) into a conv: w_fwd[co][r][s][ci] = W[co][ci][r][s]*scale[co]
+ * (ci zero-padded to Cpad), w_dgrad[ci][r][s][co] likewise (may be NULL), bias_out[co] = b - rm*scale,
+ * scale_out[co] = w*rsqrt(rv+eps).  bn_* may be NULL (plain layer: scale 1, bias copied from `bias`). */
+int td_weight_prep(const float* W, const float* bn_w, const float* bn_b, const float* bn_rm, const float* bn_rv,
+                   const float* bias, int Co, int Ci, int R, int S, int Cpad, void* w_fwd, void* w_dgrad,
+                   float* bias_out, float* scale_out, int dtype, td_stream_t stream);
+
+/* dW[co][ci][r][s] (+)= dw_k[co][r][s][ci] * scale[co]  (scale may be NULL). */
+int td_wgrad_finalize(const float* dw_k, const float* scale, float* dW, int Co, int Ci, int R, int S, int Cpad,
+                      int accumulate, td_stream_t stream);
+
+/* NCHW fp32 frames -> NHWC T with channels zero-padded to Cpad (engine.py:55 samples.tensors). */
+int td_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype, td_stream_t stream);
+/* NHWC T -> NCHW fp32 (features returned through the nn.Module boundary). */
+int td_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int dtype, td_stream_t stream);
+/* NCHW fp32 gradient -> NHWC T. */
+int td_cast(const void* x, void* y, size_t n, int src_dtype, int dst_dtype, td_stream_t stream);
+
+/* 3x3 stride-2 pad-1 max pooling, NHWC (torchvision resnet stem; forward only: the stem is frozen,
+ * models/backbone.py:82-89). */
+int td_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, td_stream_t stream);
+
+/* y = LayerNorm(x + r) * gamma + beta over the last dim (cols); s_out (optional) receives x + r;
+ * mean/rstd fp32 per row.  models/transformer.py:641-645,721-722,744-750,581,771. */
+int td_add_layernorm_fwd(const void* x, const void* r, const float* gamma, const float* beta, void* y, void* s_out,
+                         float* mean, float* rstd, int rows, int cols, float eps, int dtype, td_stream_t stream);
+/* ds = LN backward wrt (x + r) (+ extra, an optional additional upstream gradient of s);
+ * dgamma/dbeta accumulated with fp32 atomics. */
+int td_add_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd, const float* gamma,
+                         const void* extra, void* ds, float* dgamma, float* dbeta, int rows, int cols, int dtype,
+                         td_stream_t stream);
+
+/* out[n] += sum_m g[m][n]  (bias gradients). */
+int td_colsum(const void* g, float* out, int rows, int cols, int ld, int dtype, td_stream_t stream);
+/* y = a + b (b may be NULL -> copy); elementwise on T. */
+int td_add(const void* a, const void* b, void* y, size_t n, int dtype, td_stream_t stream);
+
+/* g = dy * scale where y > 0 else 0   (ReLU / ReLU+dropout backward from the saved output y). */
+int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, float scale, int dtype, td_stream_t stream);
+
+/* PositionEmbeddingSine (models/position_encoding.py:71-94, normalize=True, scale=2pi) from a
+ * (N,h,w) uint8 pad mask -> pos [N][h*w][2*npf] T  (token-major, the layout the encoder consumes). */
+int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, float temperature, int dtype,
+                td_stream_t stream);
+
+/* Multi-head attention core on already projected q,k,v (nn.MultiheadAttention internals,
+ * models/transformer.py:613,638-640 encoder; 661,713-719 temporal self-attention; 662,734-740
+ * time-aligned cross-attention with Lq=1).  Batch-major rows: q [B][Lq] rows of stride ldq, head h in
+ * columns h*hd..h*hd+hd-1 (hd = 32); k,v [B][Lk] likewise; key_pad [B][Lk] uint8 (1 = ignore) or NULL.
+ * scores = scale * q.k; probs [B][H][Lq][Lk] fp32 = softmax (pre-dropout, saved for backward);
+ * out [B][Lq] rows of stride ldo = dropout(probs) @ v; wavg [B][Lq][Lk] fp32 = head average of the
+ * post-dropout probabilities (what nn.MultiheadAttention returns) or NULL. */
+int td_mha_fwd(const void* q, const void* k, const void* v, const uint8_t* key_pad, void* out, float* probs,
+               float* wavg, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
+               float dropout_p, uint32_t dropout_seed, int dtype, td_stream_t stream);
+/* Backward of td_mha_fwd.  dwavg [B][Lq][Lk] fp32 = gradient of the head-averaged weights
+ * (guided-attention loss, models/tubedetr.py:357-369) or NULL; ds_ws: fp32 workspace [B][H][Lq][Lk].
+ * dout, dq, dk, dv are dense rows of stride ldo (= H*hd). */
+int td_mha_bwd(const void* q, const void* k, const void* v, const void* dout, const float* probs, const float* dwavg,
+               void* dq, void* dk, void* dv, float* ds_ws, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk,
+               int ldv, int ldo, float scale, float dropout_p, uint32_t dropout_seed, int dtype, td_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

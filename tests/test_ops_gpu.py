@@ -1,0 +1,281 @@
+"""Per-kernel parity on a real MI355X: every C-ABI op against a plain PyTorch fp32 (CPU) reference of the
+same op.  fp32 mode must agree to fp32 round-off; bf16 mode is compared against the reference evaluated on
+bf16-rounded inputs with a bf16-sized tolerance (stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}  # max|err| / max|ref|
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def rnd(shape, g, dt, scale=1.0):
+    x = torch.randn(shape, generator=g) * scale
+    return x.to(dt).float()  # values exactly representable in dt
+
+
+def nhwc(x, dt):  # NCHW cpu float -> NHWC device dt
+    return x.permute(0, 2, 3, 1).contiguous().to(dev(), dt)
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+CONVS = [
+    # N, Cin, H, W, Cout, R, stride, pad
+    (2, 64, 12, 12, 64, 1, 1, 0),
+    (3, 64, 11, 13, 256, 1, 1, 0),
+    (2, 128, 14, 14, 128, 3, 1, 1),
+    (2, 128, 15, 13, 128, 3, 2, 1),
+    (2, 256, 9, 9, 512, 1, 2, 0),
+    (2, 8, 30, 34, 64, 7, 2, 3),
+    (1, 512, 6, 6, 2048, 1, 1, 0),
+    (5, 256, 22, 22, 256, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_fwd_dgrad_wgrad(cfg, dt):
+    from tubedetr_amd import ops
+
+    N, Ci, H, W, Co, R, st, pad = cfg
+    g = torch.Generator().manual_seed(1)
+    x = rnd((N, Ci, H, W), g, dt)
+    w = rnd((Co, Ci, R, R), g, dt, 1.0 / math.sqrt(Ci * R * R))
+    bias = torch.randn(Co, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, bias, stride=st, padding=pad)
+    res = rnd(tuple(y_ref.shape), g, dt)
+    out_ref = F.relu(y_ref + res)
+    gy = rnd(tuple(y_ref.shape), g, dt)
+    out_ref.backward(gy)
+    gpre = (gy * (out_ref > 0)).detach()  # gradient at the conv output
+
+    wf, wd, b_out, _ = ops.weight_prep(w.to(dev()), dt, bias=bias.to(dev()))
+    xd = nhwc(x, dt)
+    y = ops.conv_fwd(xd, wf, b_out, R, R, st, pad, residual=nhwc(res, dt), relu=True)
+    assert rel_err(from_nhwc(y), out_ref) < TOL[dt]
+
+    gd = nhwc(gpre, dt)
+    dx = ops.conv_dgrad(gd, wd, (H, W), R, R, st, pad)
+    assert rel_err(from_nhwc(dx), xr.grad) < TOL[dt]
+
+    dwk = ops.conv_wgrad(gd, xd, R, R, st, pad)
+    dW = ops.wgrad_finalize(dwk, None, (Co, Ci, R, R), Ci)
+    assert rel_err(dW, wr.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_frozen_bn_fold_and_mask_epilogues(dt):
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    N, Ci, H, W, Co = 2, 64, 10, 10, 128
+    x = rnd((N, Ci, H, W), g, dt)
+    w = rnd((Co, Ci, 3, 3), g, torch.float32, 0.05)
+    bn = [torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1, torch.randn(Co, generator=g) * 0.1, torch.rand(Co, generator=g) + 0.5]
+    scale = bn[0] * (bn[3] + 1e-5).rsqrt()
+    shift = bn[1] - bn[2] * scale
+    ref = F.relu(F.conv2d(x, w, padding=1) * scale[None, :, None, None] + shift[None, :, None, None])
+    wf, wd, b_out, sc = ops.weight_prep(w.to(dev()), dt, bn=[b.to(dev()) for b in bn])
+    assert rel_err(sc, scale) < 1e-5 and rel_err(b_out, shift) < 1e-5
+    y = ops.conv_fwd(nhwc(x, dt), wf, b_out, 3, 3, 1, 1, relu=True)
+    assert rel_err(from_nhwc(y), ref) < TOL[dt] * 2
+    # dgrad with residual + mask epilogue: dx = (dgrad(g) + r) * (m > 0)
+    gy = rnd((N, Co, H, W), g, dt)
+    r = rnd((N, Ci, H, W), g, dt)
+    m = rnd((N, Ci, H, W), g, dt)
+    wfold = (w * scale[:, None, None, None])
+    if dt == torch.bfloat16:
+        wfold = wfold.bfloat16().float()
+    dx_ref = (torch.nn.grad.conv2d_input((N, Ci, H, W), wfold, gy, padding=1) + r) * (m > 0)
+    dx = ops.conv_dgrad(nhwc(gy, dt), wd, (H, W), 3, 3, 1, 1, residual=nhwc(r, dt), mask_src=nhwc(m, dt))
+    assert rel_err(from_nhwc(dx), dx_ref) < TOL[dt]
+    # wgrad un-fold: dW = dW_k * scale
+    dwk = ops.conv_wgrad(nhwc(gy, dt), nhwc(x, dt), 3, 3, 1, 1)
+    dW = ops.wgrad_finalize(dwk, sc, (Co, Ci, 3, 3), Ci)
+    dW_ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, 3, 3), gy, padding=1) * scale[:, None, None, None]
+    assert rel_err(dW, dW_ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_strided_1x1_dgrad_scatter(dt):
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    N, Ci, H, W, Co = 2, 64, 9, 11, 128
+    w = rnd((Co, Ci, 1, 1), g, dt, 0.1)
+    gy = rnd((N, Co, 5, 6), g, dt)
+    base = rnd((N, Ci, H, W), g, dt)
+    m = rnd((N, Ci, H, W), g, dt)
+    ref = (base * (m > 0) + torch.nn.grad.conv2d_input((N, Ci, H, W), w, gy, stride=2)) * (m > 0)
+    _, wd, _, _ = ops.weight_prep(w.to(dev()), dt)
+    dx = nhwc(base * (m > 0), dt)
+    ops.conv1x1s_dgrad_scatter(nhwc(gy, dt), wd, dx, 2, mask_src=nhwc(m, dt))
+    assert rel_err(from_nhwc(dx), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("shape", [(3775, 256, 768), (100, 256, 2048), (600, 2048, 256), (37, 768, 256), (600, 256, 8), (15100, 256, 3072)])
+def test_linear_fwd_bwd(shape, dt):
+    from tubedetr_amd import ops
+
+    M, K, Nn = shape
+    g = torch.Generator().manual_seed(4)
+    x = rnd((M, K), g, dt)
+    w = rnd((Nn, K), g, dt, 1 / math.sqrt(K))
+    b = torch.randn(Nn, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.relu(xr @ wr.t() + b)
+    gy = rnd((M, Nn), g, dt)
+    y_ref.backward(gy)
+    wf, wd, _, _ = ops.weight_prep(w.to(dev()), dt)
+    xd = x.to(dev(), dt)
+    y = ops.linear_fwd(xd, wf, b.to(dev()), relu=True)
+    assert rel_err(y, y_ref) < TOL[dt]
+    gpre = ops.relu_bwd(gy.to(dev(), dt), y)
+    dx = ops.linear_fwd(gpre, wd)
+    assert rel_err(dx, xr.grad) < TOL[dt]
+    dW = ops.linear_wgrad(gpre, xd)
+    assert rel_err(dW, wr.grad) < TOL[dt]
+    db = ops.colsum(gpre)
+    assert rel_err(db, (gy * (y_ref > 0)).sum(0)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_linear_sigmoid_alpha_dropout(dt):
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x, w = rnd((300, 256), g, dt), rnd((64, 256), g, dt, 0.06)
+    y = ops.linear_fwd(x.to(dev(), dt), w.to(dev(), dt), None, sigmoid=True, alpha=0.5)
+    assert rel_err(y, torch.sigmoid(0.5 * x @ w.t())) < TOL[dt]
+    # dropout: kept elements are scaled by 1/(1-p), keep-rate ~ 1-p, mask is a pure function of (seed, index)
+    y0 = ops.linear_fwd(x.to(dev(), dt), w.to(dev(), dt))
+    y1 = ops.linear_fwd(x.to(dev(), dt), w.to(dev(), dt), dropout_p=0.25, seed=123)
+    y2 = ops.linear_fwd(x.to(dev(), dt), w.to(dev(), dt), dropout_p=0.25, seed=123)
+    assert torch.equal(y1, y2)
+    kept = y1 != 0
+    assert abs(kept.float().mean().item() - 0.75) < 0.02
+    assert rel_err(y1[kept], (y0.float() / 0.75)[kept]) < 1e-2
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_add_layernorm(dt):
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(6)
+    rows, cols = 777, 256
+    x, r = rnd((rows, cols), g, dt), rnd((rows, cols), g, dt)
+    gamma, beta = torch.rand(cols, generator=g) + 0.5, torch.randn(cols, generator=g)
+    sr = (x + r).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.layer_norm(sr, (cols,), gr, br, 1e-5)
+    dy = rnd((rows, cols), g, dt)
+    extra = rnd((rows, cols), g, dt)
+    y_ref.backward(dy)
+    y, s, mean, rstd = ops.add_layernorm_fwd(x.to(dev(), dt), r.to(dev(), dt), gamma.to(dev()), beta.to(dev()), 1e-5)
+    assert rel_err(y, y_ref) < TOL[dt]
+    ds, dg, db = ops.add_layernorm_bwd(dy.to(dev(), dt), s, mean, rstd, gamma.to(dev()), extra.to(dev(), dt))
+    s_used = s.float().cpu().requires_grad_(True)
+    F.layer_norm(s_used, (cols,), gamma, beta, 1e-5).backward(dy)
+    assert rel_err(ds, s_used.grad + extra) < TOL[dt]
+    assert rel_err(dg, gr.grad) < TOL[dt] * 3 and rel_err(db, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_maxpool_and_layout(dt):
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 3, 21, 18, generator=g)
+    xd = ops.nchw_to_nhwc(x.to(dev()), dt, 8)
+    assert xd.shape == (3, 21, 18, 8)
+    assert torch.equal(xd[..., :3].float().cpu(), x.to(dt).float().permute(0, 2, 3, 1)) and xd[..., 3:].abs().sum() == 0
+    f = rnd((2, 64, 17, 20), g, dt)
+    y = ops.maxpool3x3s2(nhwc(f, dt))
+    assert torch.equal(from_nhwc(y), F.max_pool2d(f, 3, 2, 1))
+    assert torch.equal(ops.nhwc_to_nchw(nhwc(f, dt)).cpu(), f)
+    assert torch.equal(ops.cast(f.to(dev()), dt).float().cpu(), f)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_pos_sine_matches_oracle(dt):
+    from oracle.tubedetr_oracle import pos_sine
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(8)
+    mask = torch.rand(5, 11, 9, generator=g) > 0.7
+    mask[:, 0, 0] = False
+    mask[1] = False
+    mask[2, :, 6:] = True
+    ref = pos_sine(mask, 128).flatten(2).permute(0, 2, 1)  # (N, hw, 256)
+    pos = ops.pos_sine(mask.to(dev()), 128, dt)
+    tol = 2e-5 if dt == torch.float32 else 5e-3
+    assert (pos.float().cpu() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cfg", [(3, 8, 151, 151, True), (1, 8, 100, 100, True), (7, 8, 1, 151, True), (2, 8, 37, 70, False)])
+def test_mha_core_fwd_bwd(cfg, dt):
+    from tubedetr_amd import ops
+
+    B, H, Lq, Lk, use_mask = cfg
+    E, hd = H * 32, 32
+    g = torch.Generator().manual_seed(9)
+    q, k, v = rnd((B, Lq, E), g, dt), rnd((B, Lk, E), g, dt), rnd((B, Lk, E), g, dt)
+    kpm = (torch.rand(B, Lk, generator=g) > 0.8) if use_mask else None
+    if kpm is not None:
+        kpm[:, 0] = False
+    scale = 1 / math.sqrt(hd)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    qh = qr.view(B, Lq, H, hd).transpose(1, 2)
+    kh = kr.view(B, Lk, H, hd).transpose(1, 2)
+    vh = vr.view(B, Lk, H, hd).transpose(1, 2)
+    sc = (qh @ kh.transpose(-1, -2)) * scale
+    if kpm is not None:
+        sc = sc.masked_fill(kpm[:, None, None, :], float("-inf"))
+    pr = sc.softmax(-1)
+    out_ref = (pr @ vh).transpose(1, 2).reshape(B, Lq, E)
+    wavg_ref = pr.mean(1)
+    dout = rnd((B, Lq, E), g, dt)
+    dwavg = torch.randn(B, Lq, Lk, generator=g)
+    (out_ref * dout).sum().add((wavg_ref * dwavg).sum()).backward()
+
+    qd, kd, vd = (t.to(dev(), dt) for t in (q, k, v))
+    out, probs, wavg = ops.mha_fwd(qd, kd, vd, kpm.to(dev()) if kpm is not None else None, H, scale, need_wavg=True)
+    assert rel_err(out, out_ref) < TOL[dt]
+    assert rel_err(wavg, wavg_ref) < 1e-4
+    assert torch.equal(wavg.argmax(-1).cpu(), wavg_ref.argmax(-1))
+    dq, dk, dv = ops.mha_bwd(qd, kd, vd, dout.to(dev(), dt), probs, dwavg.to(dev()), H, scale)
+    for got, ref in ((dq, qr.grad), (dk, kr.grad), (dv, vr.grad)):
+        assert rel_err(got, ref) < TOL[dt]
+
+
+def test_mha_strided_qkv_views():
+    """q/k packed in one [B,L,2E] buffer (the fused QK projection output) and v separate."""
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(10)
+    B, L, H, E = 2, 40, 8, 256
+    qk = torch.randn(B, L, 2 * E, generator=g).to(dev())
+    v = torch.randn(B, L, E, generator=g).to(dev())
+    o1, p1, _ = ops.mha_fwd(qk[..., :E], qk[..., E:], v, None, H, 0.17)
+    o2, p2, _ = ops.mha_fwd(qk[..., :E].contiguous(), qk[..., E:].contiguous(), v, None, H, 0.17)
+    assert torch.equal(o1, o2) and torch.equal(p1, p2)

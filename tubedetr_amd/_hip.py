@@ -1,0 +1,104 @@
+"""ctypes binding of libtubedetr_hip.so (include/tubedetr_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a kernel reports an error this
+module raises.  Tensors cross the boundary as raw device pointers + the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+TD_F32, TD_BF16 = 0, 1
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtubedetr_hip.so")
+_lib = None
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "Hs", "Ws", "C", "Ho", "Wo", "R", "S", "stride", "pad", "mode", "Nc", "ldc", "out_sp", "out_H", "out_W")]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [
+        ("bias", C.c_void_p),
+        ("residual", C.c_void_p),
+        ("mask_src", C.c_void_p),
+        ("relu", C.c_int),
+        ("sigmoid", C.c_int),
+        ("dropout_p", C.c_float),
+        ("dropout_seed", C.c_uint32),
+        ("alpha", C.c_float),
+    ]
+
+
+_P, _I, _F, _U32, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t
+_SIGS = {
+    "td_conv_gemm": [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P],
+    "td_conv_wgrad": [_P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
+    "td_weight_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "td_wgrad_finalize": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "td_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "td_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "td_cast": [_P, _P, _SZ, _I, _I, _P],
+    "td_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "td_add_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "td_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "td_colsum": [_P, _P, _I, _I, _I, _I, _P],
+    "td_add": [_P, _P, _P, _SZ, _I, _P],
+    "td_relu_bwd": [_P, _P, _P, _SZ, _F, _I, _P],
+    "td_pos_sine": [_P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "td_mha_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _I, _P],
+    "td_mha_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _I, _P],
+}
+EXPORTS = ["td_last_error", "td_abi_version"] + list(_SIGS)
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (raises if it was not built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build it with `python -m tubedetr_amd.build` (or __graft_entry__.build()); "
+                "tubedetr_amd has no CPU / eager fallback"
+            )
+        L = C.CDLL(_LIB_PATH)
+        L.td_last_error.restype = C.c_char_p
+        L.td_last_error.argtypes = []
+        L.td_abi_version.restype = C.c_int
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = sig
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise RuntimeError(f"libtubedetr_hip {what} failed ({rc}): {lib().td_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return TD_F32
+    if dt == torch.bfloat16:
+        return TD_BF16
+    raise TypeError(f"unsupported compute dtype {dt}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous & on the GPU."""
+    if t is None:
+        return None
+    assert t.is_cuda, "tubedetr_amd kernels only run on the GPU"
+    return t.data_ptr()

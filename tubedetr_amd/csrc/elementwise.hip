@@ -1,0 +1,298 @@
+// HBM-bound elementwise / reduction kernels of the TubeDETR hot path (gfx950): stem max-pool, fused
+// residual-add + LayerNorm forward/backward (one wave per row, wavefront shuffle reductions), column
+// sums for bias gradients, elementwise add, sine position encoding from the pad mask.
+// Reference call sites: torchvision resnet stem maxpool (models/backbone.py:98), nn.LayerNorm at
+// models/transformer.py:619-620,641-645,669-672,721-750,89,581,765-771, PositionEmbeddingSine
+// (models/position_encoding.py:71-94).
+#include "td_common.h"
+
+namespace td {
+
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* x, T* y, int N, int H, int W, int C, int Ho, int Wo) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cv = C / VEC;
+  const size_t n = (size_t)N * Ho * Wo * cv;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  int c = (idx % cv) * VEC;
+  size_t t = idx / cv;
+  int wo = t % Wo; t /= Wo;
+  int ho = t % Ho;
+  int img = t / Ho;
+  float m[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) m[i] = -INFINITY;
+  for (int r = 0; r < 3; ++r) {
+    int h = ho * 2 - 1 + r;
+    if ((unsigned)h >= (unsigned)H) continue;
+    for (int s = 0; s < 3; ++s) {
+      int w = wo * 2 - 1 + s;
+      if ((unsigned)w >= (unsigned)W) continue;
+      uint4 v = *(const uint4*)(x + ((size_t)(img * H + h) * W + w) * C + c);
+      const T* e = (const T*)&v;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) m[i] = fmaxf(m[i], Elem<T>::load(e, i));
+    }
+  }
+  uint4 o;
+  T* eo = (T*)&o;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) Elem<T>::store(eo, i, m[i]);
+  *(uint4*)(y + ((size_t)(img * Ho + ho) * Wo + wo) * C + c) = o;
+}
+
+// one wave per row; cols <= 64*MAXJ
+constexpr int LN_MAXJ = 16;
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T* x, const T* r, const float* gamma, const float* beta,
+                                                                T* y, T* s_out, float* mean, float* rstd, int rows, int cols,
+                                                                float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t base = (size_t)row * cols;
+  float v[LN_MAXJ];
+  float sum = 0.f;
+  const int nj = (cols + 63) / 64;
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    v[j] = 0.f;
+    int c = lane + 64 * j;
+    if (j < nj && c < cols) {
+      float a = Elem<T>::load(x, base + c);
+      if (r) a += Elem<T>::load(r, base + c);
+      v[j] = a;
+      sum += a;
+    }
+  }
+  const float mu = wave_sum(sum) / cols;
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    int c = lane + 64 * j;
+    if (j < nj && c < cols) {
+      float dlt = v[j] - mu;
+      var += dlt * dlt;
+    }
+  }
+  var = wave_sum(var) / cols;
+  const float rs = rsqrtf(var + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    int c = lane + 64 * j;
+    if (j < nj && c < cols) {
+      if (s_out) Elem<T>::store(s_out, base + c, v[j]);
+      Elem<T>::store(y, base + c, (v[j] - mu) * rs * gamma[c] + beta[c]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T* dy, const T* s, const float* mean, const float* rstd,
+                                                                const float* gamma, const T* extra, T* ds, float* dgamma,
+                                                                float* dbeta, int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  const int nj = (cols + 63) / 64;
+  float pg[LN_MAXJ], pb[LN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) pg[j] = pb[j] = 0.f;
+  for (int row = wid; row < rows; row += nw) {
+    const size_t base = (size_t)row * cols;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[LN_MAXJ], dg[LN_MAXJ];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      xh[j] = dg[j] = 0.f;
+      int c = lane + 64 * j;
+      if (j < nj && c < cols) {
+        float d = Elem<T>::load(dy, base + c);
+        xh[j] = (Elem<T>::load(s, base + c) - mu) * rs;
+        dg[j] = d * gamma[c];
+        c1 += dg[j];
+        c2 += dg[j] * xh[j];
+        pg[j] += d * xh[j];
+        pb[j] += d;
+      }
+    }
+    c1 = wave_sum(c1) / cols;
+    c2 = wave_sum(c2) / cols;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      int c = lane + 64 * j;
+      if (j < nj && c < cols) {
+        float o = rs * (dg[j] - c1 - xh[j] * c2);
+        if (extra) o += Elem<T>::load(extra, base + c);
+        Elem<T>::store(ds, base + c, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    int c = lane + 64 * j;
+    if (j < nj && c < cols) {
+      if (dgamma) atomicAdd(dgamma + c, pg[j]);
+      if (dbeta) atomicAdd(dbeta + c, pb[j]);
+    }
+  }
+}
+
+template <typename T>
+__global__ void colsum_kernel(const T* g, float* out, int rows, int cols, int ld, int rows_per_block) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += Elem<T>::load(g, (size_t)r * ld + c);
+  atomicAdd(out + c, acc);
+}
+
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* y, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) Elem<T>::store(y, i, Elem<T>::load(a, i) + (b ? Elem<T>::load(b, i) : 0.f));
+}
+
+template <typename T>
+__global__ void relu_bwd_kernel(const T* dy, const T* y, T* g, size_t n, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) Elem<T>::store(g, i, Elem<T>::load(y, i) > 0.f ? Elem<T>::load(dy, i) * scale : 0.f);
+}
+
+// one block per image; thread per (y,x) token, loops over channels
+template <typename T>
+__global__ void pos_sine_kernel(const uint8_t* mask, T* pos, int h, int w, int npf, float temperature) {
+  const int img = blockIdx.x;
+  const uint8_t* m = mask + (size_t)img * h * w;
+  const float two_pi = 6.283185307179586f;
+  for (int tkn = threadIdx.x; tkn < h * w; tkn += blockDim.x) {
+    const int y = tkn / w, x = tkn - y * w;
+    float ye = 0.f, xe = 0.f, ylast = 0.f, xlast = 0.f;
+    for (int yy = 0; yy < h; ++yy) {
+      float nm = m[yy * w + x] ? 0.f : 1.f;
+      ylast += nm;
+      if (yy <= y) ye += nm;
+    }
+    for (int xx = 0; xx < w; ++xx) {
+      float nm = m[y * w + xx] ? 0.f : 1.f;
+      xlast += nm;
+      if (xx <= x) xe += nm;
+    }
+    ye = ye / (ylast + 1e-6f) * two_pi;
+    xe = xe / (xlast + 1e-6f) * two_pi;
+    T* o = pos + ((size_t)img * h * w + tkn) * (2 * npf);
+    for (int i = 0; i < npf; ++i) {
+      float dim_t = powf(temperature, (float)(2 * (i / 2)) / (float)npf);
+      float vy = ye / dim_t, vx = xe / dim_t;
+      Elem<T>::store(o, i, (i & 1) ? cosf(vy) : sinf(vy));
+      Elem<T>::store(o, npf + i, (i & 1) ? cosf(vx) : sinf(vx));
+    }
+  }
+}
+
+}  // namespace td
+using namespace td;
+
+static inline unsigned nblk(size_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+#define TD_DISPATCH(dtype, CALL_BF16, CALL_F32, who)  \
+  if (dtype == TD_BF16) { CALL_BF16; }                \
+  else if (dtype == TD_F32) { CALL_F32; }             \
+  else TD_REQUIRE(false, who ": bad dtype")
+
+extern "C" int td_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, td_stream_t stream) {
+  TD_REQUIRE(x && y, "td_maxpool3x3s2: null pointer");
+  const int vec = dtype == TD_BF16 ? 8 : 4;
+  TD_REQUIRE(C % vec == 0, "td_maxpool3x3s2: C must be a multiple of %d", vec);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  size_t n = (size_t)N * Ho * Wo * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  TD_DISPATCH(dtype, (maxpool3x3s2_kernel<u16><<<nblk(n), 256, 0, st>>>((const u16*)x, (u16*)y, N, H, W, C, Ho, Wo)),
+              (maxpool3x3s2_kernel<float><<<nblk(n), 256, 0, st>>>((const float*)x, (float*)y, N, H, W, C, Ho, Wo)),
+              "td_maxpool3x3s2");
+  return check_launch("td_maxpool3x3s2");
+}
+
+extern "C" int td_add_layernorm_fwd(const void* x, const void* r, const float* gamma, const float* beta, void* y,
+                                    void* s_out, float* mean, float* rstd, int rows, int cols, float eps, int dtype,
+                                    td_stream_t stream) {
+  TD_REQUIRE(x && gamma && beta && y, "td_add_layernorm_fwd: null pointer");
+  TD_REQUIRE(cols <= 64 * LN_MAXJ, "td_add_layernorm_fwd: cols > %d", 64 * LN_MAXJ);
+  if (rows == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned g = (rows + 3) / 4;
+  TD_DISPATCH(dtype,
+              (add_layernorm_fwd_kernel<u16><<<g, 256, 0, st>>>((const u16*)x, (const u16*)r, gamma, beta, (u16*)y, (u16*)s_out, mean, rstd, rows, cols, eps)),
+              (add_layernorm_fwd_kernel<float><<<g, 256, 0, st>>>((const float*)x, (const float*)r, gamma, beta, (float*)y, (float*)s_out, mean, rstd, rows, cols, eps)),
+              "td_add_layernorm_fwd");
+  return check_launch("td_add_layernorm_fwd");
+}
+
+extern "C" int td_add_layernorm_bwd(const void* dy, const void* s, const float* mean, const float* rstd,
+                                    const float* gamma, const void* extra, void* ds, float* dgamma, float* dbeta,
+                                    int rows, int cols, int dtype, td_stream_t stream) {
+  TD_REQUIRE(dy && s && mean && rstd && gamma && ds, "td_add_layernorm_bwd: null pointer");
+  TD_REQUIRE(cols <= 64 * LN_MAXJ, "td_add_layernorm_bwd: cols > %d", 64 * LN_MAXJ);
+  if (rows == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned g = (rows + 3) / 4;
+  if (g > 512) g = 512;
+  TD_DISPATCH(dtype,
+              (add_layernorm_bwd_kernel<u16><<<g, 256, 0, st>>>((const u16*)dy, (const u16*)s, mean, rstd, gamma, (const u16*)extra, (u16*)ds, dgamma, dbeta, rows, cols)),
+              (add_layernorm_bwd_kernel<float><<<g, 256, 0, st>>>((const float*)dy, (const float*)s, mean, rstd, gamma, (const float*)extra, (float*)ds, dgamma, dbeta, rows, cols)),
+              "td_add_layernorm_bwd");
+  return check_launch("td_add_layernorm_bwd");
+}
+
+extern "C" int td_colsum(const void* g, float* out, int rows, int cols, int ld, int dtype, td_stream_t stream) {
+  TD_REQUIRE(g && out, "td_colsum: null pointer");
+  if (rows == 0 || cols == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = 128;
+  dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
+  TD_DISPATCH(dtype, (colsum_kernel<u16><<<grid, 256, 0, st>>>((const u16*)g, out, rows, cols, ld, rpb)),
+              (colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)g, out, rows, cols, ld, rpb)), "td_colsum");
+  return check_launch("td_colsum");
+}
+
+extern "C" int td_add(const void* a, const void* b, void* y, size_t n, int dtype, td_stream_t stream) {
+  TD_REQUIRE(a && y, "td_add: null pointer");
+  if (n == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned g = nblk(n);
+  if (g > 4096) g = 4096;
+  TD_DISPATCH(dtype, (add_kernel<u16><<<g, 256, 0, st>>>((const u16*)a, (const u16*)b, (u16*)y, n)),
+              (add_kernel<float><<<g, 256, 0, st>>>((const float*)a, (const float*)b, (float*)y, n)), "td_add");
+  return check_launch("td_add");
+}
+
+extern "C" int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, float scale, int dtype, td_stream_t stream) {
+  TD_REQUIRE(dy && y && g, "td_relu_bwd: null pointer");
+  if (n == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned gr = nblk(n);
+  if (gr > 4096) gr = 4096;
+  TD_DISPATCH(dtype, (relu_bwd_kernel<u16><<<gr, 256, 0, st>>>((const u16*)dy, (const u16*)y, (u16*)g, n, scale)),
+              (relu_bwd_kernel<float><<<gr, 256, 0, st>>>((const float*)dy, (const float*)y, (float*)g, n, scale)), "td_relu_bwd");
+  return check_launch("td_relu_bwd");
+}
+
+extern "C" int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, float temperature, int dtype,
+                           td_stream_t stream) {
+  TD_REQUIRE(mask && pos, "td_pos_sine: null pointer");
+  if (N == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  TD_DISPATCH(dtype, (pos_sine_kernel<u16><<<N, 128, 0, st>>>(mask, (u16*)pos, h, w, npf, temperature)),
+              (pos_sine_kernel<float><<<N, 128, 0, st>>>(mask, (float*)pos, h, w, npf, temperature)), "td_pos_sine");
+  return check_launch("td_pos_sine");
+}

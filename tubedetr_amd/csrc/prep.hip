@@ -1,0 +1,154 @@
+// Layout / precision preparation kernels: FrozenBatchNorm folding into conv weights, weight-gradient
+// un-folding, NCHW<->NHWC conversion, dtype casts.  All HBM-bound, one pass each.
+// Reference call sites: models/backbone.py:60-70 (FrozenBatchNorm2d.forward), engine.py:55 (NCHW fp32
+// frames handed over by the data loader), models/backbone.py:98 (features returned as NCHW).
+#include "td_common.h"
+
+namespace td {
+
+template <typename T>
+__global__ void weight_prep_kernel(const float* W, const float* bn_w, const float* bn_b, const float* bn_rm,
+                                   const float* bn_rv, const float* bias, int Co, int Ci, int R, int S, int Cpad,
+                                   T* w_fwd, T* w_dgrad, float* bias_out, float* scale_out) {
+  const size_t nf = (size_t)Co * R * S * Cpad;
+  const size_t nd = w_dgrad ? (size_t)Ci * R * S * Co : 0;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < nf) {
+    int ci = idx % Cpad;
+    size_t t = idx / Cpad;
+    int s = t % S; t /= S;
+    int r = t % R;
+    int co = t / R;
+    float sc = bn_w ? bn_w[co] * rsqrtf(bn_rv[co] + 1e-5f) : 1.f;
+    float v = ci < Ci ? W[(((size_t)co * Ci + ci) * R + r) * S + s] * sc : 0.f;
+    Elem<T>::store(w_fwd, idx, v);
+  } else if (idx - nf < nd) {
+    size_t j = idx - nf;
+    int co = j % Co;
+    size_t t = j / Co;
+    int s = t % S; t /= S;
+    int r = t % R;
+    int ci = t / R;
+    float sc = bn_w ? bn_w[co] * rsqrtf(bn_rv[co] + 1e-5f) : 1.f;
+    Elem<T>::store(w_dgrad, j, W[(((size_t)co * Ci + ci) * R + r) * S + s] * sc);
+  }
+  if (idx < (size_t)Co) {
+    int co = (int)idx;
+    float sc = bn_w ? bn_w[co] * rsqrtf(bn_rv[co] + 1e-5f) : 1.f;
+    if (scale_out) scale_out[co] = sc;
+    if (bias_out) bias_out[co] = bn_w ? (bn_b[co] - bn_rm[co] * sc) : (bias ? bias[co] : 0.f);
+  }
+}
+
+__global__ void wgrad_finalize_kernel(const float* dw_k, const float* scale, float* dW, int Co, int Ci, int R, int S,
+                                      int Cpad, int accumulate) {
+  const size_t n = (size_t)Co * Ci * R * S;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  int s = idx % S;
+  size_t t = idx / S;
+  int r = t % R; t /= R;
+  int ci = t % Ci;
+  int co = t / Ci;
+  float v = dw_k[(((size_t)co * R + r) * S + s) * Cpad + ci] * (scale ? scale[co] : 1.f);
+  dW[idx] = accumulate ? dW[idx] + v : v;
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int N, int C, int H, int W, int Cpad) {
+  const size_t n = (size_t)N * H * W;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const size_t hw = (size_t)H * W;
+  const size_t img = idx / hw, p = idx - img * hw;
+  for (int c = 0; c < Cpad; ++c) {
+    float v = c < C ? x[(img * C + c) * hw + p] : 0.f;
+    Elem<T>::store(y, idx * Cpad + c, v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* x, float* y, int N, int C, int H, int W) {
+  const size_t n = (size_t)N * C * H * W;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const size_t hw = (size_t)H * W;
+  size_t p = idx % hw;
+  size_t t = idx / hw;
+  int c = t % C;
+  size_t img = t / C;
+  y[idx] = Elem<T>::load(x, (img * hw + p) * C + c);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* x, TD* y, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) Elem<TD>::store(y, i, Elem<TS>::load(x, i));
+}
+
+}  // namespace td
+using namespace td;
+
+static inline unsigned nblk(size_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" int td_weight_prep(const float* W, const float* bn_w, const float* bn_b, const float* bn_rm,
+                              const float* bn_rv, const float* bias, int Co, int Ci, int R, int S, int Cpad,
+                              void* w_fwd, void* w_dgrad, float* bias_out, float* scale_out, int dtype,
+                              td_stream_t stream) {
+  TD_REQUIRE(W && w_fwd, "td_weight_prep: null pointer");
+  TD_REQUIRE(Cpad >= Ci, "td_weight_prep: Cpad < Ci");
+  TD_REQUIRE(!bn_w || (bn_b && bn_rm && bn_rv), "td_weight_prep: incomplete FrozenBN buffers");
+  size_t n = (size_t)Co * R * S * Cpad + (w_dgrad ? (size_t)Ci * R * S * Co : 0);
+  if (n < (size_t)Co) n = Co;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16)
+    weight_prep_kernel<u16><<<nblk(n), 256, 0, st>>>(W, bn_w, bn_b, bn_rm, bn_rv, bias, Co, Ci, R, S, Cpad, (u16*)w_fwd,
+                                                     (u16*)w_dgrad, bias_out, scale_out);
+  else if (dtype == TD_F32)
+    weight_prep_kernel<float><<<nblk(n), 256, 0, st>>>(W, bn_w, bn_b, bn_rm, bn_rv, bias, Co, Ci, R, S, Cpad,
+                                                       (float*)w_fwd, (float*)w_dgrad, bias_out, scale_out);
+  else TD_REQUIRE(false, "td_weight_prep: bad dtype");
+  return check_launch("td_weight_prep");
+}
+
+extern "C" int td_wgrad_finalize(const float* dw_k, const float* scale, float* dW, int Co, int Ci, int R, int S,
+                                 int Cpad, int accumulate, td_stream_t stream) {
+  TD_REQUIRE(dw_k && dW, "td_wgrad_finalize: null pointer");
+  size_t n = (size_t)Co * Ci * R * S;
+  wgrad_finalize_kernel<<<nblk(n), 256, 0, (hipStream_t)stream>>>(dw_k, scale, dW, Co, Ci, R, S, Cpad, accumulate);
+  return check_launch("td_wgrad_finalize");
+}
+
+extern "C" int td_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype,
+                               td_stream_t stream) {
+  TD_REQUIRE(x && y && Cpad >= C, "td_nchw_to_nhwc: bad arguments");
+  size_t n = (size_t)N * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16) nchw_to_nhwc_kernel<u16><<<nblk(n), 256, 0, st>>>(x, (u16*)y, N, C, H, W, Cpad);
+  else nchw_to_nhwc_kernel<float><<<nblk(n), 256, 0, st>>>(x, (float*)y, N, C, H, W, Cpad);
+  return check_launch("td_nchw_to_nhwc");
+}
+
+extern "C" int td_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int dtype, td_stream_t stream) {
+  TD_REQUIRE(x && y, "td_nhwc_to_nchw: null pointer");
+  size_t n = (size_t)N * C * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16) nhwc_to_nchw_kernel<u16><<<nblk(n), 256, 0, st>>>((const u16*)x, y, N, C, H, W);
+  else nhwc_to_nchw_kernel<float><<<nblk(n), 256, 0, st>>>((const float*)x, y, N, C, H, W);
+  return check_launch("td_nhwc_to_nchw");
+}
+
+extern "C" int td_cast(const void* x, void* y, size_t n, int src_dtype, int dst_dtype, td_stream_t stream) {
+  TD_REQUIRE(x && y, "td_cast: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned g = nblk(n);
+  if (g > 4096) g = 4096;
+  if (g == 0) return TD_OK;
+  if (src_dtype == TD_F32 && dst_dtype == TD_BF16) cast_kernel<float, u16><<<g, 256, 0, st>>>((const float*)x, (u16*)y, n);
+  else if (src_dtype == TD_BF16 && dst_dtype == TD_F32) cast_kernel<u16, float><<<g, 256, 0, st>>>((const u16*)x, (float*)y, n);
+  else if (src_dtype == TD_F32 && dst_dtype == TD_F32) cast_kernel<float, float><<<g, 256, 0, st>>>((const float*)x, (float*)y, n);
+  else if (src_dtype == TD_BF16 && dst_dtype == TD_BF16) cast_kernel<u16, u16><<<g, 256, 0, st>>>((const u16*)x, (u16*)y, n);
+  else TD_REQUIRE(false, "td_cast: bad dtype");
+  return check_launch("td_cast");
+}

@@ -1,0 +1,247 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see functional.py).
+
+Every function launches hand-written gfx950 kernels on the current HIP stream.  Activations are
+NHWC / row-major in the compute dtype (torch.float32 = exact-fp32 parity mode, torch.bfloat16 =
+throughput mode).  There is no CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _hip
+from ._hip import ConvDesc, Epilogue, check, dtype_code, ptr, stream_ptr
+
+Tensor = torch.Tensor
+
+
+def vec_of(dt: torch.dtype) -> int:
+    return 8 if dt == torch.bfloat16 else 4
+
+
+def pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def conv_out(h: int, k: int, stride: int, pad: int) -> int:
+    return (h + 2 * pad - k) // stride + 1
+
+
+def _desc(N, Hs, Ws, Cs, Ho, Wo, R, S, stride, pad, mode, Nc, ldc, out_sp=1, out_H=0, out_W=0) -> ConvDesc:
+    return ConvDesc(N, Hs, Ws, Cs, Ho, Wo, R, S, stride, pad, mode, Nc, ldc, out_sp, out_H, out_W)
+
+
+def _epi(bias=None, residual=None, mask_src=None, relu=False, sigmoid=False, dropout_p=0.0, seed=0, alpha=1.0) -> Epilogue:
+    return Epilogue(ptr(bias), ptr(residual), ptr(mask_src), int(relu), int(sigmoid), float(dropout_p), int(seed) & 0xFFFFFFFF, float(alpha))
+
+
+def conv_gemm_raw(src: Tensor, w: Tensor, out: Tensor, desc: ConvDesc, epi: Optional[Epilogue]):
+    check(_hip.lib().td_conv_gemm(ptr(src), ptr(w), ptr(out), C.byref(desc), C.byref(epi) if epi is not None else None,
+                                  dtype_code(src.dtype), stream_ptr()), "td_conv_gemm")
+
+
+def conv_fwd(x: Tensor, w_fwd: Tensor, bias: Optional[Tensor], R: int, S: int, stride: int, pad: int, *,
+             residual: Optional[Tensor] = None, relu: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """x [N,H,W,C] (NHWC), w_fwd [Co, R*S*C]  ->  y [N,Ho,Wo,Co] = relu(conv(x) + bias + residual)."""
+    N, H, W, Cs = x.shape
+    Co = w_fwd.shape[0]
+    assert w_fwd.shape[1] == R * S * Cs and w_fwd.dtype == x.dtype and x.is_contiguous() and w_fwd.is_contiguous()
+    Ho, Wo = conv_out(H, R, stride, pad), conv_out(W, S, stride, pad)
+    y = out if out is not None else torch.empty((N, Ho, Wo, Co), dtype=x.dtype, device=x.device)
+    conv_gemm_raw(x, w_fwd, y, _desc(N, H, W, Cs, Ho, Wo, R, S, stride, pad, 0, Co, Co), _epi(bias, residual, None, relu))
+    return y
+
+
+def conv_dgrad(g: Tensor, w_dgrad: Tensor, in_hw: Tuple[int, int], R: int, S: int, stride: int, pad: int, *,
+               residual: Optional[Tensor] = None, mask_src: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """g [N,Ho,Wo,Co] = grad of the conv output, w_dgrad [Ci, R*S*Co]  ->  dx [N,H,W,Ci] (+residual, masked)."""
+    N, Hg, Wg, Co = g.shape
+    H, W = in_hw
+    Ci = w_dgrad.shape[0]
+    assert w_dgrad.shape[1] == R * S * Co and g.is_contiguous()
+    dx = out if out is not None else torch.empty((N, H, W, Ci), dtype=g.dtype, device=g.device)
+    conv_gemm_raw(g, w_dgrad, dx, _desc(N, Hg, Wg, Co, H, W, R, S, stride, pad, 1, Ci, Ci), _epi(None, residual, mask_src))
+    return dx
+
+
+def conv1x1s_dgrad_scatter(g: Tensor, w_dgrad: Tensor, dx: Tensor, stride: int, *, mask_src: Optional[Tensor] = None):
+    """Input gradient of a strided 1x1 conv, accumulated in place: dx[n, ho*s, wo*s, :] = (dx + g @ W) (masked).
+    Positions not hit by the stride keep dx but still need the mask: callers pass mask_src only when dx was
+    already masked or apply the mask themselves."""
+    N, Hg, Wg, Co = g.shape
+    _, H, W, Ci = dx.shape
+    d = _desc(N, Hg, Wg, Co, Hg, Wg, 1, 1, 1, 0, 0, Ci, Ci, stride, H, W)
+    conv_gemm_raw(g, w_dgrad, dx, d, _epi(None, dx, mask_src))
+    return dx
+
+
+def conv_wgrad(g: Tensor, x: Tensor, R: int, S: int, stride: int, pad: int, *, out: Optional[Tensor] = None, splits: int = 0) -> Tensor:
+    """dw_k [Co, R*S*C] fp32 (+)= sum_m g[m][co] * im2col(x)[m][k].  `out` (fp32) is accumulated into."""
+    N, H, W, Cs = x.shape
+    _, Ho, Wo, Co = g.shape
+    dw = out if out is not None else torch.zeros((Co, R * S * Cs), dtype=torch.float32, device=x.device)
+    d = _desc(N, H, W, Cs, Ho, Wo, R, S, stride, pad, 0, Co, Co)
+    check(_hip.lib().td_conv_wgrad(ptr(g), ptr(x), ptr(dw), C.byref(d), Co, dtype_code(x.dtype), splits, stream_ptr()), "td_conv_wgrad")
+    return dw
+
+
+def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, residual=None, relu=False, sigmoid=False,
+               mask_src=None, dropout_p=0.0, seed=0, alpha=1.0, out: Optional[Tensor] = None) -> Tensor:
+    """x [M,K], w [N,K] (K contiguous)  ->  [M,N] = epilogue(alpha * x @ w^T + bias + residual)."""
+    M, K = x.shape
+    Nn = w.shape[0]
+    assert w.shape[1] == K and w.dtype == x.dtype and x.is_contiguous() and w.is_contiguous()
+    y = out if out is not None else torch.empty((M, Nn), dtype=x.dtype, device=x.device)
+    conv_gemm_raw(x, w, y, _desc(1, M, 1, K, M, 1, 1, 1, 1, 0, 0, Nn, Nn), _epi(bias, residual, mask_src, relu, sigmoid, dropout_p, seed, alpha))
+    return y
+
+
+def linear_wgrad(g: Tensor, x: Tensor, *, out: Optional[Tensor] = None, splits: int = 0) -> Tensor:
+    """dW [N,K] fp32 (+)= g^T @ x   with g [M,N], x [M,K]."""
+    M, K = x.shape
+    Nn = g.shape[1]
+    dw = out if out is not None else torch.zeros((Nn, K), dtype=torch.float32, device=x.device)
+    d = _desc(1, M, 1, K, M, 1, 1, 1, 1, 0, 0, Nn, Nn)
+    check(_hip.lib().td_conv_wgrad(ptr(g), ptr(x), ptr(dw), C.byref(d), g.shape[1], dtype_code(x.dtype), splits, stream_ptr()), "td_conv_wgrad")
+    return dw
+
+
+def weight_prep(W: Tensor, dtype: torch.dtype, *, bn=None, bias: Optional[Tensor] = None, need_dgrad: bool = True, cpad: Optional[int] = None):
+    """W fp32 [Co,Ci,R,S] (or [Co,Ci]) -> (w_fwd [Co,R*S*Cpad], w_dgrad [Ci,R*S*Co] | None, bias_out [Co] fp32, scale [Co] fp32).
+    bn = (weight, bias, running_mean, running_var) of a FrozenBatchNorm2d to fold, or None."""
+    if W.dim() == 2:
+        Co, Ci = W.shape
+        R = S = 1
+    else:
+        Co, Ci, R, S = W.shape
+    cp = cpad if cpad is not None else pad_to(Ci, vec_of(dtype))
+    dev = W.device
+    wf = torch.empty((Co, R * S * cp), dtype=dtype, device=dev)
+    wd = torch.empty((Ci, R * S * Co), dtype=dtype, device=dev) if need_dgrad else None
+    b_out = torch.empty(Co, dtype=torch.float32, device=dev) if (bn is not None or bias is not None) else None
+    sc = torch.empty(Co, dtype=torch.float32, device=dev) if bn is not None else None
+    bw, bb, brm, brv = bn if bn is not None else (None, None, None, None)
+    check(_hip.lib().td_weight_prep(ptr(W), ptr(bw), ptr(bb), ptr(brm), ptr(brv), ptr(bias), Co, Ci, R, S, cp, ptr(wf), ptr(wd),
+                                    ptr(b_out), ptr(sc), dtype_code(dtype), stream_ptr()), "td_weight_prep")
+    return wf, wd, b_out, sc
+
+
+def wgrad_finalize(dw_k: Tensor, scale: Optional[Tensor], shape, cpad: int, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    Co, Ci, R, S = shape
+    dW = out if out is not None else torch.empty(shape, dtype=torch.float32, device=dw_k.device)
+    check(_hip.lib().td_wgrad_finalize(ptr(dw_k), ptr(scale), ptr(dW), Co, Ci, R, S, cpad, int(accumulate), stream_ptr()), "td_wgrad_finalize")
+    return dW
+
+
+def nchw_to_nhwc(x: Tensor, dtype: torch.dtype, cpad: int) -> Tensor:
+    N, Cc, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty((N, H, W, cpad), dtype=dtype, device=x.device)
+    check(_hip.lib().td_nchw_to_nhwc(ptr(x), ptr(y), N, Cc, H, W, cpad, dtype_code(dtype), stream_ptr()), "td_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: Tensor) -> Tensor:
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+    check(_hip.lib().td_nhwc_to_nchw(ptr(x), ptr(y), N, Cc, H, W, dtype_code(x.dtype), stream_ptr()), "td_nhwc_to_nchw")
+    return y
+
+
+def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(_hip.lib().td_cast(ptr(x.contiguous()), ptr(y), x.numel(), dtype_code(x.dtype), dtype_code(dtype), stream_ptr()), "td_cast")
+    return y
+
+
+def maxpool3x3s2(x: Tensor) -> Tensor:
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1), Cc), dtype=x.dtype, device=x.device)
+    check(_hip.lib().td_maxpool3x3s2(ptr(x), ptr(y), N, H, W, Cc, dtype_code(x.dtype), stream_ptr()), "td_maxpool3x3s2")
+    return y
+
+
+def add_layernorm_fwd(x: Tensor, r: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float, save: bool = True):
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if (save and r is not None) else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    check(_hip.lib().td_add_layernorm_fwd(ptr(x), ptr(r), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd), rows, cols, eps,
+                                          dtype_code(x.dtype), stream_ptr()), "td_add_layernorm_fwd")
+    return y, (s if r is not None else x), mean, rstd
+
+
+def add_layernorm_bwd(dy: Tensor, s: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, extra: Optional[Tensor] = None):
+    rows, cols = dy.shape
+    ds = torch.empty_like(dy)
+    dgamma = torch.zeros(cols, dtype=torch.float32, device=dy.device)
+    dbeta = torch.zeros(cols, dtype=torch.float32, device=dy.device)
+    check(_hip.lib().td_add_layernorm_bwd(ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(extra), ptr(ds), ptr(dgamma), ptr(dbeta),
+                                          rows, cols, dtype_code(dy.dtype), stream_ptr()), "td_add_layernorm_bwd")
+    return ds, dgamma, dbeta
+
+
+def colsum(g: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    rows, cols = g.shape
+    o = out if out is not None else torch.zeros(cols, dtype=torch.float32, device=g.device)
+    check(_hip.lib().td_colsum(ptr(g), ptr(o), rows, cols, cols, dtype_code(g.dtype), stream_ptr()), "td_colsum")
+    return o
+
+
+def add(a: Tensor, b: Optional[Tensor]) -> Tensor:
+    y = torch.empty_like(a)
+    check(_hip.lib().td_add(ptr(a), ptr(b), ptr(y), a.numel(), dtype_code(a.dtype), stream_ptr()), "td_add")
+    return y
+
+
+def relu_bwd(dy: Tensor, y: Tensor, scale: float = 1.0) -> Tensor:
+    g = torch.empty_like(dy)
+    check(_hip.lib().td_relu_bwd(ptr(dy), ptr(y), ptr(g), dy.numel(), scale, dtype_code(dy.dtype), stream_ptr()), "td_relu_bwd")
+    return g
+
+
+def pos_sine(mask: Tensor, npf: int, dtype: torch.dtype, temperature: float = 10000.0) -> Tensor:
+    """mask (N,h,w) bool/uint8 -> pos [N, h*w, 2*npf]."""
+    N, h, w = mask.shape
+    m8 = mask.to(torch.uint8).contiguous()
+    pos = torch.empty((N, h * w, 2 * npf), dtype=dtype, device=mask.device)
+    check(_hip.lib().td_pos_sine(ptr(m8), ptr(pos), N, h, w, npf, temperature, dtype_code(dtype), stream_ptr()), "td_pos_sine")
+    return pos
+
+
+def mha_fwd(q: Tensor, k: Tensor, v: Tensor, key_pad: Optional[Tensor], H: int, scale: float, *, need_wavg: bool = False,
+            dropout_p: float = 0.0, seed: int = 0):
+    """q [B,Lq,>=E] / k,v [B,Lk,>=E] views with unit stride on the last dim and row stride = stride(1)."""
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    hd = E // H
+    for t_ in (q, k, v):
+        assert t_.stride(2) == 1 and t_.stride(0) == t_.shape[1] * t_.stride(1)
+    out = torch.empty((B, Lq, E), dtype=q.dtype, device=q.device)
+    probs = torch.empty((B, H, Lq, Lk), dtype=torch.float32, device=q.device)
+    wavg = torch.empty((B, Lq, Lk), dtype=torch.float32, device=q.device) if need_wavg else None
+    kp = key_pad.to(torch.uint8).contiguous() if key_pad is not None else None
+    check(_hip.lib().td_mha_fwd(ptr(q), ptr(k), ptr(v), ptr(kp), ptr(out), ptr(probs), ptr(wavg), B, H, Lq, Lk, hd, q.stride(1), k.stride(1),
+                                v.stride(1), E, scale, dropout_p, seed & 0xFFFFFFFF, dtype_code(q.dtype), stream_ptr()), "td_mha_fwd")
+    return out, probs, wavg
+
+
+def mha_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, probs: Tensor, dwavg: Optional[Tensor], H: int, scale: float, *,
+            dropout_p: float = 0.0, seed: int = 0):
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    hd = E // H
+    dq = torch.empty((B, Lq, E), dtype=q.dtype, device=q.device)
+    dk = torch.empty((B, Lk, E), dtype=q.dtype, device=q.device)
+    dv = torch.empty((B, Lk, E), dtype=q.dtype, device=q.device)
+    ws = torch.empty_like(probs)
+    assert dout.is_contiguous()
+    check(_hip.lib().td_mha_bwd(ptr(q), ptr(k), ptr(v), ptr(dout), ptr(probs), ptr(dwavg), ptr(dq), ptr(dk), ptr(dv), ptr(ws), B, H, Lq, Lk, hd,
+                                q.stride(1), k.stride(1), v.stride(1), E, scale, dropout_p, seed & 0xFFFFFFFF, dtype_code(q.dtype), stream_ptr()),
+          "td_mha_bwd")
+    return dq, dk, dv
