@@ -113,6 +113,10 @@ int td_add(const void* a, const void* b, void* y, size_t n, int dtype, td_stream
 /* g = dy * scale where y > 0 else 0   (ReLU / ReLU+dropout backward from the saved output y). */
 int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, float scale, int dtype, td_stream_t stream);
 
+/* y[i] = keep(seed, i) ? x[i] / (1-p) : 0 - the same counter-based mask as the fused epilogues
+ * (element index i = row*ld + col), used standalone and to re-apply the mask in backward. */
+int td_dropout(const void* x, void* y, size_t n, float p, uint32_t seed, int dtype, td_stream_t stream);
+
 /* PositionEmbeddingSine (models/position_encoding.py:71-94, normalize=True, scale=2pi) from a
  * (N,h,w) uint8 pad mask -> pos [N][h*w][2*npf] T  (token-major, the layout the encoder consumes). */
 int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, float temperature, int dtype,
@@ -130,7 +134,7 @@ int td_mha_fwd(const void* q, const void* k, const void* v, const uint8_t* key_p
                float dropout_p, uint32_t dropout_seed, int dtype, td_stream_t stream);
 /* Backward of td_mha_fwd.  dwavg [B][Lq][Lk] fp32 = gradient of the head-averaged weights
  * (guided-attention loss, models/tubedetr.py:357-369) or NULL; ds_ws: fp32 workspace [B][H][Lq][Lk].
- * dout, dq, dk, dv are dense rows of stride ldo (= H*hd). */
+ * dq, dk, dv are written with the row strides of q, k, v (ldq, ldk, ldv); dout has row stride ldo. */
 int td_mha_bwd(const void* q, const void* k, const void* v, const void* dout, const float* probs, const float* dwavg,
                void* dq, void* dk, void* dv, float* ds_ws, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk,
                int ldv, int ldo, float scale, float dropout_p, uint32_t dropout_seed, int dtype, td_stream_t stream);

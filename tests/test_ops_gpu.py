@@ -263,7 +263,7 @@ def test_mha_core_fwd_bwd(cfg, dt):
     assert rel_err(out, out_ref) < TOL[dt]
     assert rel_err(wavg, wavg_ref) < 1e-4
     assert torch.equal(wavg.argmax(-1).cpu(), wavg_ref.argmax(-1))
-    dq, dk, dv = ops.mha_bwd(qd, kd, vd, dout.to(dev(), dt), probs, dwavg.to(dev()), H, scale)
+    dq, dk, dv = ops.mha_bwd(qd, kd, vd, dout.to(dev(), dt), probs, dwavg.to(dev()), H, scale, torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd))
     for got, ref in ((dq, qr.grad), (dk, kr.grad), (dv, vr.grad)):
         assert rel_err(got, ref) < TOL[dt]
 

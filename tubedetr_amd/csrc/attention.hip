@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(MhaParams p) {
     float acc = 0.f;
     for (int kk = half; kk < Lk; kk += 2) acc += myP[kk] * sA[kk * 33 + d];
     acc += __shfl_xor(acc, 32, 64);
-    if (half == 0) Elem<T>::store(p.dq, (size_t)(b * Lq + qi) * p.ldo + h * HD + d, acc * p.scale);
+    if (half == 0) Elem<T>::store(p.dq, (size_t)(b * Lq + qi) * p.ldq + h * HD + d, acc * p.scale);
     LDS_FENCE();
   }
   __syncthreads();  // K,V no longer needed; ds_ws rows written by this workgroup are visible to it
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(MhaParams p) {
         dV[4 * d4 + 0] += pr * o.x; dV[4 * d4 + 1] += pr * o.y; dV[4 * d4 + 2] += pr * o.z; dV[4 * d4 + 3] += pr * o.w;
       }
     }
-    const size_t ko = (size_t)(b * Lk + kk) * p.ldo + h * HD, vo = ko;  // gradients are dense (row stride ldo)
+    const size_t ko = (size_t)(b * Lk + kk) * p.ldk + h * HD, vo = (size_t)(b * Lk + kk) * p.ldv + h * HD;
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
       Elem<T>::store(p.dk, ko + d, dK[d] * p.scale);

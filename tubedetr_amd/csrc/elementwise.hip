@@ -170,6 +170,13 @@ __global__ void relu_bwd_kernel(const T* dy, const T* y, T* g, size_t n, float s
   for (; i < n; i += stride) Elem<T>::store(g, i, Elem<T>::load(y, i) > 0.f ? Elem<T>::load(dy, i) * scale : 0.f);
 }
 
+template <typename T>
+__global__ void dropout_kernel(const T* x, T* y, size_t n, uint32_t thresh, float scale, uint32_t seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) Elem<T>::store(y, i, dropout_keep(seed, (uint32_t)i, thresh) ? Elem<T>::load(x, i) * scale : 0.f);
+}
+
 // one block per image; thread per (y,x) token, loops over channels
 template <typename T>
 __global__ void pos_sine_kernel(const uint8_t* mask, T* pos, int h, int w, int npf, float temperature) {
@@ -285,6 +292,21 @@ extern "C" int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, flo
   TD_DISPATCH(dtype, (relu_bwd_kernel<u16><<<gr, 256, 0, st>>>((const u16*)dy, (const u16*)y, (u16*)g, n, scale)),
               (relu_bwd_kernel<float><<<gr, 256, 0, st>>>((const float*)dy, (const float*)y, (float*)g, n, scale)), "td_relu_bwd");
   return check_launch("td_relu_bwd");
+}
+
+extern "C" int td_dropout(const void* x, void* y, size_t n, float p, uint32_t seed, int dtype, td_stream_t stream) {
+  TD_REQUIRE(x && y, "td_dropout: null pointer");
+  TD_REQUIRE(p >= 0.f && p < 1.f, "td_dropout: p out of range");
+  if (n == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned gr = nblk(n);
+  if (gr > 4096) gr = 4096;
+  uint32_t thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
+  if (p > 0.f && !thresh) thresh = 1;
+  float scale = 1.f / (1.f - p);
+  TD_DISPATCH(dtype, (dropout_kernel<u16><<<gr, 256, 0, st>>>((const u16*)x, (u16*)y, n, thresh, scale, seed)),
+              (dropout_kernel<float><<<gr, 256, 0, st>>>((const float*)x, (float*)y, n, thresh, scale, seed)), "td_dropout");
+  return check_launch("td_dropout");
 }
 
 extern "C" int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, float temperature, int dtype,

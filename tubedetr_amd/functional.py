@@ -1,0 +1,280 @@
+"""torch.autograd.Function wrappers: forward AND backward of every op on the hot path run through the
+hand-written gfx950 kernels (ops.py -> C ABI).  No torch compute kernels are used for the math here;
+torch only owns the memory and the autograd graph.
+
+All activation tensors are 2-D row-major [rows, channels] (batch-major tokens) or NHWC, in the compute
+dtype of the model (torch.float32 = exact-fp32 parity mode, torch.bfloat16 = throughput mode).
+Parameters stay fp32 (the reference's state_dict); per-step prepared copies (cast / transposed /
+FrozenBN-folded) are cached on the parameter's version counter.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+Tensor = torch.Tensor
+
+_PREP_CACHE: dict = {}
+
+
+def prepared(W: Tensor, dtype: torch.dtype, *, bn=None, need_dgrad: bool = True, cpad: Optional[int] = None, pad_out: int = 0):
+    """(w_fwd, w_dgrad, bias_fold, scale) for parameter W, cached until W (or the BN buffers) change."""
+    key = (W.data_ptr(), tuple(W.shape), dtype, need_dgrad, cpad, pad_out)
+    ver = (W._version,) + (tuple(b._version for b in bn) if bn is not None else ())
+    hit = _PREP_CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    Wd = W.detach()
+    if pad_out and Wd.shape[0] < pad_out:  # tiny output layers (4 box coords, 2 start/end logits) are padded to the vector width
+        Wp = torch.zeros((pad_out,) + tuple(Wd.shape[1:]), dtype=Wd.dtype, device=Wd.device)
+        Wp[: Wd.shape[0]] = Wd
+        Wd = Wp
+    res = ops.weight_prep(Wd.contiguous(), dtype, bn=[b.detach() for b in bn] if bn is not None else None, need_dgrad=need_dgrad, cpad=cpad)
+    _PREP_CACHE[key] = (ver, res)
+    return res
+
+
+def clear_prepared_cache():
+    _PREP_CACHE.clear()
+
+
+def _seed() -> int:
+    """Fresh dropout seed from torch's CPU generator (so torch.manual_seed controls it)."""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+class LinearFn(Function):
+    """y = dropout(act(x @ W^T + b)); act in {none, relu}.  x [M,K], W fp32 [N,K], b fp32 [N]."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu: bool, dropout_p: float, seed: int):
+        N = W.shape[0]
+        vec = ops.vec_of(x.dtype)
+        Np = ops.pad_to(N, vec)
+        wf, wd, _, _ = prepared(W, x.dtype, pad_out=Np if Np != N else 0)
+        bias = b.detach() if b is not None else None
+        if bias is not None and Np != N:
+            bias = torch.cat([bias, bias.new_zeros(Np - N)])
+        y = ops.linear_fwd(x, wf, bias, relu=relu, dropout_p=dropout_p, seed=seed)
+        ctx.save_for_backward(x, y if (relu or dropout_p > 0) else None, wd)
+        ctx.cfg = (relu, dropout_p, seed, N, Np, b is not None)
+        return y[:, :N].contiguous() if Np != N else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, wd = ctx.saved_tensors
+        relu, p, seed, N, Np, has_b = ctx.cfg
+        dy = dy.contiguous()
+        if Np != N:
+            g = dy.new_zeros((dy.shape[0], Np))
+            g[:, :N] = dy
+            dy = g
+        if relu:
+            g = ops.relu_bwd(dy, y, 1.0 / (1.0 - p) if p > 0 else 1.0)  # y > 0 <=> kept and active
+        elif p > 0:
+            g = ops.dropout(dy, p, seed)
+        else:
+            g = dy
+        dx = ops.linear_fwd(g, wd) if ctx.needs_input_grad[0] else None
+        dW = ops.linear_wgrad(g, x)[:N] if ctx.needs_input_grad[1] else None
+        db = ops.colsum(g)[:N] if (has_b and ctx.needs_input_grad[2]) else None
+        return dx, dW, db, None, None, None
+
+
+def linear(x, W, b=None, relu=False, dropout_p=0.0, training=False):
+    p = dropout_p if training else 0.0
+    return LinearFn.apply(x, W, b, relu, p, _seed() if p > 0 else 0)
+
+
+class FFNFn(Function):
+    """y = dropout2(relu_dropout(x W1^T + b1) W2^T + b2)   (models/transformer.py:643,748)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, p: float, seed1: int, seed2: int):
+        w1f, w1d, _, _ = prepared(W1, x.dtype)
+        w2f, w2d, _, _ = prepared(W2, x.dtype)
+        h = ops.linear_fwd(x, w1f, b1.detach(), relu=True, dropout_p=p, seed=seed1)
+        y = ops.linear_fwd(h, w2f, b2.detach(), dropout_p=p, seed=seed2)
+        ctx.save_for_backward(x, h, w1d, w2d)
+        ctx.cfg = (p, seed1, seed2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, w1d, w2d = ctx.saved_tensors
+        p, seed1, seed2 = ctx.cfg
+        g2 = ops.dropout(dy.contiguous(), p, seed2) if p > 0 else dy.contiguous()
+        dW2 = ops.linear_wgrad(g2, h)
+        db2 = ops.colsum(g2)
+        # dh = (g2 @ W2) * (h > 0) / (1-p): mask + scale fused in the GEMM epilogue
+        dh = ops.linear_fwd(g2, w2d, mask_src=h, alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
+        dW1 = ops.linear_wgrad(dh, x)
+        db1 = ops.colsum(dh)
+        dx = ops.linear_fwd(dh, w1d) if ctx.needs_input_grad[0] else None
+        return dx, dW1, db1, dW2, db2, None, None, None
+
+
+def ffn(x, W1, b1, W2, b2, dropout_p=0.0, training=False):
+    p = dropout_p if training else 0.0
+    return FFNFn.apply(x, W1, b1, W2, b2, p, _seed() if p > 0 else 0, _seed() if p > 0 else 0)
+
+
+class AddLayerNormFn(Function):
+    """y = LayerNorm(x + r) (r optional)."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps: float):
+        y, s, mean, rstd = ops.add_layernorm_fwd(x, r, gamma.detach(), beta.detach(), eps)
+        ctx.save_for_backward(s, mean, rstd, gamma.detach())
+        ctx.has_r = r is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, mean, rstd, gamma = ctx.saved_tensors
+        ds, dg, db = ops.add_layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma)
+        return ds, (ds if ctx.has_r else None), dg, db, None
+
+
+def add_layernorm(x, r, gamma, beta, eps=1e-5):
+    return AddLayerNormFn.apply(x, r, gamma, beta, eps)
+
+
+class AddFn(Function):
+    """a + b on the elementwise kernel (pos-enc add in front of the Q/K projections)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class MHAFn(Function):
+    """nn.MultiheadAttention forward/backward (packed in_proj, 1/sqrt(hd) scaling, key padding mask, prob dropout,
+    out_proj, head-averaged weights) on batch-major rows.
+
+    q_in [B*Lq, E], k_in [B*Lk, E] (None = same tensor as q_in), v_in [B*Lk, E]; returns (out [B*Lq,E],
+    wavg [B,Lq,Lk] fp32 or None).  The optional ``out_dropout`` is the residual-branch dropout that follows the
+    attention in the reference layers (dropout1 / dropout3), fused into the out_proj epilogue."""
+
+    @staticmethod
+    def forward(ctx, q_in, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_w, p_attn, seed_attn, p_out, seed_out):
+        E = q_in.shape[1]
+        dt = q_in.dtype
+        same_qk = k_in is None  # self-attention with q = k = x + pos: one fused [rows, 2E] projection
+        bi = b_in.detach()
+        if same_qk:
+            wqk_f, wqk_d, _, _ = prepared(W_in[: 2 * E], dt)
+            qk = ops.linear_fwd(q_in, wqk_f, bi[: 2 * E]).view(B, Lq, 2 * E)
+            q, k = qk[..., :E], qk[..., E:]
+            wd_list = (wqk_d,)
+        else:
+            wq_f, wq_d, _, _ = prepared(W_in[:E], dt)
+            wk_f, wk_d, _, _ = prepared(W_in[E : 2 * E], dt)
+            q = ops.linear_fwd(q_in, wq_f, bi[:E]).view(B, Lq, E)
+            k = ops.linear_fwd(k_in, wk_f, bi[E : 2 * E]).view(B, Lk, E)
+            wd_list = (wq_d, wk_d)
+        wv_f, wv_d, _, _ = prepared(W_in[2 * E :], dt)
+        v = ops.linear_fwd(v_in, wv_f, bi[2 * E :]).view(B, Lk, E)
+        scale = 1.0 / math.sqrt(E // H)
+        ctxv, probs, wavg = ops.mha_fwd(q, k, v, key_pad, H, scale, need_wavg=need_w, dropout_p=p_attn, seed=seed_attn)
+        wo_f, wo_d, _, _ = prepared(W_out, dt)
+        out = ops.linear_fwd(ctxv.view(B * Lq, E), wo_f, b_out.detach(), dropout_p=p_out, seed=seed_out)
+        ctx.save_for_backward(q_in, k_in, v_in, q, k, v, probs, ctxv, wv_d, wo_d, *wd_list)
+        ctx.cfg = (B, Lq, Lk, H, E, same_qk, scale, p_attn, seed_attn, p_out, seed_out)
+        return out, (wavg if need_w else None)
+
+    @staticmethod
+    def backward(ctx, dout, dwavg):
+        q_in, k_in, v_in, q, k, v, probs, ctxv, wv_d, wo_d, *wd_list = ctx.saved_tensors
+        B, Lq, Lk, H, E, same_qk, scale, p_attn, seed_attn, p_out, seed_out = ctx.cfg
+        dt = q_in.dtype
+        dev = q_in.device
+        g = ops.dropout(dout.contiguous(), p_out, seed_out) if p_out > 0 else dout.contiguous()
+        dW_in = torch.zeros((3 * E, E), dtype=torch.float32, device=dev)
+        db_in = torch.zeros(3 * E, dtype=torch.float32, device=dev)
+        dW_out = ops.linear_wgrad(g, ctxv.view(B * Lq, E))
+        db_out = ops.colsum(g)
+        dctx = ops.linear_fwd(g, wo_d).view(B, Lq, E)
+        if same_qk:
+            dqk = torch.empty((B, Lq, 2 * E), dtype=dt, device=dev)
+            dq, dk = dqk[..., :E], dqk[..., E:]
+        else:
+            dq = torch.empty((B, Lq, E), dtype=dt, device=dev)
+            dk = torch.empty((B, Lk, E), dtype=dt, device=dev)
+        dv = torch.empty((B, Lk, E), dtype=dt, device=dev)
+        dwa = dwavg.contiguous().float() if dwavg is not None else None
+        ops.mha_bwd(q, k, v, dctx, probs, dwa, H, scale, dq, dk, dv, dropout_p=p_attn, seed=seed_attn)
+        dv2 = dv.view(B * Lk, E)
+        ops.linear_wgrad(dv2, v_in, out=dW_in[2 * E :])
+        ops.colsum(dv2, out=db_in[2 * E :])
+        d_v_in = ops.linear_fwd(dv2, wv_d) if ctx.needs_input_grad[2] else None
+        d_q_in = d_k_in = None
+        if same_qk:
+            dqk2 = dqk.view(B * Lq, 2 * E)
+            ops.linear_wgrad(dqk2, q_in, out=dW_in[: 2 * E])
+            ops.colsum(dqk2, out=db_in[: 2 * E])
+            if ctx.needs_input_grad[0]:
+                d_q_in = ops.linear_fwd(dqk2, wd_list[0])
+        else:
+            dq2, dk2 = dq.view(B * Lq, E), dk.view(B * Lk, E)
+            ops.linear_wgrad(dq2, q_in, out=dW_in[:E])
+            ops.colsum(dq2, out=db_in[:E])
+            ops.linear_wgrad(dk2, k_in, out=dW_in[E : 2 * E])
+            ops.colsum(dk2, out=db_in[E : 2 * E])
+            if ctx.needs_input_grad[0]:
+                d_q_in = ops.linear_fwd(dq2, wd_list[0])
+            if ctx.needs_input_grad[1]:
+                d_k_in = ops.linear_fwd(dk2, wd_list[1])
+        return (d_q_in, d_k_in, d_v_in, dW_in, db_in, dW_out, db_out) + (None,) * 10
+
+
+def multihead_attention(q_in, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_weights=False,
+                        attn_dropout=0.0, out_dropout=0.0, training=False):
+    pa = attn_dropout if training else 0.0
+    po = out_dropout if training else 0.0
+    return MHAFn.apply(q_in, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_weights,
+                       pa, _seed() if pa > 0 else 0, po, _seed() if po > 0 else 0)
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.cfg = (p, seed)
+        return ops.dropout(x.contiguous(), p, seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed = ctx.cfg
+        return ops.dropout(g.contiguous(), p, seed), None, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0:
+        return x
+    return DropoutFn.apply(x, p, _seed())
+
+
+class CastFn(Function):
+    """dtype conversion on the cast kernel (fp32 <-> compute dtype at the module boundary)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.cast(x.contiguous(), dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.cast(g.contiguous(), ctx.src), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else CastFn.apply(x, dtype)

@@ -1,0 +1,77 @@
+"""Minimal training-step driver with the reference's calling protocol (engine.py:55-151): two model calls
+(encode_and_save=True then False), keep-index gather of the annotated frames, time mask, criterion, weighted sum,
+backward.  bench.py, smoke() and the parity tests drive the model through this exactly like engine.py would."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .util.misc import NestedTensor
+
+
+class FixedTokenizer:
+    """Tokenizer stand-in for synthetic clips: returns preset ids (there are no tokenizer files offline)."""
+
+    def __init__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor):
+        self.ids, self.att = input_ids, attention_mask
+
+    def batch_encode_plus(self, text, padding="longest", return_tensors="pt"):
+        from transformers import BatchEncoding
+
+        be = BatchEncoding({"input_ids": self.ids.clone(), "attention_mask": self.att.clone()})
+        be._encodings = [None] * len(text)
+        return be
+
+
+def batch_to(batch: dict, device) -> dict:
+    out = {}
+    for k, v in batch.items():
+        out[k] = v.to(device, non_blocking=True) if torch.is_tensor(v) else v
+    return out
+
+
+def forward_step(model, criterion, weight_dict: Dict[str, float], batch: dict):
+    """batch: frames (n_slow,3,H,W), frames_mask, frames_fast / fast_mask (or None), durations, target_boxes (sum dur, 4),
+    inter_idx; captions come from the model's tokenizer (set a FixedTokenizer for synthetic ids)."""
+    durations: List[int] = batch["durations"]
+    samples = NestedTensor(batch["frames"], batch["frames_mask"])
+    samples_fast = NestedTensor(batch["frames_fast"], batch["fast_mask"]) if batch.get("frames_fast") is not None else None
+    captions = batch.get("captions") or ["synthetic caption"] * len(durations)
+    memory_cache = model(samples, durations, captions, encode_and_save=True, samples_fast=samples_fast)
+    outputs = model(samples, durations, captions, encode_and_save=False, memory_cache=memory_cache)
+    raw = dict(outputs)
+    raw["aux_outputs"] = [dict(a) for a in outputs.get("aux_outputs", [])]
+
+    t = max(durations)
+    dev = outputs["pred_boxes"].device
+    keep = []
+    for i, (_d, inter) in enumerate(zip(durations, batch["inter_idx"])):
+        keep.extend(range(i * t + inter[0], i * t + inter[1] + 1))
+    keep = torch.tensor(keep, dtype=torch.long, device=dev)
+    outputs["pred_boxes"] = outputs["pred_boxes"][keep]
+    for a in outputs.get("aux_outputs", []):
+        a["pred_boxes"] = a["pred_boxes"][keep]
+    time_mask = None
+    if "pred_sted" in outputs:
+        time_mask = torch.zeros(len(durations), t, dtype=torch.bool)
+        for i, d in enumerate(durations):
+            time_mask[i, :d] = True
+        time_mask = time_mask.to(dev)
+    targets = [{"boxes": bx[None]} for bx in batch["target_boxes"]]
+    assert len(targets) == len(outputs["pred_boxes"])
+    loss_dict = criterion(outputs, targets, batch["inter_idx"], time_mask)
+    loss = sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)
+    return loss, loss_dict, raw, memory_cache
+
+
+def train_step(model, criterion, weight_dict, batch, optimizer: Optional[torch.optim.Optimizer] = None, max_norm: float = 0.0):
+    loss, loss_dict, _, _ = forward_step(model, criterion, weight_dict, batch)
+    if optimizer is not None:
+        optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if optimizer is not None:
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        optimizer.step()
+    return loss, loss_dict

@@ -1,0 +1,393 @@
+"""Video-text encoder + space-time decoder behind the reference's ``models.transformer`` interface
+(models/transformer.py:24-176 constructor / init, 178-491 forward, 494-773 layers, 780-801 build).
+
+Same class names, constructor keywords, parameter names (``encoder.layers.0.self_attn.in_proj_weight`` ...)
+and the same two-mode ``forward`` contract (encode -> 9-key memory_cache, decode -> hs / weights /
+cross_weights).  What differs is the engine:
+
+  * every matmul, attention, LayerNorm, residual add and dropout runs in hand-written gfx950 kernels through
+    ``tubedetr_amd.functional`` (forward and backward); torch only builds index tensors and concatenates;
+  * activations are batch-major rows [batch*tokens, 256] in the model's compute dtype; the reference's
+    sequence-first tensors in ``memory_cache`` are zero-copy permuted views of them;
+  * work the reference does and discards is skipped (SURVEY.md 8a': the encoder's attention-weight averaging,
+    transformer.py:346), pos+memory for the cross-attention keys is formed once for all six layers, and the
+    temporal replication / text replication are index gathers built once per (durations) instead of Python loops.
+
+RoBERTa (HF ``RobertaModel``, third party) stays a PyTorch-ROCm module, as in SURVEY.md 8a E2.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from .. import functional as Fk
+from .position_encoding import TimeEmbeddingSine
+
+FAST_MODES_IN_HIP = ("",)
+
+
+class MultiheadAttention(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names / shapes / init; computed by functional.MHAFn."""
+
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)  # holder only (weight, bias)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def run(self, q_in, k_in, v_in, key_pad, B, Lq, Lk, need_weights, out_dropout, training):
+        return Fk.multihead_attention(q_in, k_in, v_in, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight,
+                                      self.out_proj.bias, key_pad, B, Lq, Lk, self.num_heads, need_weights,
+                                      attn_dropout=self.dropout, out_dropout=out_dropout, training=training)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
+        super().__init__()
+        if activation != "relu":
+            raise NotImplementedError("only the reference default activation (relu) is fused in the HIP FFN")
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.p = dropout
+
+    def forward(self, src: Tensor, pos: Optional[Tensor], key_pad: Optional[Tensor], B: int, S: int) -> Tensor:
+        """src, pos: rows [B*S, d] (batch-major); post-norm layer of transformer.py:629-646."""
+        qk = Fk.AddFn.apply(src, pos) if pos is not None else src
+        a, _ = self.self_attn.run(qk, None, src, key_pad, B, S, S, False, self.p, self.training)
+        src = Fk.add_layernorm(a, src, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        f = Fk.ffn(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.p, self.training)
+        return Fk.add_layernorm(f, src, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None, return_weights=False):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_weights = return_weights  # accepted for signature parity; the weights are dead in the reference
+
+    def forward(self, src, key_pad, pos, B, S):
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, key_pad, B, S)
+        if self.norm is not None:
+            out = Fk.add_layernorm(out, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return out
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", no_tsa=False):
+        super().__init__()
+        if activation != "relu":
+            raise NotImplementedError("only relu")
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.cross_attn_image = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.norm4 = nn.LayerNorm(d_model)
+        self.p = dropout
+        self.no_tsa = no_tsa
+
+    def forward(self, tgt, query_pos, mem_k, mem_v, query_mask, memory_mask, b: int, t: int, S: int):
+        """tgt/query_pos rows [b*t, d] (video-major frames); mem_k = memory+pos, mem_v = memory rows [b*t*S, d]
+        (transformer.py:684-751)."""
+        qk = Fk.AddFn.apply(tgt, query_pos)
+        if self.no_tsa:  # every frame attends to itself only: sequence length 1 (transformer.py:701-711)
+            a, w = self.self_attn.run(qk, None, tgt, None, b * t, 1, 1, True, self.p, self.training)
+        else:
+            a, w = self.self_attn.run(qk, None, tgt, query_mask, b, t, t, True, self.p, self.training)
+        tgt = Fk.add_layernorm(a, tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qc = Fk.AddFn.apply(tgt, query_pos)
+        a, cw = self.cross_attn_image.run(qc, mem_k, mem_v, memory_mask, b * t, 1, S, True, self.p, self.training)
+        tgt = Fk.add_layernorm(a, tgt, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        f = Fk.ffn(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.p, self.training)
+        tgt = Fk.add_layernorm(f, tgt, self.norm4.weight, self.norm4.bias, self.norm4.eps)
+        return tgt, w, cw
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False, return_weights=False):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(decoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+        self.return_weights = return_weights
+
+    def forward(self, tgt, query_pos, mem_k, mem_v, query_mask, memory_mask, b, t, S):
+        inter, ws, cws = [], [], []
+        out = tgt
+        for layer in self.layers:
+            out, w, cw = layer(out, query_pos, mem_k, mem_v, query_mask, memory_mask, b, t, S)
+            if self.return_intermediate:
+                inter.append(Fk.add_layernorm(out, None, self.norm.weight, self.norm.bias, self.norm.eps))
+                ws.append(w)
+                cws.append(cw)
+        if not self.return_intermediate:
+            out = Fk.add_layernorm(out, None, self.norm.weight, self.norm.bias, self.norm.eps) if self.norm is not None else out
+            return (out, w, cw) if self.return_weights else out
+        hs = torch.stack(inter)
+        if not self.return_weights:
+            return hs
+        return hs, torch.stack(ws), torch.stack(cws)
+
+
+class FeatureResizer(nn.Module):
+    """fc (768->256) + LayerNorm(eps=1e-12) + dropout (transformer.py:754-773)."""
+
+    def __init__(self, input_feat_size, output_feat_size, dropout, do_ln=True):
+        super().__init__()
+        self.do_ln = do_ln
+        self.fc = nn.Linear(input_feat_size, output_feat_size, bias=True)
+        self.layer_norm = nn.LayerNorm(output_feat_size, eps=1e-12)
+        self.p = dropout
+
+    def forward(self, rows: Tensor) -> Tensor:
+        x = Fk.linear(rows, self.fc.weight, self.fc.bias)
+        if self.do_ln:
+            x = Fk.add_layernorm(x, None, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return Fk.dropout(x, self.p, self.training)
+
+
+class HashTokenizer:
+    """Offline stand-in for RobertaTokenizerFast when no roberta-base files exist on the box: words are hashed
+    into the RoBERTa id range, <s>=0, </s>=2, <pad>=1.  Exposes the one method the model calls."""
+
+    def batch_encode_plus(self, text: List[str], padding="longest", return_tensors="pt"):
+        import zlib
+
+        from transformers import BatchEncoding
+
+        rows = [[0] + [3 + zlib.crc32(w.encode()) % 49990 for w in s.split()] + [2] for s in text]
+        L = max(len(r) for r in rows)
+        ids = torch.tensor([r + [1] * (L - len(r)) for r in rows], dtype=torch.long)
+        att = torch.tensor([[1] * len(r) + [0] * (L - len(r)) for r in rows], dtype=torch.long)
+        be = BatchEncoding({"input_ids": ids, "attention_mask": att})
+        be._encodings = [None] * len(text)
+        return be
+
+
+def _load_text_encoder(name: str):
+    from transformers import RobertaConfig, RobertaModel, RobertaTokenizerFast
+
+    try:
+        tok = RobertaTokenizerFast.from_pretrained(name, local_files_only=True)
+    except Exception:
+        tok = HashTokenizer()
+    try:
+        enc = RobertaModel.from_pretrained(name, local_files_only=True)
+    except Exception:  # no weights offline: roberta-base geometry, random init
+        enc = RobertaModel(RobertaConfig(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5))
+    return tok, enc
+
+
+class Transformer(nn.Module):
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048, dropout=0.1,
+                 activation="relu", return_intermediate_dec=False, pass_pos_and_query=True, text_encoder_type="roberta-base",
+                 freeze_text_encoder=False, video_max_len=0, stride=0, no_tsa=False, return_weights=False, fast=False,
+                 fast_mode="", learn_time_embed=False, rd_init_tsa=False, no_time_embed=False):
+        super().__init__()
+        if not pass_pos_and_query:
+            raise NotImplementedError("pass_pos_and_query=False is an ablation outside the HIP hot path")
+        if learn_time_embed:
+            raise NotImplementedError("learned time embeddings are outside the HIP hot path")
+        if fast and fast_mode not in FAST_MODES_IN_HIP:
+            raise NotImplementedError(f"fast_mode={fast_mode!r}: only the default slow-fast aggregation is implemented in HIP")
+        self.pass_pos_and_query = pass_pos_and_query
+        enc_layer = TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation)
+        self.encoder = TransformerEncoder(enc_layer, num_encoder_layers, None, return_weights=True)
+        dec_layer = TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, activation, no_tsa=no_tsa)
+        self.decoder = TransformerDecoder(dec_layer, num_decoder_layers, nn.LayerNorm(d_model),
+                                          return_intermediate=return_intermediate_dec, return_weights=return_weights)
+        self._reset_parameters()
+        self.return_weights = return_weights
+        self.learn_time_embed = learn_time_embed
+        self.use_time_embed = not no_time_embed
+        if self.use_time_embed:
+            self.time_embed = TimeEmbeddingSine(video_max_len, d_model)
+        self.fast = fast
+        self.fast_mode = fast_mode
+        if fast:
+            self.fast_encoder = nn.Linear(d_model, d_model)
+            self.fast_residual = nn.Linear(d_model, d_model)
+        self.rd_init_tsa = rd_init_tsa
+        self._reset_temporal_parameters()
+        self.tokenizer, self.text_encoder = _load_text_encoder(text_encoder_type)
+        if freeze_text_encoder:
+            for p in self.text_encoder.parameters():
+                p.requires_grad_(False)
+        self.expander_dropout = 0.1
+        self.resizer = FeatureResizer(self.text_encoder.config.hidden_size, d_model, self.expander_dropout)
+        self.d_model, self.nhead = d_model, nhead
+        self.video_max_len, self.stride = video_max_len, stride
+        self.compute_dtype = torch.float32
+        self._idx_cache: dict = {}
+
+    # ---- init (transformer.py:154-176) ----
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def _reset_temporal_parameters(self):
+        for n, p in self.named_parameters():
+            if self.rd_init_tsa and "decoder" in n and "self_attn" in n and p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+            if "fast_residual" in n:
+                nn.init.constant_(p, 0)
+
+    # ---- helpers ----
+    def _indices(self, durations, n_clips_per_video: int, device):
+        """owner clip of every (video, frame) and the per-clip / per-frame video index; cached per durations."""
+        key = (tuple(durations), n_clips_per_video, str(device))
+        hit = self._idx_cache.get(key)
+        if hit is None:
+            b, t, k = len(durations), max(durations), self.stride
+            vid = torch.arange(b)
+            owner = (vid[:, None] * n_clips_per_video + torch.arange(t)[None, :] // k).reshape(-1)
+            hit = (owner.to(device), vid.repeat_interleave(n_clips_per_video).to(device), vid.repeat_interleave(t).to(device))
+            self._idx_cache[key] = hit
+        return hit
+
+    def _encode_text(self, text, device):
+        if isinstance(text[0], str):
+            tokenized = self.tokenizer.batch_encode_plus(text, padding="longest", return_tensors="pt").to(device)
+            enc = self.text_encoder(input_ids=tokenized["input_ids"], attention_mask=tokenized["attention_mask"])
+            hidden = enc.last_hidden_state  # (B, L, 768) fp32
+            Bt, L, _ = hidden.shape
+            rows = Fk.cast(hidden.reshape(Bt * L, -1), self.compute_dtype)
+            resized = self.resizer(rows).view(Bt, L, -1)  # batch-major [B, L, d]
+            return tokenized["attention_mask"].ne(1), resized, tokenized
+        mask, resized_seq_first, tokenized = text  # pre-encoded triple (transformer.py:264-266), (L,B,d)
+        return mask, Fk.cast(resized_seq_first.transpose(0, 1).contiguous(), self.compute_dtype), tokenized
+
+    def forward(self, src=None, mask=None, query_embed=None, pos_embed=None, text=None, encode_and_save=True, durations=None,
+                tpad_mask_t=None, fast_src=None, img_memory=None, query_mask=None, text_memory=None, text_mask=None,
+                memory_mask=None):
+        if encode_and_save:
+            return self._encode(src, mask, query_embed, pos_embed, text, durations, tpad_mask_t, fast_src)
+        return self._decode(img_memory, mask, pos_embed, query_embed, query_mask)
+
+    # ---- encode (transformer.py:195-460) ----
+    def _encode(self, src, mask, query_embed, pos_embed, text, durations, tpad_mask_t, fast_src):
+        if not self.stride:
+            raise NotImplementedError("stride=0 (dense, no temporal sampling) is outside the HIP hot path")
+        n, d, h, w = src.shape  # (n_clips_total, d, h, w) channels-last view of NHWC rows
+        dev, dt = src.device, self.compute_dtype
+        hw = h * w
+        b, t = len(durations), max(durations)
+        n_clips = math.ceil(t / self.stride)
+        assert n == b * n_clips, "every video of the batch must yield the same number of slow clips"
+        src_bm = src.permute(0, 2, 3, 1).reshape(n, hw, d)  # zero-copy when src is channels-last
+        pos_bm = pos_embed.permute(0, 2, 3, 1).reshape(n, hw, d)
+        owner, vid_of_clip, vid_of_frame = self._indices(durations, n_clips, dev)
+
+        # time queries (transformer.py:211-238): identical for every video, video-major rows [b*t, d]
+        nq = query_embed.shape[0]
+        if nq != 1:
+            raise NotImplementedError("num_queries > 1 is outside the HIP hot path")
+        q = query_embed[0].float()
+        qpos_t = (q[None, :] + self.time_embed(t)[:, 0, :]) if self.use_time_embed else q[None, :].expand(t, -1)
+        query_pos_bm = qpos_t[None].expand(b, t, d)  # fp32, autograd reaches query_embed.weight
+        query_mask = torch.ones(b, t, dtype=torch.bool)
+        query_mask[:, 0] = False
+        for i, dur in enumerate(durations):
+            query_mask[i, :dur] = False
+        query_mask = query_mask.to(dev)
+
+        text_attention_mask_orig, text_resized, tokenized = self._encode_text(text, dev)  # [B,L], [B,L,d]
+        L = text_resized.shape[1]
+        assert n_clips == n // text_resized.shape[0] == mask.shape[0] // text_attention_mask_orig.shape[0]
+        text_clip = text_resized[vid_of_clip]  # [n, L, d]
+        text_mask_clip = text_attention_mask_orig[vid_of_clip]
+        self._repeat_tokenized(tokenized, vid_of_clip)
+
+        S = hw + L
+        x = torch.cat([src_bm.to(dt), text_clip], dim=1)  # [n, S, d]
+        pos_full = torch.cat([pos_bm.to(dt), torch.zeros(n, L, d, dtype=dt, device=dev)], dim=1)
+        key_pad = torch.cat([mask.flatten(1), text_mask_clip], dim=1).to(torch.uint8)  # [n, S], 1 = ignore
+        mem = self.encoder(x.reshape(n * S, d), key_pad, pos_full.reshape(n * S, d), n, S).view(n, S, d)
+
+        # temporal replication (transformer.py:393-427): frame (i, j) <- clip i*n_clips + j//k
+        frames_mem = mem[owner]  # [b*t, S, d]
+        frames_pos = pos_full[owner]
+        frame_mask = torch.cat([tpad_mask_t.flatten(1), text_attention_mask_orig[vid_of_frame]], dim=1)  # [b*t, S]
+        frame_mask[:, 0] = False  # "avoid empty masks" (transformer.py:424)
+        if self.fast:  # transformer.py:373-375,387,441-445
+            fs = fast_src.permute(0, 2, 3, 1).reshape(b * t * hw, d)
+            fast_mem = Fk.linear(fs.to(dt), self.fast_encoder.weight, self.fast_encoder.bias).view(b * t, hw, d)
+            vis = frames_mem[:, :hw].reshape(b * t * hw, d)
+            mix = Fk.AddFn.apply(vis, fast_mem.reshape(b * t * hw, d))
+            agg = Fk.linear(mix, self.fast_residual.weight, self.fast_residual.bias)
+            vis = Fk.AddFn.apply(vis, agg).view(b * t, hw, d)
+            frames_mem = torch.cat([vis, frames_mem[:, hw:]], dim=1)
+        return {
+            "text_memory_resized": text_clip.transpose(0, 1),  # (L, n, d) seq-first views like the reference
+            "text_memory": frames_mem[:, hw:].transpose(0, 1),
+            "text_attention_mask": text_mask_clip,
+            "tokenized": tokenized,
+            "img_memory": frames_mem.transpose(0, 1),  # (S, b*t, d)
+            "mask": frame_mask,
+            "pos_embed": frames_pos.transpose(0, 1),
+            "query_embed": query_pos_bm.transpose(0, 1),  # (t, b, d)
+            "query_mask": query_mask,
+        }
+
+    @staticmethod
+    def _repeat_tokenized(tokenized, vid_of_clip):
+        """The reference repeats the BatchEncoding per clip in place (transformer.py:275-308)."""
+        try:
+            idx = vid_of_clip.tolist() if tokenized["input_ids"].device.type == "cpu" else None
+            sel = vid_of_clip.to(tokenized["input_ids"].device)
+            if getattr(tokenized, "_encodings", None) is not None:
+                ids = idx if idx is not None else vid_of_clip.cpu().tolist()
+                tokenized._encodings = [tokenized._encodings[i] for i in ids]
+            tokenized["input_ids"] = tokenized["input_ids"][sel]
+            tokenized["attention_mask"] = tokenized["attention_mask"][sel]
+        except Exception:
+            pass
+
+    # ---- decode (transformer.py:462-491) ----
+    def _decode(self, img_memory, mask, pos_embed, query_embed, query_mask):
+        dt = self.compute_dtype
+        S, bt, d = img_memory.shape
+        t, b, _ = query_embed.shape
+        mem = img_memory.transpose(0, 1).reshape(bt * S, d)  # zero-copy for the cache produced by _encode
+        pos = pos_embed.transpose(0, 1).reshape(bt * S, d)
+        mem = Fk.cast(mem, dt)
+        mem_k = Fk.AddFn.apply(mem, Fk.cast(pos, dt))  # keys = memory + pos, shared by the six layers
+        query_pos = Fk.cast(query_embed.transpose(0, 1).reshape(b * t, d).contiguous(), dt)
+        tgt = torch.zeros_like(query_pos)
+        res = self.decoder(tgt, query_pos, mem_k, mem, query_mask, mask, b, t, S)
+        if self.return_weights:
+            hs, weights, cross_weights = res
+        else:
+            hs = res
+        hs = hs.view(hs.shape[0], b, t, d)  # the reference's hs.transpose(1, 2): (layers, b, t, d)
+        if not self.return_weights:
+            return hs
+        return hs, weights, cross_weights
+
+
+def build_transformer(args):
+    return Transformer(
+        d_model=args.hidden_dim, dropout=args.dropout, nhead=args.nheads, dim_feedforward=args.dim_feedforward,
+        num_encoder_layers=args.enc_layers, num_decoder_layers=args.dec_layers, return_intermediate_dec=True,
+        pass_pos_and_query=args.pass_pos_and_query, text_encoder_type=args.text_encoder_type,
+        freeze_text_encoder=args.freeze_text_encoder, video_max_len=args.video_max_len_train, stride=args.stride,
+        no_tsa=args.no_tsa, return_weights=args.guided_attn, fast=args.fast, fast_mode=args.fast_mode,
+        learn_time_embed=args.learn_time_embed, rd_init_tsa=args.rd_init_tsa, no_time_embed=args.no_time_embed,
+    )

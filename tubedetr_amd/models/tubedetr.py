@@ -1,0 +1,272 @@
+"""TubeDETR top module, heads and criterion behind the reference's ``models.tubedetr`` interface
+(models/tubedetr.py:23-42 MLP, 45-254 TubeDETR, 257-460 SetCriterion, 463-506 build).
+
+``model(samples, durations, captions, encode_and_save=True, samples_fast=...)`` returns the 9-key memory cache,
+``model(..., encode_and_save=False, memory_cache=cache)`` returns pred_boxes / pred_sted / weights / ca_weights /
+aux_outputs exactly like the reference, so engine.py's train_one_epoch / evaluate drive it unchanged.  All
+heavy math runs in the gfx950 kernels (see backbone.py / transformer.py / functional.py); the per-video
+padding bookkeeping the reference does with Python slice loops is a cached index gather here.
+The criterion is small elementwise math on (T,4)/(T,2)/(T,T) tensors and stays PyTorch-ROCm ops (SURVEY.md
+section 2 row 5)."""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import functional as Fk
+from ..util.misc import NestedTensor
+from .backbone import build_backbone
+from .transformer import build_transformer
+
+
+class MLP(nn.Module):
+    """Linear stack with ReLU between layers; optional dropout after EVERY layer incl. the last (tubedetr.py:37-42)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers, dropout=0):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.dropout = dropout
+
+    def forward(self, rows: torch.Tensor) -> torch.Tensor:
+        for i, layer in enumerate(self.layers):
+            rows = Fk.linear(rows, layer.weight, layer.bias, relu=i < self.num_layers - 1,
+                             dropout_p=float(self.dropout or 0.0), training=self.training)
+        return rows
+
+
+class TubeDETR(nn.Module):
+    def __init__(self, backbone, transformer, num_queries, aux_loss=False, video_max_len=200, stride=5, guided_attn=False,
+                 fast=False, fast_mode="", sted=True, compute_dtype=torch.float32):
+        super().__init__()
+        self.num_queries = num_queries
+        self.transformer = transformer
+        hidden_dim = transformer.d_model
+        self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.input_proj = nn.Conv2d(backbone.num_channels, hidden_dim, kernel_size=1)  # parameter holder
+        self.backbone = backbone
+        self.aux_loss = aux_loss
+        self.video_max_len = video_max_len
+        self.stride = stride
+        self.guided_attn = guided_attn
+        self.fast = fast
+        self.fast_mode = fast_mode
+        self.sted = sted
+        if sted:
+            self.sted_embed = MLP(hidden_dim, hidden_dim, 2, 2, dropout=0.5)
+        self._idx_cache: dict = {}
+        self.set_compute_dtype(compute_dtype)
+
+    def set_compute_dtype(self, dt: torch.dtype):
+        """torch.float32: exact-fp32 MFMA kernels (parity mode); torch.bfloat16: bf16 MFMA, fp32 accumulate."""
+        assert dt in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dt
+        self.backbone.set_compute_dtype(dt)
+        self.transformer.compute_dtype = dt
+        return self
+
+    def _project(self, feat: torch.Tensor) -> torch.Tensor:
+        """input_proj 1x1 conv on a channels-last (N,C,h,w) view -> (N,d,h,w) channels-last view."""
+        n, c, h, w = feat.shape
+        rows = feat.permute(0, 2, 3, 1).reshape(n * h * w, c)
+        y = Fk.linear(rows, self.input_proj.weight.view(self.input_proj.out_channels, c), self.input_proj.bias)
+        return y.view(n, h, w, -1).permute(0, 3, 1, 2)
+
+    def _frame_index(self, durations, device):
+        key = (tuple(durations), str(device))
+        if key not in self._idx_cache:
+            t = max(durations)
+            dest = torch.cat([torch.arange(d) + i * t for i, d in enumerate(durations)])
+            self._idx_cache[key] = dest.to(device)
+        return self._idx_cache[key]
+
+    def forward(self, samples: NestedTensor, durations, captions, encode_and_save=True, memory_cache=None, samples_fast=None):
+        if encode_and_save:
+            assert memory_cache is None
+            if not isinstance(samples, NestedTensor):
+                samples = NestedTensor.from_tensor_list(samples)
+            return self._encode(samples, durations, captions, samples_fast)
+        assert memory_cache is not None
+        return self._decode(memory_cache)
+
+    def _encode(self, samples, durations, captions, samples_fast):
+        if not self.stride:
+            raise NotImplementedError("stride=0 is outside the HIP hot path")
+        b, t, k = len(durations), max(durations), self.stride
+        features, pos = self.backbone(samples)
+        src, mask = features[-1].decompose()
+        dev = src.device
+        dest = self._frame_index(durations, dev)
+        identity = dest.numel() == b * t
+        fast_src = None
+        if self.fast:
+            with torch.no_grad():  # the fast branch does not back-propagate into the backbone (tubedetr.py:128-129)
+                features_fast, _ = self.backbone(samples_fast)
+            src_fast, mask_fast = features_fast[-1].decompose()
+            src_fast = self._project(src_fast)
+        src = self._project(src)
+        n, f, h, w = src.shape
+        n_clips = math.ceil(t / k)
+        assert n == b * n_clips, "all videos of a batch must have the same number of slow clips"
+        tpad_mask_t = torch.ones(b * t, h, w, dtype=torch.bool, device=dev)
+        if self.fast:
+            if identity:
+                fast_src, tpad_mask_t = src_fast, mask_fast.clone()
+            else:
+                fast_rows = torch.zeros((b * t, h, w, f), dtype=src_fast.dtype, device=dev)
+                fast_rows = fast_rows.index_put((dest,), src_fast.permute(0, 2, 3, 1))
+                fast_src = fast_rows.permute(0, 3, 1, 2)
+                tpad_mask_t[dest] = mask_fast
+        else:  # frames inherit the mask of their slow clip (tubedetr.py:172-178)
+            clip_of = torch.cat([i * n_clips + torch.arange(d) // k for i, d in enumerate(durations)]).to(dev)
+            tpad_mask_t[dest] = mask[clip_of]
+        tpad_mask = mask.clone()
+        tpad_mask[:, 0, 0] = False  # avoid empty masks
+        tpad_mask_t[:, 0, 0] = False
+        return self.transformer(src, tpad_mask, self.query_embed.weight, pos[-1], captions, encode_and_save=True,
+                                durations=durations, tpad_mask_t=tpad_mask_t, fast_src=fast_src)
+
+    def _decode(self, memory_cache):
+        res = self.transformer(img_memory=memory_cache["img_memory"], mask=memory_cache["mask"], pos_embed=memory_cache["pos_embed"],
+                               query_embed=memory_cache["query_embed"], query_mask=memory_cache["query_mask"], encode_and_save=False,
+                               text_memory=memory_cache["text_memory"], text_mask=memory_cache["text_attention_mask"])
+        if self.guided_attn:
+            hs, weights, cross_weights = res
+        else:
+            hs = res
+        nl, b, t, d = hs.shape
+        rows = hs.reshape(nl * b * t, d)
+        out = {}
+        if self.sted:
+            outputs_sted = Fk.cast(self.sted_embed(rows), torch.float32).view(nl, b, t, 2)
+        outputs_coord = Fk.cast(self.bbox_embed(rows), torch.float32).view(nl, b * t, 4).sigmoid()
+        out["pred_boxes"] = outputs_coord[-1]
+        if self.sted:
+            out["pred_sted"] = outputs_sted[-1]
+        if self.guided_attn:
+            out["weights"] = weights[-1]
+            out["ca_weights"] = cross_weights[-1]
+        if self.aux_loss:
+            out["aux_outputs"] = []
+            for i in range(nl - 1):
+                a = {"pred_boxes": outputs_coord[i]}
+                if self.sted:
+                    a["pred_sted"] = outputs_sted[i]
+                if self.guided_attn:
+                    a["weights"] = weights[i]
+                    a["ca_weights"] = cross_weights[i]
+                out["aux_outputs"].append(a)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# criterion (PyTorch-ROCm elementwise ops; same loss names / formulas as tubedetr.py:270-372)
+# ----------------------------------------------------------------------------------------------------------
+def _xyxy(b):
+    cx, cy, w, h = b.unbind(-1)
+    return torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), -1)
+
+
+def _paired_giou(a, b):
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    assert (a[:, 2:] >= a[:, :2]).all() and (b[:, 2:] >= b[:, :2]).all(), "degenerate boxes"
+    iwh = (torch.min(a[:, 2:], b[:, 2:]) - torch.max(a[:, :2], b[:, :2])).clamp(min=0)
+    inter = iwh[:, 0] * iwh[:, 1]
+    union = area_a + area_b - inter
+    ewh = (torch.max(a[:, 2:], b[:, 2:]) - torch.min(a[:, :2], b[:, :2])).clamp(min=0)
+    hull = ewh[:, 0] * ewh[:, 1]
+    return inter / union - (hull - union) / hull
+
+
+class SetCriterion(nn.Module):
+    def __init__(self, losses, sigma=1):
+        super().__init__()
+        self.losses = losses
+        self.sigma = sigma
+
+    def loss_boxes(self, outputs, targets, num_boxes):
+        src = outputs["pred_boxes"]
+        tgt = torch.cat([t["boxes"] for t in targets], dim=0)
+        giou = _paired_giou(_xyxy(src), _xyxy(tgt))
+        return {"loss_bbox": (src - tgt).abs().sum() / max(num_boxes, 1), "loss_giou": (1 - giou).sum() / max(num_boxes, 1)}
+
+    def loss_sted(self, outputs, num_boxes, inter_idx, positive_map, time_mask=None):
+        sted = outputs["pred_sted"].masked_fill(~time_mask[:, :, None], -1e32)
+        T, dev, eps = sted.shape[1], sted.device, 1e-6
+        grid = torch.arange(T, device=dev)[None, :]
+        total = 0
+        for col, which in ((0, 0), (1, 1)):
+            tgt = torch.tensor([x[which] for x in inter_idx], dtype=torch.long, device=dev)
+            gauss = (-((grid - tgt[:, None]) ** 2) / (2 * self.sigma ** 2)).exp()
+            gauss = F.normalize(gauss + eps, p=1, dim=1)
+            p = sted[:, :, col].softmax(1)
+            total = total + p * ((p + eps) / gauss).log() * time_mask
+        return {"loss_sted": total.mean()}
+
+    def loss_guided_attn(self, outputs, num_boxes, inter_idx, positive_map, time_mask=None):
+        w = outputs["weights"]
+        excl = positive_map + (~time_mask)
+        loss = (-(1 - w + 1e-6).log()).masked_fill(excl[:, :, None], 0)
+        nb_neg = (~excl).sum(1) + 1e-6
+        return {"loss_guided_attn": (loss.sum(2) / nb_neg[:, None]).sum(1).mean()}
+
+    def get_loss(self, loss, outputs, targets, num_boxes, inter_idx, positive_map, time_mask, **kw):
+        if loss == "boxes":
+            return self.loss_boxes(outputs, targets, num_boxes)
+        if loss == "sted":
+            return self.loss_sted(outputs, num_boxes, inter_idx, positive_map, time_mask)
+        if loss == "guided_attn":
+            return self.loss_guided_attn(outputs, num_boxes, inter_idx, positive_map, time_mask)
+        raise AssertionError(f"do you really want to compute {loss} loss?")
+
+    def forward(self, outputs, targets, inter_idx=None, time_mask=None):
+        dev = next(iter(outputs.values())).device
+        nb = torch.as_tensor([sum(len(t["boxes"]) for t in targets)], dtype=torch.float, device=dev)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(nb)
+            world = torch.distributed.get_world_size()
+        num_boxes = torch.clamp(nb / world, min=1).item()
+        positive_map = None
+        if inter_idx is not None and time_mask is not None:
+            positive_map = torch.zeros(time_mask.shape, dtype=torch.bool)
+            for kk, idx in enumerate(inter_idx):
+                if idx[0] >= 0:
+                    positive_map[kk, idx[0] : idx[1] + 1] = True
+            positive_map = positive_map.to(time_mask.device)
+        losses = {}
+        for loss in self.losses:
+            losses.update(self.get_loss(loss, outputs, targets, num_boxes, inter_idx, positive_map, time_mask))
+        for i, aux in enumerate(outputs.get("aux_outputs", [])):
+            for loss in self.losses:
+                losses.update({f"{k}_{i}": v for k, v in self.get_loss(loss, aux, targets, num_boxes, inter_idx, positive_map, time_mask).items()})
+        return losses
+
+
+def build(args):
+    device = torch.device(args.device)
+    backbone = build_backbone(args)
+    transformer = build_transformer(args)
+    model = TubeDETR(backbone, transformer, num_queries=args.num_queries, aux_loss=args.aux_loss, video_max_len=args.video_max_len_train,
+                     stride=args.stride, guided_attn=args.guided_attn, fast=args.fast, fast_mode=args.fast_mode, sted=args.sted,
+                     compute_dtype=getattr(args, "compute_dtype", torch.float32))
+    weight_dict = {"loss_bbox": args.bbox_loss_coef, "loss_giou": args.giou_loss_coef, "loss_sted": args.sted_loss_coef}
+    if args.guided_attn:
+        weight_dict["loss_guided_attn"] = args.guided_attn_loss_coef
+    if args.aux_loss:
+        base = dict(weight_dict)
+        for i in range(args.dec_layers - 1):
+            weight_dict.update({f"{k}_{i}": v for k, v in base.items()})
+    losses = ["boxes", "sted"] if args.sted else ["boxes"]
+    if args.guided_attn:
+        losses += ["guided_attn"]
+    criterion = SetCriterion(losses=losses, sigma=args.sigma)
+    criterion.to(device)
+    return model, criterion, weight_dict

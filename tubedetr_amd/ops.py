@@ -231,17 +231,23 @@ def mha_fwd(q: Tensor, k: Tensor, v: Tensor, key_pad: Optional[Tensor], H: int, 
     return out, probs, wavg
 
 
-def mha_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, probs: Tensor, dwavg: Optional[Tensor], H: int, scale: float, *,
-            dropout_p: float = 0.0, seed: int = 0):
+def mha_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, probs: Tensor, dwavg: Optional[Tensor], H: int, scale: float,
+            dq: Tensor, dk: Tensor, dv: Tensor, *, dropout_p: float = 0.0, seed: int = 0):
+    """dq/dk/dv must be allocated by the caller with exactly the strides of q/k/v (e.g. views of a packed buffer)."""
     B, Lq, E = q.shape
     Lk = k.shape[1]
     hd = E // H
-    dq = torch.empty((B, Lq, E), dtype=q.dtype, device=q.device)
-    dk = torch.empty((B, Lk, E), dtype=q.dtype, device=q.device)
-    dv = torch.empty((B, Lk, E), dtype=q.dtype, device=q.device)
     ws = torch.empty_like(probs)
     assert dout.is_contiguous()
+    for a, b in ((q, dq), (k, dk), (v, dv)):
+        assert a.stride() == b.stride() and a.shape == b.shape
     check(_hip.lib().td_mha_bwd(ptr(q), ptr(k), ptr(v), ptr(dout), ptr(probs), ptr(dwavg), ptr(dq), ptr(dk), ptr(dv), ptr(ws), B, H, Lq, Lk, hd,
                                 q.stride(1), k.stride(1), v.stride(1), E, scale, dropout_p, seed & 0xFFFFFFFF, dtype_code(q.dtype), stream_ptr()),
           "td_mha_bwd")
     return dq, dk, dv
+
+
+def dropout(x: Tensor, p: float, seed: int) -> Tensor:
+    y = torch.empty_like(x)
+    check(_hip.lib().td_dropout(ptr(x), ptr(y), x.numel(), p, seed & 0xFFFFFFFF, dtype_code(x.dtype), stream_ptr()), "td_dropout")
+    return y

@@ -1,0 +1,54 @@
+"""Boundary carrier type of the hot path: the reference's ``util.misc.NestedTensor`` (util/misc.py:106-178)
+- a batch of frames plus its pad mask (True = padded pixel).  Written from the interface description in
+SURVEY.md section 8(a) F1; only the members the hot path and its callers touch."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+
+class NestedTensor(object):
+    def __init__(self, tensors: torch.Tensor, mask: Optional[torch.Tensor]):
+        self.tensors = tensors
+        self.mask = mask
+
+    def to(self, *args, **kwargs) -> "NestedTensor":
+        m = self.mask.to(*args, **kwargs) if self.mask is not None else None
+        return type(self)(self.tensors.to(*args, **kwargs), m)
+
+    def decompose(self):
+        return self.tensors, self.mask
+
+    @classmethod
+    def from_tensor_list(cls, tensor_list: List[torch.Tensor], do_round: bool = False) -> "NestedTensor":
+        """Images (C,H,W) -> (B,C,Hmax,Wmax); video clips (C,T,H,W) -> all frames (sum T, C, Hmax, Wmax).
+        Pixels outside an item's own extent are zero and masked True."""
+        first = tensor_list[0]
+        if first.ndim not in (3, 4):
+            raise ValueError("not supported")
+        video = first.ndim == 4
+        hs = [t.shape[-2] for t in tensor_list]
+        ws = [t.shape[-1] for t in tensor_list]
+        H, W = max(hs), max(ws)
+        if do_round:
+            H, W = -(-H // 128) * 128, -(-W // 128) * 128
+        C = max(t.shape[0] for t in tensor_list)
+        n = sum(t.shape[1] for t in tensor_list) if video else len(tensor_list)
+        out = torch.zeros((n, C, H, W), dtype=first.dtype, device=first.device)
+        mask = torch.ones((n, H, W), dtype=torch.bool, device=first.device)
+        cur = 0
+        for t in tensor_list:
+            if video:
+                k = t.shape[1]
+                out[cur : cur + k, : t.shape[0], : t.shape[2], : t.shape[3]].copy_(t.transpose(0, 1))
+                mask[cur : cur + k, : t.shape[2], : t.shape[3]] = False
+                cur += k
+            else:
+                out[cur, : t.shape[0], : t.shape[1], : t.shape[2]].copy_(t)
+                mask[cur, : t.shape[1], : t.shape[2]] = False
+                cur += 1
+        return cls(out, mask)
+
+    def __repr__(self):
+        return repr(self.tensors)
