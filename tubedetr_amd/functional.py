@@ -19,14 +19,15 @@ from . import ops
 
 Tensor = torch.Tensor
 
-_PREP_CACHE: dict = {}
-
-
 def prepared(W: Tensor, dtype: torch.dtype, *, bn=None, need_dgrad: bool = True, cpad: Optional[int] = None, pad_out: int = 0):
-    """(w_fwd, w_dgrad, bias_fold, scale) for parameter W, cached until W (or the BN buffers) change."""
-    key = (W.data_ptr(), tuple(W.shape), dtype, need_dgrad, cpad, pad_out)
-    ver = (W._version,) + (tuple(b._version for b in bn) if bn is not None else ())
-    hit = _PREP_CACHE.get(key)
+    """(w_fwd, w_dgrad, bias_fold, scale) for parameter W (or a row-slice view of one), cached ON the parameter
+    object until it (or the BN buffers) change in place - the cache dies with the parameter, so a recycled device
+    address can never alias a stale entry."""
+    base = W._base if W._base is not None else W
+    cache = base.__dict__.setdefault("_td_prepared", {})
+    key = (W.storage_offset(), tuple(W.shape), dtype, need_dgrad, cpad, pad_out)
+    ver = (base._version, base.data_ptr()) + (tuple((b._version, b.data_ptr()) for b in bn) if bn is not None else ())
+    hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     Wd = W.detach()
@@ -35,12 +36,8 @@ def prepared(W: Tensor, dtype: torch.dtype, *, bn=None, need_dgrad: bool = True,
         Wp[: Wd.shape[0]] = Wd
         Wd = Wp
     res = ops.weight_prep(Wd.contiguous(), dtype, bn=[b.detach() for b in bn] if bn is not None else None, need_dgrad=need_dgrad, cpad=cpad)
-    _PREP_CACHE[key] = (ver, res)
+    cache[key] = (ver, res)
     return res
-
-
-def clear_prepared_cache():
-    _PREP_CACHE.clear()
 
 
 def _seed() -> int:
