@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py - training clips/sec (forward + backward) of the TubeDETR hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
+torch.distributed.run with one rank per GPU (RCCL).  A "step" = one pass of the hot path over one synthetic clip
+per GPU: the two model calls of engine.py:67-80 (video-text encoder, then space-time decoder), the criterion, and
+the backward pass (DDP gradient all-reduce overlapped when N>1).  Rank 0 prints ONE JSON line.
+
+Workload at N=1: BASELINE.json configs[2] (the config the metric is quoted on): T=100 frames, stride k=4,
+res=352, L=30 text tokens, 1 clip per GPU, bf16 MFMA kernels with fp32 accumulation, random-init weights,
+train mode (dropout active).  Inputs are generated on the device before the timed region.
+
+Extra legs (rank 0, after the timed region, not part of `value`):
+  roofline     : `--roofline-steps` more identical steps with HIP events recorded on the launch stream around every
+                 launch of the dominant kernel (the implicit-GEMM conv/linear MFMA kernel); achieved = algorithmic
+                 FLOPs of those launches / their summed duration.
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on the host cores on a bounded
+                 sample (a T=`--cpu-frames` clip of the same resolution, fwd+bwd) and scaled to T=100.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (T, res, k, L)
+    "cfg3": (100, 352, 4, 30),   # headline: res=352 k=4 T=100 L=30
+    "cfg2": (64, 224, 2, 20),
+    "cfg1": (8, 224, 5, 20),
+}
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+# algorithmic GFLOP per clip fwd+bwd
+ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
+
+
+def make_batch(T, res, k, L, seed, device):
+    """SURVEY.md 8d synthetic clip, generated directly in HBM: video ~ N(0,1), slow = video[::k], fast = all frames."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    video = torch.randn(T, 3, res, res, generator=g, device=device)
+    ids = torch.randint(3, 50000, (1, L), generator=g, device=device)
+    ids[:, 0], ids[:, -1] = 0, 2
+    cxcy = torch.rand(T, 2, generator=g, device=device) * 0.6 + 0.2
+    wh = torch.rand(T, 2, generator=g, device=device) * 0.3 + 0.1
+    return {
+        "frames": video[::k].contiguous(),
+        "frames_mask": torch.zeros((math.ceil(T / k), res, res), dtype=torch.bool, device=device),
+        "frames_fast": video,
+        "fast_mask": torch.zeros((T, res, res), dtype=torch.bool, device=device),
+        "durations": [T],
+        "input_ids": ids,
+        "attention_mask": torch.ones(1, L, dtype=torch.long, device=device),
+        "target_boxes": torch.cat([cxcy, wh], 1),
+        "inter_idx": [[0, T - 1]],
+    }
+
+
+class BatchTokenizer:
+    """Feeds the current synthetic batch's token ids to the model (no tokenizer files offline)."""
+
+    def __init__(self):
+        self.batch = None
+
+    def batch_encode_plus(self, text, padding="longest", return_tensors="pt"):
+        from transformers import BatchEncoding
+
+        be = BatchEncoding({"input_ids": self.batch["input_ids"].clone(), "attention_mask": self.batch["attention_mask"].clone()})
+        be._encodings = [None] * len(text)
+        return be
+
+
+def cpu_baseline(T_sample, res, k, L, T_full):
+    """Reference algorithm on the host cores (oracle port), fwd+bwd of a T_sample-frame clip, scaled to T_full frames."""
+    from oracle.tubedetr_oracle import OracleConfig, train_step
+    from oracle.weights import fill_state, state_spec, synthetic_batch
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = OracleConfig(stride=k)
+    sd = fill_state(state_spec(cfg), 1, requires_grad=True)
+    batch = synthetic_batch(T=T_sample, res=res, k=k, L=L, seed=5)
+    best = None
+    for _ in range(2):  # second pass = steady state
+        for v in sd.values():
+            v.grad = None
+        t0 = time.time()
+        loss, _, _, _ = train_step(sd, cfg, batch)
+        loss.backward()
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+    per_clip = best * (T_full / T_sample)
+    return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"fwd+bwd of a T={T_sample} clip (k={k}, res={res}, L={L}) by the CPU oracle in {best:.1f}s, scaled x{T_full}/{T_sample} to T={T_full}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--roofline-steps", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-baseline sample clip (0 = skip)")
+    ap.add_argument("--no-fast", action="store_true")
+    ap.add_argument("--no-tsa", action="store_true")
+    ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: run in eval mode")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    import tubedetr_amd
+    from tubedetr_amd import _hip
+    from tubedetr_amd.harness import forward_step
+    from tubedetr_amd.models import build_model
+
+    T, res, k, L = WORKLOADS[a.workload]
+    cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(42 + rank)  # main.py:358
+    args = tubedetr_amd.default_args(stride=k, fast=not a.no_fast, no_tsa=a.no_tsa, compute_dtype=cdt, video_max_len_train=max(200, T))
+    model, criterion, weight_dict = build_model(args)
+    model.to(dev)
+    model.train(not a.eval_dropout_off)
+    tok = BatchTokenizer()
+    model.transformer.tokenizer = tok
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True)  # main.py:372-376
+
+    n_batches = a.warmup + a.steps + a.roofline_steps
+    batches = [make_batch(T, res, k, L, 1000 * rank + s, dev) for s in range(min(n_batches, 4))]
+
+    def step(i):
+        b = batches[i % len(batches)]
+        tok.batch = b
+        net.zero_grad(set_to_none=True)
+        loss, _, _, _ = forward_step(net, criterion, weight_dict, b)
+        loss.backward()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert math.isfinite(loss.item()), "non-finite loss"
+
+    roofline, cpu = None, None
+    if rank == 0:
+        if a.roofline_steps > 0:
+            L_ = _hip.lib()
+            L_.td_prof_enable(1)
+            for i in range(a.roofline_steps):
+                step(a.warmup + a.steps + i)
+            torch.cuda.synchronize()
+            n, ms, fl = C.c_longlong(), C.c_double(), C.c_double()
+            code = _hip.TD_BF16 if cdt == torch.bfloat16 else _hip.TD_F32
+            _hip.check(L_.td_prof_collect(0, code, C.byref(n), C.byref(ms), C.byref(fl)), "td_prof_collect")
+            L_.td_prof_enable(0)
+            if n.value:
+                achieved = fl.value / (ms.value * 1e-3) / 1e12
+                peak = PEAK_BF16_TFLOPS if cdt == torch.bfloat16 else 157.3
+                roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel<%s,128,128>" % ("bf16" if cdt == torch.bfloat16 else "f32"),
+                            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                            "launches_per_step": n.value // a.roofline_steps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                            "kernel_ms_per_step": round(ms.value / a.roofline_steps, 3),
+                            "algorithmic_gflop_per_step": round(fl.value / a.roofline_steps / 1e9, 1)}
+        if world == 1 and a.cpu_frames > 0:
+            try:
+                cpu = cpu_baseline(max(a.cpu_frames, k), res, k, L, T)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                cpu = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+
+    if rank == 0:
+        clips = world * a.steps
+        value = clips / elapsed
+        step_tflop = ALGO_TFLOP_PER_CLIP.get(a.workload)
+        out = {
+            "metric": "training clips/sec (fwd+bwd)", "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, 1 clip/GPU, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}",
+                       "global_batch": world, "parallelism": f"dp{world}", "weights": "random init (reference scheme), seed 42+rank"},
+            "step_frac_of_mfma_peak": round(step_tflop * value / world / PEAK_BF16_TFLOPS, 4) if (step_tflop and a.dtype == "bf16") else None,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,6 +32,17 @@ typedef void* td_stream_t; /* hipStream_t */
 const char* td_last_error(void);
 int td_abi_version(void);
 
+/* Optional per-kernel-family timing with HIP events recorded on the launch stream around every MFMA kernel
+ * launch (bench.py's roofline leg).  td_prof_enable(1) starts collecting (not thread safe: single launching
+ * thread), td_prof_collect synchronises the recorded events and returns, per family (TD_PROF_*), the number of
+ * launches, the summed duration in ms and the summed ALGORITHMIC flops (2*M*N*K of the un-padded problem). */
+#define TD_PROF_GEMM_128x128 0
+#define TD_PROF_GEMM_128x64 1
+#define TD_PROF_WGRAD 2
+#define TD_PROF_FAMILIES 3
+int td_prof_enable(int on);
+int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
+
 /* Geometry of one implicit-GEMM convolution / linear layer.  rows m enumerate (n, ho, wo);
  * k enumerates (r, s, c) with c fastest; the gathered source is NHWC [N][Hs][Ws][C].
  * mode 0 (forward):  hs = ho*stride - pad + r

@@ -1,6 +1,8 @@
 // Error plumbing of the C ABI (thread-local last-error string, launch checks).
 #include <stdarg.h>
 
+#include <vector>
+
 #include "td_common.h"
 
 namespace td {
@@ -23,7 +25,47 @@ int check_launch(const char* what) {
   return TD_OK;
 }
 
+// ---- launch timing for bench.py's roofline leg ----
+struct ProfRec { int family, dtype; double flops; hipEvent_t a, b; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+bool prof_on() { return g_prof; }
+void prof_begin(int family, int dtype, double flops, hipStream_t st) {
+  ProfRec r{family, dtype, flops, get_event(), get_event()};
+  hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+}
+void prof_end(hipStream_t st) { hipEventRecord(g_recs.back().b, st); }
+
 }  // namespace td
+
+extern "C" int td_prof_enable(int on) {
+  td::g_prof = on != 0;
+  if (on) {
+    for (auto& r : td::g_recs) { td::g_pool.push_back(r.a); td::g_pool.push_back(r.b); }
+    td::g_recs.clear();
+  }
+  return TD_OK;
+}
+extern "C" int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops) {
+  long long n = 0; double t = 0, f = 0;
+  for (auto& r : td::g_recs) {
+    if (r.family != family || r.dtype != dtype) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) { td::set_error("td_prof_collect: event sync failed"); return TD_ERR_LAUNCH; }
+    float e = 0.f;
+    hipEventElapsedTime(&e, r.a, r.b);
+    n++; t += e; f += r.flops;
+  }
+  if (launches) *launches = n;
+  if (ms) *ms = t;
+  if (flops) *flops = f;
+  return TD_OK;
+}
 
 extern "C" const char* td_last_error(void) { return td::g_err; }
 extern "C" int td_abi_version(void) { return 1; }

@@ -450,6 +450,8 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   hipStream_t st = (hipStream_t)stream;
   const bool narrow = d->Nc <= 64;
   dim3 grid(cdiv(p.M, 128), cdiv(d->Nc, narrow ? 64 : 128));
+  const bool prof = prof_on();
+  if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : TD_PROF_GEMM_128x128, dtype, 2.0 * p.M * d->Nc * p.K, st);
   if (dtype == TD_BF16) {
     if (narrow) conv_gemm_kernel<u16, 128, 64><<<grid, 256, 0, st>>>(p);
     else conv_gemm_kernel<u16, 128, 128><<<grid, 256, 0, st>>>(p);
@@ -457,6 +459,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
     if (narrow) conv_gemm_kernel<float, 128, 64><<<grid, 256, 0, st>>>(p);
     else conv_gemm_kernel<float, 128, 128><<<grid, 256, 0, st>>>(p);
   }
+  if (prof) prof_end(st);
   return check_launch("td_conv_gemm");
 }
 
@@ -489,7 +492,10 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
   splits = cdiv(p.M, p.mper);
   dim3 grid(cdiv(d->Nc, 128), cdiv(p.K, 128), splits);
   hipStream_t st = (hipStream_t)stream;
+  const bool prof = prof_on();
+  if (prof) prof_begin(TD_PROF_WGRAD, dtype, 2.0 * p.M * d->Nc * p.K, st);
   if (dtype == TD_BF16) conv_wgrad_kernel<u16><<<grid, 256, 0, st>>>(p);
   else conv_wgrad_kernel<float><<<grid, 256, 0, st>>>(p);
+  if (prof) prof_end(st);
   return check_launch("td_conv_wgrad");
 }

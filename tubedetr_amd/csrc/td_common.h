@@ -26,6 +26,11 @@ int check_launch(const char* what);
     }                                   \
   } while (0)
 
+// bench-only launch timing (api.cpp)
+bool prof_on();
+void prof_begin(int family, int dtype, double flops, hipStream_t st);
+void prof_end(hipStream_t st);
+
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- bf16 <-> f32 (round-to-nearest-even), bit exact with torch's float->bfloat16 ----
