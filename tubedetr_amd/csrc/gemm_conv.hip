@@ -23,6 +23,7 @@ struct GemmParams {
   char* out;
   td_conv_desc d;
   int M, K;
+  uint32_t src_bytes, w_bytes;
   const float* bias;
   const char* residual;
   const char* mask_src;
@@ -53,32 +54,79 @@ struct Mfma<float> {
   }
 };
 
+template <typename T>
+__device__ __forceinline__ void load4(const char* base, size_t off, float (&o)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const char* base, size_t off, float (&o)[4]) {
+  float4 v = *(const float4*)(base + off * 4);
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load4<u16>(const char* base, size_t off, float (&o)[4]) {
+  uint2 v = *(const uint2*)(base + off * 2);
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ void store4(char* base, size_t off, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<float>(char* base, size_t off, const float (&v)[4]) {
+  *(float4*)(base + off * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<u16>(char* base, size_t off, const float (&v)[4]) {
+  uint2 o;
+  o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  *(uint2*)(base + off * 2) = o;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Main loop: operands go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB = 8 rows x 128 B per wave
+// instruction, no VGPR staging).  The LDS image is row-major with the 16-byte chunk index XOR-swizzled by
+// (row & 7): the DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE address and
+// again on the fragment read.  Out-of-image taps, rows >= M, channels >= Nc and the K tail are given an
+// out-of-range buffer offset, which the hardware returns as zeros - no divergent control flow in the loop.
 template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;   // elements per 16-byte chunk
   constexpr int BK = 128 / ES;   // K elements per tile (128 bytes per row)
-  constexpr int AI = BM / 32, BI = BN / 32;
+  constexpr int AI = BM / 32, BI = BN / 32;   // 8-row groups per wave
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 16, TN = WN / 16;
-  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];
-  auto sA = [&](int buf) -> char* { return smem + buf * ((BM + BN) * 128); };
-  auto sB = [&](int buf) -> char* { return smem + buf * ((BM + BN) * 128) + BM * 128; };
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  // two distinct LDS objects (one per pipeline stage): LDS lowering then tags their accesses with disjoint alias
+  // scopes, so fragment reads of one stage do not wait (vmcnt) for the DMA that is filling the other stage.
+  __shared__ __attribute__((aligned(16))) char smem0[(BM + BN) * 128];
+  __shared__ __attribute__((aligned(16))) char smem1[(BM + BN) * 128];
 
   const td_conv_desc& d = p.d;
   const int t = threadIdx.x;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int chunk = t & 7, rowt = t >> 3;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  // 1-D grid; consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each), so M tiles are dealt to XCDs
+  // and every XCD walks all N tiles of its M tile back to back: the activation tile is re-read from that XCD's L2.
+  const int NT = (d.Nc + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mt = (seq / NT) * 8 + xcd, nt = seq - (seq / NT) * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (m0 >= p.M) return;
+  const int lrow = lane >> 3;                 // row inside an 8-row group
+  const int chunk = (lane & 7) ^ lrow;        // source chunk that lands in LDS slot (lane & 7) of that row
   const int HoWo = d.Ho * d.Wo;
 
-  // per-thread row bookkeeping (fixed for the whole K loop)
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  // per-lane row bookkeeping (fixed for the whole K loop)
   int a_img[AI], a_hb[AI], a_wb[AI];
   bool a_ok[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    int m = m0 + rowt + 32 * i;
+    int m = m0 + (i * 4 + wave) * 8 + lrow;
     a_ok[i] = m < p.M;
     int mm = a_ok[i] ? m : 0;
     int n = mm / HoWo;
@@ -93,28 +141,35 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
       a_wb[i] = wo + d.pad;
     }
   }
-  const int RS = d.R * d.S;
-  uint4 ra[AI], rb[BI];
+  uint32_t b_off[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    int n = n0 + (i * 4 + wave) * 8 + lrow;
+    b_off[i] = n < d.Nc ? (uint32_t)n * (uint32_t)p.K * ES : OOB;
+  }
+  // running decomposition of this lane's k index into (r, s, c)
+  int kk = chunk * VEC;
+  int kr = 0, ks_ = 0, kc = kk;
+  if (d.R * d.S > 1) {
+    int tap = kk / d.C;
+    kc = kk - tap * d.C;
+    kr = tap / d.S;
+    ks_ = tap - kr * d.S;
+  }
 
-  auto load_tile = [&](int kt) {
-    int kk = kt * BK + chunk * VEC;
-    bool kvalid = kk < p.K;
-    int r = 0, s = 0, c = kk;
-    if (RS > 1) {
-      int tap = kk / d.C;
-      c = kk - tap * d.C;
-      r = tap / d.S;
-      s = tap - r * d.S;
-    }
+  auto issue_tile = [&](char* stage) {
+    char* stA = stage;
+    char* stB = stage + BM * 128;
+    const bool kvalid = kk < p.K;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       int hs, ws;
       bool ok = a_ok[i] && kvalid;
       if (d.mode == 0) {
-        hs = a_hb[i] + r;
-        ws = a_wb[i] + s;
+        hs = a_hb[i] + kr;
+        ws = a_wb[i] + ks_;
       } else {
-        int th = a_hb[i] - r, tw = a_wb[i] - s;
+        int th = a_hb[i] - kr, tw = a_wb[i] - ks_;
         ok = ok && th >= 0 && tw >= 0;
         if (d.stride == 1) {
           hs = th; ws = tw;
@@ -127,35 +182,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
         }
       }
       ok = ok && (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        size_t off = ((size_t)(a_img[i] + hs * d.Ws + ws) * d.C + c) * ES;
-        v = *(const uint4*)(p.src + off);
+      uint32_t off = ok ? ((uint32_t)(a_img[i] + hs * d.Ws + ws) * (uint32_t)d.C + (uint32_t)kc) * ES : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stA + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      uint32_t off = (kvalid && b_off[i] != OOB) ? b_off[i] + (uint32_t)kk * ES : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(stB + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+    }
+    // advance this lane's k by one tile
+    kk += BK;
+    kc += BK;
+    if (d.R * d.S > 1) {
+      while (kc >= d.C) {
+        kc -= d.C;
+        if (++ks_ == d.S) { ks_ = 0; ++kr; }
       }
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      int n = n0 + rowt + 32 * i;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kvalid && n < d.Nc) v = *(const uint4*)(p.w + ((size_t)n * p.K + kk) * ES);
-      rb[i] = v;
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      int row = rowt + 32 * i;
-      *(uint4*)(sA(buf) + row * 128 + ((chunk ^ (row & 7)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      int row = rowt + 32 * i;
-      *(uint4*)(sB(buf) + row * 128 + ((chunk ^ (row & 7)) << 4)) = rb[i];
     }
   };
 
-  const int wave = t >> 6, lane = t & 63;
   const int wy = wave >> 1, wx = wave & 1;
   const int lr = lane & 15, lg = lane >> 4;
 
@@ -165,13 +210,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+  auto compute_tile = [&](const char* stage) {
+    const char* stA = stage;
+    const char* stB = stage + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int cidx = ks * 4 + lg;
@@ -179,24 +220,35 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         int row = wy * WM + j * 16 + lr;
-        af[j] = *(const uint4*)(sA(buf) + row * 128 + ((cidx ^ (row & 7)) << 4));
+        af[j] = *(const uint4*)(stA + row * 128 + ((cidx ^ (row & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         int row = wx * WN + i * 16 + lr;
-        wf[i] = *(const uint4*)(sB(buf) + row * 128 + ((cidx ^ (row & 7)) << 4));
+        wf[i] = *(const uint4*)(stB + row * 128 + ((cidx ^ (row & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) Mfma<T>::run(wf[i], af[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  issue_tile(smem0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    __syncthreads();  // tile kt has landed in stage 0 (vmcnt(0) + barrier); all waves are done reading stage 1
+    if (kt + 1 < nk) issue_tile(smem1);
+    compute_tile(smem0);
+    if (kt + 1 >= nk) break;
     __syncthreads();
+    if (kt + 2 < nk) issue_tile(smem0);
+    compute_tile(smem1);
   }
 
   // ---- epilogue: lane holds out[m][nb..nb+3] per (i,j) tile ----
   const float alpha = p.alpha;
+  const bool vec_ok = (d.ldc & 3) == 0;
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     int m = m0 + wy * WM + j * 16 + lr;
@@ -216,31 +268,48 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmParams p) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
-      const bool full = (nb + 3 < d.Nc) && ((d.ldc & 3) == 0);
-      const int cnt = full ? 4 : min(4, d.Nc - nb);
-      if (p.bias)
-        for (int r = 0; r < cnt; ++r) v[r] += p.bias[nb + r];
-      if (p.residual)
-        for (int r = 0; r < cnt; ++r) v[r] += Elem<T>::load(p.residual, off + r);
-      if (p.relu)
-        for (int r = 0; r < cnt; ++r) v[r] = fmaxf(v[r], 0.f);
-      if (p.sigmoid)
-        for (int r = 0; r < cnt; ++r) v[r] = sigmoidf_(v[r]);
-      if (p.mask_src)
-        for (int r = 0; r < cnt; ++r) v[r] = Elem<T>::load(p.mask_src, off + r) > 0.f ? v[r] : 0.f;
-      if (p.drop_thresh)
-        for (int r = 0; r < cnt; ++r) v[r] = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
-      if (full) {
-        if (ES == 2) {
-          uint2 o;
-          o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-          o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-          *(uint2*)(p.out + off * 2) = o;
-        } else {
-          *(float4*)(p.out + off * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      if (vec_ok && nb + 3 < d.Nc) {
+        if (p.bias) {
+          float4 b4 = *(const float4*)(p.bias + nb);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
         }
+        if (p.residual) {
+          float r4[4];
+          load4<T>(p.residual, off, r4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += r4[r];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.sigmoid) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+        }
+        if (p.mask_src) {
+          float m4[4];
+          load4<T>(p.mask_src, off, m4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.f ? v[r] : 0.f;
+        }
+        if (p.drop_thresh) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
+        }
+        store4<T>(p.out, off, v);
       } else {
-        for (int r = 0; r < cnt; ++r) Elem<T>::store(p.out, off + r, v[r]);
+        const int cnt = min(4, d.Nc - nb);
+        for (int r = 0; r < cnt; ++r) {
+          float x = v[r];
+          if (p.bias) x += p.bias[nb + r];
+          if (p.residual) x += Elem<T>::load(p.residual, off + r);
+          if (p.relu) x = fmaxf(x, 0.f);
+          if (p.sigmoid) x = sigmoidf_(x);
+          if (p.mask_src) x = Elem<T>::load(p.mask_src, off + r) > 0.f ? x : 0.f;
+          if (p.drop_thresh) x = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? x * p.drop_scale : 0.f;
+          Elem<T>::store(p.out, off + r, x);
+        }
       }
     }
   }
@@ -430,6 +499,13 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   if (p.d.out_sp < 1) p.d.out_sp = 1;
   p.M = d->N * d->Ho * d->Wo;
   p.K = d->R * d->S * d->C;
+  {
+    const double es = dtype == TD_BF16 ? 2.0 : 4.0;
+    const double sb = (double)d->N * d->Hs * d->Ws * d->C * es, wb = (double)d->Nc * p.K * es;
+    TD_REQUIRE(sb < 4294967000.0 && wb < 4294967000.0, "td_conv_gemm: operand exceeds the 4 GiB buffer-descriptor range");
+    p.src_bytes = (uint32_t)sb;
+    p.w_bytes = (uint32_t)wb;
+  }
   p.alpha = 1.f;
   if (e) {
     p.bias = e->bias;
@@ -448,15 +524,22 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   }
   TD_REQUIRE(d->ldc >= d->Nc, "td_conv_gemm: ldc < Nc");
   hipStream_t st = (hipStream_t)stream;
+  // tile choice: 128x64 for <=64 output channels; 64x128 when 128x128 would leave the 256 CUs under-filled
   const bool narrow = d->Nc <= 64;
-  dim3 grid(cdiv(p.M, 128), cdiv(d->Nc, narrow ? 64 : 128));
+  const int tiles128 = cdiv(p.M, 128) * cdiv(d->Nc, 128);
+  const bool small_m = !narrow && tiles128 < 512;
+  const int BMsel = small_m ? 64 : 128, BNsel = narrow ? 64 : 128;
+  const int MT = cdiv(p.M, BMsel), NTl = cdiv(d->Nc, BNsel);
+  dim3 grid(8 * cdiv(MT, 8) * NTl);
   const bool prof = prof_on();
   if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : TD_PROF_GEMM_128x128, dtype, 2.0 * p.M * d->Nc * p.K, st);
   if (dtype == TD_BF16) {
     if (narrow) conv_gemm_kernel<u16, 128, 64><<<grid, 256, 0, st>>>(p);
+    else if (small_m) conv_gemm_kernel<u16, 64, 128><<<grid, 256, 0, st>>>(p);
     else conv_gemm_kernel<u16, 128, 128><<<grid, 256, 0, st>>>(p);
   } else {
     if (narrow) conv_gemm_kernel<float, 128, 64><<<grid, 256, 0, st>>>(p);
+    else if (small_m) conv_gemm_kernel<float, 64, 128><<<grid, 256, 0, st>>>(p);
     else conv_gemm_kernel<float, 128, 128><<<grid, 256, 0, st>>>(p);
   }
   if (prof) prof_end(st);
