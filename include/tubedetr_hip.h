@@ -84,6 +84,25 @@ int td_conv_gemm(const void* src, const void* wmat, void* out, const td_conv_des
 int td_conv_wgrad(const void* g, const void* src, float* dw, const td_conv_desc* d, int ldg, int dtype, int splits,
                   td_stream_t stream);
 
+/* Native executor of the bottleneck-ResNet trunk (replaces the module-graph execution of torchvision resnet101 through
+ * IntermediateLayerGetter, models/backbone.py:94-98, and its autograd backward).  Conv order in every array: stem,
+ * then per block conv1, conv2, conv3[, downsample] (td_resnet_num_convs entries).  x_nchw: (N,3,H,W) fp32 frames;
+ * w_fwd/bias: prepared (FrozenBN-folded) weights of td_weight_prep; ws: caller-allocated workspace.  save=1 keeps every
+ * activation for td_resnet_bwd; save=0 (the no_grad "fast" pass, models/tubedetr.py:128-129) runs in a 6-slot ring.
+ * *feat points into ws: layer4 output NHWC [N][feat_hw[0]][feat_hw[1]][feat_hw[2]]. */
+size_t td_resnet_fwd_ws_bytes(int N, int H, int W, const int* nblocks, int dtype, int save);
+int td_resnet_num_convs(const int* nblocks);
+int td_resnet_fwd(const float* x_nchw, int N, int H, int W, const int* nblocks, const void* const* w_fwd,
+                  const float* const* bias, int save, void* ws, size_t ws_bytes, void** feat, int* feat_hw, int dtype,
+                  td_stream_t stream);
+/* Backward through the stages >= first_train_stage (0..3; the reference trains layer2-4 = 1, backbone.py:82-89):
+ * dfeat = gradient of *feat; fwd_ws = the save=1 workspace of the forward; dW[i] receives the gradient of conv i in
+ * the parameter's own [Co][Ci][R][S] fp32 layout (FrozenBN scale un-folded); entries of frozen convs are ignored. */
+size_t td_resnet_bwd_ws_bytes(int N, int H, int W, const int* nblocks, int first_train_stage, int dtype);
+int td_resnet_bwd(const void* dfeat, int N, int H, int W, const int* nblocks, int first_train_stage,
+                  const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws, void* ws,
+                  size_t ws_bytes, int dtype, td_stream_t stream);
+
 /* Fold FrozenBatchNorm2d (models/backbone.py:60-70) into a conv: w_fwd[co][r][s][ci] = W[co][ci][r][s]*scale[co]
  * (ci zero-padded to Cpad), w_dgrad[ci][r][s][co] likewise (may be NULL), bias_out[co] = b - rm*scale,
  * scale_out[co] = w*rsqrt(rv+eps).  bn_* may be NULL (plain layer: scale 1, bias copied from `bias`). */

@@ -38,6 +38,9 @@ _SIGS = {
     "td_prof_collect": [_I, _I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "td_conv_gemm": [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P],
     "td_conv_wgrad": [_P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
+    "td_resnet_num_convs": [C.POINTER(C.c_int)],
+    "td_resnet_fwd": [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ, C.POINTER(_P), C.POINTER(C.c_int), _I, _P],
+    "td_resnet_bwd": [_P, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _I, _P],
     "td_weight_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "td_wgrad_finalize": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "td_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -54,7 +57,11 @@ _SIGS = {
     "td_mha_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _I, _P],
     "td_mha_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _I, _P],
 }
-EXPORTS = ["td_last_error", "td_abi_version"] + list(_SIGS)
+_SIZE_SIGS = {
+    "td_resnet_fwd_ws_bytes": [_I, _I, _I, C.POINTER(C.c_int), _I, _I],
+    "td_resnet_bwd_ws_bytes": [_I, _I, _I, C.POINTER(C.c_int), _I, _I],
+}
+EXPORTS = ["td_last_error", "td_abi_version"] + list(_SIGS) + list(_SIZE_SIGS)
 
 
 def lib_path() -> str:
@@ -77,6 +84,10 @@ def lib() -> C.CDLL:
         for name, sig in _SIGS.items():
             fn = getattr(L, name)
             fn.restype = C.c_int
+            fn.argtypes = sig
+        for name, sig in _SIZE_SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = C.c_size_t
             fn.argtypes = sig
         _lib = L
     return _lib

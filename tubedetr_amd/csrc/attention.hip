@@ -115,27 +115,28 @@ __global__ void avg_heads_kernel(const float* probs, float* wavg, int B, int H, 
   wavg[idx] = acc / H;
 }
 
-// one workgroup per (batch, head).  Pass A: wave per query -> dS rows (to ds_ws) and dQ.
-// Pass B: thread per key -> dK, dV.
+// Backward, kernel A: grid (batch*head, query tiles).  One wavefront per query row: dP = dO V^T (+ dwavg/H),
+// dS = P * (dP - sum(P dP)) written to ds_ws, dQ = scale * dS K.
 template <typename T>
-__global__ __launch_bounds__(256) void mha_bwd_kernel(MhaParams p) {
+__global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Lk = p.Lk, Lq = p.Lq;
-  const int Lmax = max(Lk, Lq);
-  float* sA = sm;                // pass A: K [Lk][33]   pass B: Q  [Lq][32]
-  float* sB = sA + Lmax * 33;    // pass A: V [Lk][33]   pass B: dO [Lq][32]
-  float* sP = sB + Lmax * 33;    // [4][Lk]
+  float* sK = sm;
+  float* sV = sK + Lk * 33;
+  float* sP = sV + Lk * 33;  // [4][Lk]
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
   for (int idx = t; idx < Lk * HD; idx += 256) {
     int kk = idx >> 5, d = idx & 31;
-    sA[kk * 33 + d] = Elem<T>::load(p.k, (size_t)(b * Lk + kk) * p.ldk + h * HD + d);
-    sB[kk * 33 + d] = Elem<T>::load(p.v, (size_t)(b * Lk + kk) * p.ldv + h * HD + d);
+    sK[kk * 33 + d] = Elem<T>::load(p.k, (size_t)(b * Lk + kk) * p.ldk + h * HD + d);
+    sV[kk * 33 + d] = Elem<T>::load(p.v, (size_t)(b * Lk + kk) * p.ldv + h * HD + d);
   }
   __syncthreads();
   float* myP = sP + wave * Lk;
   const float invH = 1.f / p.H;
-  for (int qi = wave; qi < Lq; qi += 4) {
+  const int q0 = blockIdx.y * QT;
+  const int q1 = min(Lq, q0 + QT);
+  for (int qi = q0 + wave; qi < q1; qi += 4) {
     float dov[HD];
     const size_t ooff = (size_t)(b * Lq + qi) * p.ldo + h * HD;
 #pragma unroll
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(MhaParams p) {
       if (kk < Lk) {
         float dot = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) dot += dov[d] * sB[kk * 33 + d];
+        for (int d = 0; d < HD; ++d) dot += dov[d] * sV[kk * 33 + d];
         if (p.dwavg) dot += p.dwavg[((size_t)b * Lq + qi) * Lk + kk] * invH;
         if (p.drop_thresh) dot = dropout_keep(p.seed, (uint32_t)(prow + kk), p.drop_thresh) ? dot * p.drop_scale : 0.f;
         dp[j] = dot;
@@ -171,42 +172,54 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(MhaParams p) {
     LDS_FENCE();
     const int d = lane & 31, half = lane >> 5;
     float acc = 0.f;
-    for (int kk = half; kk < Lk; kk += 2) acc += myP[kk] * sA[kk * 33 + d];
+    for (int kk = half; kk < Lk; kk += 2) acc += myP[kk] * sK[kk * 33 + d];
     acc += __shfl_xor(acc, 32, 64);
     if (half == 0) Elem<T>::store(p.dq, (size_t)(b * Lq + qi) * p.ldq + h * HD + d, acc * p.scale);
     LDS_FENCE();
   }
-  __syncthreads();  // K,V no longer needed; ds_ws rows written by this workgroup are visible to it
+}
+
+// Backward, kernel B: grid (batch*head, tiles of 64 keys).  Thread = (key, 8-channel slice); loops over all queries:
+// dK = scale * dS^T Q, dV = dropout(P)^T dO.  Q / dO rows are wave-uniform LDS broadcasts, dS / P columns are
+// coalesced over keys.
+template <typename T>
+__global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Lk = p.Lk, Lq = p.Lq;
+  float* sQ = sm;             // [Lq][32]
+  float* sO = sm + Lq * HD;   // [Lq][32]
+  const int t = threadIdx.x;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
   for (int idx = t; idx < Lq * HD; idx += 256) {
     int qq = idx >> 5, d = idx & 31;
-    sA[qq * HD + d] = Elem<T>::load(p.q, (size_t)(b * Lq + qq) * p.ldq + h * HD + d);
-    sB[qq * HD + d] = Elem<T>::load(p.dout, (size_t)(b * Lq + qq) * p.ldo + h * HD + d);
+    sQ[idx] = Elem<T>::load(p.q, (size_t)(b * Lq + qq) * p.ldq + h * HD + d);
+    sO[idx] = Elem<T>::load(p.dout, (size_t)(b * Lq + qq) * p.ldo + h * HD + d);
   }
   __syncthreads();
-  for (int kk = t; kk < Lk; kk += 256) {
-    float dK[HD], dV[HD];
+  const int kk = blockIdx.y * 64 + (t & 63);
+  const int part = t >> 6;  // wave-uniform: channels part*8 .. part*8+7
+  if (kk >= Lk) return;
+  float dK[8], dV[8];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) dK[d] = dV[d] = 0.f;
-    for (int qq = 0; qq < Lq; ++qq) {
-      const size_t pi = ((size_t)bh * Lq + qq) * Lk + kk;
-      float ds = p.ds_ws[pi];
-      float pr = p.probs[pi];
-      if (p.drop_thresh) pr = dropout_keep(p.seed, (uint32_t)pi, p.drop_thresh) ? pr * p.drop_scale : 0.f;
-      const float4* q4 = (const float4*)(sA + qq * HD);
-      const float4* o4 = (const float4*)(sB + qq * HD);
+  for (int d = 0; d < 8; ++d) dK[d] = dV[d] = 0.f;
+  for (int qq = 0; qq < Lq; ++qq) {
+    const size_t pi = ((size_t)bh * Lq + qq) * Lk + kk;
+    float ds = p.ds_ws[pi];
+    float pr = p.probs[pi];
+    if (p.drop_thresh) pr = dropout_keep(p.seed, (uint32_t)pi, p.drop_thresh) ? pr * p.drop_scale : 0.f;
+    const float4* q4 = (const float4*)(sQ + qq * HD + part * 8);
+    const float4* o4 = (const float4*)(sO + qq * HD + part * 8);
+    float4 a0 = q4[0], a1 = q4[1], o0 = o4[0], o1 = o4[1];
+    dK[0] += ds * a0.x; dK[1] += ds * a0.y; dK[2] += ds * a0.z; dK[3] += ds * a0.w;
+    dK[4] += ds * a1.x; dK[5] += ds * a1.y; dK[6] += ds * a1.z; dK[7] += ds * a1.w;
+    dV[0] += pr * o0.x; dV[1] += pr * o0.y; dV[2] += pr * o0.z; dV[3] += pr * o0.w;
+    dV[4] += pr * o1.x; dV[5] += pr * o1.y; dV[6] += pr * o1.z; dV[7] += pr * o1.w;
+  }
+  const size_t ko = (size_t)(b * Lk + kk) * p.ldk + h * HD + part * 8, vo = (size_t)(b * Lk + kk) * p.ldv + h * HD + part * 8;
 #pragma unroll
-      for (int d4 = 0; d4 < HD / 4; ++d4) {
-        float4 a = q4[d4], o = o4[d4];
-        dK[4 * d4 + 0] += ds * a.x; dK[4 * d4 + 1] += ds * a.y; dK[4 * d4 + 2] += ds * a.z; dK[4 * d4 + 3] += ds * a.w;
-        dV[4 * d4 + 0] += pr * o.x; dV[4 * d4 + 1] += pr * o.y; dV[4 * d4 + 2] += pr * o.z; dV[4 * d4 + 3] += pr * o.w;
-      }
-    }
-    const size_t ko = (size_t)(b * Lk + kk) * p.ldk + h * HD, vo = (size_t)(b * Lk + kk) * p.ldv + h * HD;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) {
-      Elem<T>::store(p.dk, ko + d, dK[d] * p.scale);
-      Elem<T>::store(p.dv, vo + d, dV[d]);
-    }
+  for (int d = 0; d < 8; ++d) {
+    Elem<T>::store(p.dk, ko + d, dK[d] * p.scale);
+    Elem<T>::store(p.dv, vo + d, dV[d]);
   }
 }
 
@@ -273,16 +286,21 @@ extern "C" int td_mha_bwd(const void* q, const void* k, const void* v, const voi
   p.q = q; p.k = k; p.v = v; p.dout = dout; p.probs = (float*)probs; p.dwavg = dwavg;
   p.dq = dq; p.dk = dk; p.dv = dv; p.ds_ws = ds_ws;
   hipStream_t st = (hipStream_t)stream;
-  const int Lmax = Lk > Lq ? Lk : Lq;
-  size_t lds = (size_t)(2 * Lmax * 33 + 4 * Lk) * sizeof(float);
-  TD_REQUIRE(lds <= 160 * 1024, "td_mha_bwd: Lq/Lk too large for LDS");
+  size_t ldsA = (size_t)(2 * Lk * 33 + 4 * Lk) * sizeof(float);
+  size_t ldsB = (size_t)(2 * Lq * HD) * sizeof(float);
+  TD_REQUIRE(ldsA <= 160 * 1024 && ldsB <= 160 * 1024, "td_mha_bwd: Lq/Lk too large for LDS");
+  dim3 gridA(B * H, (Lq + QT - 1) / QT), gridB(B * H, (Lk + 63) / 64);
   hipError_t e;
   if (dtype == TD_BF16) {
-    e = hipFuncSetAttribute((const void*)mha_bwd_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    mha_bwd_kernel<u16><<<B * H, 256, lds, st>>>(p);
+    e = hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    mha_bwd_dq_kernel<u16><<<gridA, 256, ldsA, st>>>(p);
+    mha_bwd_dkv_kernel<u16><<<gridB, 256, ldsB, st>>>(p);
   } else if (dtype == TD_F32) {
-    e = hipFuncSetAttribute((const void*)mha_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    mha_bwd_kernel<float><<<B * H, 256, lds, st>>>(p);
+    e = hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    mha_bwd_dq_kernel<float><<<gridA, 256, ldsA, st>>>(p);
+    mha_bwd_dkv_kernel<float><<<gridB, 256, ldsB, st>>>(p);
   } else TD_REQUIRE(false, "td_mha_bwd: bad dtype");
   (void)e;
   return check_launch("td_mha_bwd");

@@ -265,7 +265,9 @@ extern "C" int td_colsum(const void* g, float* out, int rows, int cols, int ld, 
   TD_REQUIRE(g && out, "td_colsum: null pointer");
   if (rows == 0 || cols == 0) return TD_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = 128;
+  // enough row chunks to fill the chip: ~1024 workgroups, at least 8 rows each
+  int rpb = (int)(((long long)rows * ((cols + 255) / 256) + 1023) / 1024);
+  if (rpb < 8) rpb = 8;
   dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
   TD_DISPATCH(dtype, (colsum_kernel<u16><<<grid, 256, 0, st>>>((const u16*)g, out, rows, cols, ld, rpb)),
               (colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)g, out, rows, cols, ld, rpb)), "td_colsum");

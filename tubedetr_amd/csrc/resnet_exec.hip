@@ -1,0 +1,279 @@
+// Native executor of the bottleneck-ResNet trunk (torchvision resnet50/101 body with FrozenBatchNorm folded in):
+// one C call walks the static layer plan and enqueues every kernel of a forward or backward pass on the given
+// stream - no per-layer host round trips through Python (104 convs forward, ~210 GEMM launches backward).
+// Replaces the module-graph execution of models/backbone.py:97-98 (IntermediateLayerGetter(resnet101) forward) and
+// its autograd backward.  Conv order everywhere: stem, then per block conv1, conv2, conv3[, downsample].
+#include <vector>
+
+#include "td_common.h"
+
+namespace td {
+
+struct ConvSpec {
+  int cin, cout, k, stride, pad;
+};
+struct Tens {
+  size_t off;  // byte offset in the workspace
+  int H, W, C;
+};
+struct BlockPlan {
+  int conv[4];  // indices into the conv list: conv1, conv2, conv3, downsample(-1)
+  int stride, stage;
+  Tens in, h1, h2, idt, out;
+};
+struct Plan {
+  std::vector<ConvSpec> convs;
+  std::vector<BlockPlan> blocks;
+  Tens x, stem, pool;
+  size_t total, slot;
+  int es;
+};
+
+static inline int co(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Forward activation layout.  save=1: every tensor has its own region (kept for backward).  save=0: a ring of 6
+// slots of the largest activation (a block keeps at most {in, h1, h2, idt, out} alive).
+static Plan make_plan(int N, int H, int W, const int* nb, int dtype, int save) {
+  Plan P;
+  P.es = dtype == TD_BF16 ? 2 : 4;
+  const int cpad = dtype == TD_BF16 ? 8 : 4;
+  std::vector<Tens*> order;
+  P.convs.push_back({cpad, 64, 7, 2, 3});
+  P.x = {0, H, W, cpad};
+  int h = co(H, 7, 2, 3), w = co(W, 7, 2, 3);
+  P.stem = {0, h, w, 64};
+  h = co(h, 3, 2, 1);
+  w = co(w, 3, 2, 1);
+  P.pool = {0, h, w, 64};
+  int inpl = 64;
+  Tens cur = P.pool;
+  for (int s = 0; s < 4; ++s) {
+    const int planes = 64 << s;
+    for (int j = 0; j < nb[s]; ++j) {
+      BlockPlan b;
+      b.stride = (j == 0 && s > 0) ? 2 : 1;
+      b.stage = s;
+      b.conv[0] = (int)P.convs.size();
+      P.convs.push_back({inpl, planes, 1, 1, 0});
+      b.conv[1] = (int)P.convs.size();
+      P.convs.push_back({planes, planes, 3, b.stride, 1});
+      b.conv[2] = (int)P.convs.size();
+      P.convs.push_back({planes, planes * 4, 1, 1, 0});
+      b.conv[3] = -1;
+      if (j == 0) {
+        b.conv[3] = (int)P.convs.size();
+        P.convs.push_back({inpl, planes * 4, 1, b.stride, 0});
+      }
+      const int ho = co(cur.H, 3, b.stride, 1), wo = co(cur.W, 3, b.stride, 1);
+      b.in = cur;
+      b.h1 = {0, cur.H, cur.W, planes};
+      b.h2 = {0, ho, wo, planes};
+      b.idt = {0, ho, wo, planes * 4};
+      b.out = {0, ho, wo, planes * 4};
+      cur = b.out;
+      inpl = planes * 4;
+      P.blocks.push_back(b);
+    }
+  }
+  auto bytes = [&](const Tens& t) { return align256((size_t)N * t.H * t.W * t.C * P.es); };
+  // assign offsets in execution order
+  size_t maxb = 0;
+  std::vector<Tens*> seq = {&P.x, &P.stem, &P.pool};
+  for (auto& b : P.blocks) {
+    seq.push_back(&b.h1);
+    seq.push_back(&b.h2);
+    if (b.conv[3] >= 0) seq.push_back(&b.idt);
+    seq.push_back(&b.out);
+  }
+  for (auto* t : seq) maxb = std::max(maxb, bytes(*t));
+  P.slot = maxb;
+  size_t off = 0;
+  int ring = 0;
+  for (auto* t : seq) {
+    if (save) {
+      t->off = off;
+      off += bytes(*t);
+    } else {
+      t->off = (size_t)(ring % 6) * maxb;
+      ++ring;
+    }
+  }
+  P.total = save ? off : 6 * maxb;
+  // block inputs alias the previous output
+  Tens prev = P.pool;
+  for (auto& b : P.blocks) {
+    b.in = prev;
+    prev = b.out;
+  }
+  return P;
+}
+
+static int run_conv(const char* ws, const Tens& in, const Tens& out, int N, const ConvSpec& c, const void* w, const float* bias,
+                    const void* residual, int relu, int dtype, td_stream_t st) {
+  td_conv_desc d = {N, in.H, in.W, in.C, out.H, out.W, c.k, c.k, c.stride, c.pad, 0, c.cout, c.cout, 1, 0, 0};
+  td_epilogue e;
+  memset(&e, 0, sizeof(e));
+  e.bias = bias;
+  e.residual = residual;
+  e.relu = relu;
+  return td_conv_gemm(ws + in.off, w, (void*)(ws + out.off), &d, &e, dtype, st);
+}
+
+}  // namespace td
+using namespace td;
+
+extern "C" size_t td_resnet_fwd_ws_bytes(int N, int H, int W, const int* nblocks, int dtype, int save) {
+  return make_plan(N, H, W, nblocks, dtype, save).total;
+}
+
+extern "C" int td_resnet_num_convs(const int* nblocks) {
+  int n = 1;
+  for (int s = 0; s < 4; ++s) n += 3 * nblocks[s] + (nblocks[s] > 0 ? 1 : 0);
+  return n;
+}
+
+extern "C" int td_resnet_fwd(const float* x_nchw, int N, int H, int W, const int* nblocks, const void* const* w_fwd,
+                             const float* const* bias, int save, void* ws, size_t ws_bytes, void** feat, int* feat_hw,
+                             int dtype, td_stream_t stream) {
+  TD_REQUIRE(x_nchw && nblocks && w_fwd && bias && ws && feat, "td_resnet_fwd: null pointer");
+  TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "td_resnet_fwd: bad dtype");
+  Plan P = make_plan(N, H, W, nblocks, dtype, save);
+  TD_REQUIRE(ws_bytes >= P.total, "td_resnet_fwd: workspace too small (%zu < %zu)", ws_bytes, P.total);
+  char* base = (char*)ws;
+  int rc = td_nchw_to_nhwc(x_nchw, base + P.x.off, N, 3, H, W, P.x.C, dtype, stream);
+  if (rc) return rc;
+  rc = run_conv(base, P.x, P.stem, N, P.convs[0], w_fwd[0], bias[0], nullptr, 1, dtype, stream);
+  if (rc) return rc;
+  rc = td_maxpool3x3s2(base + P.stem.off, base + P.pool.off, N, P.stem.H, P.stem.W, 64, dtype, stream);
+  if (rc) return rc;
+  for (auto& b : P.blocks) {
+    const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
+    if ((rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream))) return rc;
+    if ((rc = run_conv(base, b.h1, b.h2, N, P.convs[c2], w_fwd[c2], bias[c2], nullptr, 1, dtype, stream))) return rc;
+    const void* idt = base + b.in.off;
+    if (cd >= 0) {
+      if ((rc = run_conv(base, b.in, b.idt, N, P.convs[cd], w_fwd[cd], bias[cd], nullptr, 0, dtype, stream))) return rc;
+      idt = base + b.idt.off;
+    }
+    if ((rc = run_conv(base, b.h2, b.out, N, P.convs[c3], w_fwd[c3], bias[c3], idt, 1, dtype, stream))) return rc;
+  }
+  const Tens& last = P.blocks.empty() ? P.pool : P.blocks.back().out;
+  *feat = base + last.off;
+  if (feat_hw) {
+    feat_hw[0] = last.H;
+    feat_hw[1] = last.W;
+    feat_hw[2] = last.C;
+  }
+  return TD_OK;
+}
+
+// ---- backward ----
+// ws layout: [ dw_k accumulators (fp32, all trainable convs) | ring of 6 gradient-activation slots ]
+static size_t dwk_bytes(const Plan& P, int first_stage, std::vector<size_t>* offs) {
+  size_t off = 0;
+  if (offs) offs->assign(P.convs.size(), (size_t)-1);
+  for (auto& b : P.blocks) {
+    if (b.stage < first_stage) continue;
+    for (int q = 0; q < 4; ++q) {
+      int ci = b.conv[q];
+      if (ci < 0) continue;
+      const ConvSpec& c = P.convs[ci];
+      if (offs) (*offs)[ci] = off;
+      off += align256((size_t)c.cout * c.k * c.k * c.cin * sizeof(float));
+    }
+  }
+  return off;
+}
+static size_t grad_slot_bytes(const Plan& P, int N, int first_stage) {
+  size_t m = 0;
+  for (auto& b : P.blocks) {
+    if (b.stage < first_stage) continue;
+    for (const Tens* t : {&b.in, &b.h1, &b.h2, &b.out}) m = std::max(m, align256((size_t)N * t->H * t->W * t->C * P.es));
+  }
+  return m;
+}
+
+extern "C" size_t td_resnet_bwd_ws_bytes(int N, int H, int W, const int* nblocks, int first_train_stage, int dtype) {
+  Plan P = make_plan(N, H, W, nblocks, dtype, 1);
+  return dwk_bytes(P, first_train_stage, nullptr) + 6 * grad_slot_bytes(P, N, first_train_stage);
+}
+
+extern "C" int td_resnet_bwd(const void* dfeat, int N, int H, int W, const int* nblocks, int first_train_stage,
+                             const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws,
+                             void* ws, size_t ws_bytes, int dtype, td_stream_t stream) {
+  TD_REQUIRE(dfeat && nblocks && w_dgrad && scale && dW && fwd_ws && ws, "td_resnet_bwd: null pointer");
+  Plan P = make_plan(N, H, W, nblocks, dtype, 1);
+  std::vector<size_t> dwoff;
+  const size_t dwb = dwk_bytes(P, first_train_stage, &dwoff);
+  const size_t slot = grad_slot_bytes(P, N, first_train_stage);
+  TD_REQUIRE(ws_bytes >= dwb + 6 * slot, "td_resnet_bwd: workspace too small");
+  const char* acts = (const char*)fwd_ws;
+  char* base = (char*)ws;
+  char* ring = base + dwb;
+  int rix = 0;
+  auto galloc = [&]() { return ring + (size_t)(rix++ % 6) * slot; };
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(base, 0, dwb, st) != hipSuccess) {
+    set_error("td_resnet_bwd: memset failed");
+    return TD_ERR_LAUNCH;
+  }
+  int rc;
+  auto wgrad = [&](const void* g, const Tens& gt, const Tens& xin, int ci) -> int {
+    const ConvSpec& c = P.convs[ci];
+    td_conv_desc d = {N, xin.H, xin.W, xin.C, gt.H, gt.W, c.k, c.k, c.stride, c.pad, 0, c.cout, c.cout, 1, 0, 0};
+    float* dwk = (float*)(base + dwoff[ci]);
+    int r = td_conv_wgrad(g, acts + xin.off, dwk, &d, c.cout, dtype, 0, stream);
+    if (r) return r;
+    return td_wgrad_finalize(dwk, scale[ci], dW[ci], c.cout, c.cin, c.k, c.k, c.cin, 0, stream);
+  };
+  auto dgrad = [&](const void* g, const Tens& gt, const Tens& xin, int ci, const void* residual, const void* mask, void* out) -> int {
+    const ConvSpec& c = P.convs[ci];
+    td_conv_desc d = {N, gt.H, gt.W, gt.C, xin.H, xin.W, c.k, c.k, c.stride, c.pad, 1, c.cin, c.cin, 1, 0, 0};
+    td_epilogue e;
+    memset(&e, 0, sizeof(e));
+    e.residual = residual;
+    e.mask_src = mask;
+    return td_conv_gemm(g, w_dgrad[ci], out, &d, &e, dtype, stream);
+  };
+  int last = (int)P.blocks.size() - 1;
+  int first = 0;
+  while (first <= last && P.blocks[first].stage < first_train_stage) ++first;
+  if (first > last) return TD_OK;
+  const Tens& fo = P.blocks[last].out;
+  char* g_out = galloc();
+  if ((rc = td_relu_bwd(dfeat, acts + fo.off, g_out, (size_t)N * fo.H * fo.W * fo.C, 1.f, dtype, stream))) return rc;
+  for (int bi = last; bi >= first; --bi) {
+    const BlockPlan& b = P.blocks[bi];
+    const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
+    if ((rc = wgrad(g_out, b.out, b.h2, c3))) return rc;
+    char* g_h2 = galloc();
+    if ((rc = dgrad(g_out, b.out, b.h2, c3, nullptr, acts + b.h2.off, g_h2))) return rc;
+    if ((rc = wgrad(g_h2, b.h2, b.h1, c2))) return rc;
+    char* g_h1 = galloc();
+    if ((rc = dgrad(g_h2, b.h2, b.h1, c2, nullptr, acts + b.h1.off, g_h1))) return rc;
+    if ((rc = wgrad(g_h1, b.h1, b.in, c1))) return rc;
+    if (cd >= 0 && (rc = wgrad(g_out, b.out, b.in, cd))) return rc;
+    if (bi == first) break;  // the first trainable block's input comes from frozen layers
+    char* dx = galloc();
+    const void* xin = acts + b.in.off;
+    if (cd >= 0) {
+      if ((rc = dgrad(g_h1, b.h1, b.in, c1, nullptr, xin, dx))) return rc;
+      const ConvSpec& c = P.convs[cd];
+      if (c.stride == 1) {
+        if ((rc = dgrad(g_out, b.out, b.in, cd, dx, xin, dx))) return rc;
+      } else {  // strided 1x1: scatter-accumulate into the positions the stride touches
+        td_conv_desc d = {N, b.out.H, b.out.W, b.out.C, b.out.H, b.out.W, 1, 1, 1, 0, 0, c.cin, c.cin, c.stride, b.in.H, b.in.W};
+        td_epilogue e;
+        memset(&e, 0, sizeof(e));
+        e.residual = dx;
+        e.mask_src = xin;
+        if ((rc = td_conv_gemm(g_out, w_dgrad[cd], dx, &d, &e, dtype, stream))) return rc;
+      }
+    } else {
+      if ((rc = dgrad(g_h1, b.h1, b.in, c1, g_out, xin, dx))) return rc;
+    }
+    g_out = dx;
+  }
+  return TD_OK;
+}

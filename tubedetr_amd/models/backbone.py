@@ -92,6 +92,7 @@ class ResNetBody(nn.Module):
                 inplanes = planes * 4
             setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
         self.out_channels = inplanes
+        self.layers = tuple(layers)
 
     def blocks(self):
         for li in range(1, 5):
@@ -111,77 +112,82 @@ def _prep(conv: ConvWeight, bn: FrozenBatchNorm2d, dt, need_dgrad, cpad=None):
     return prepared(conv.weight, dt, bn=bn.fold(), need_dgrad=need_dgrad, cpad=cpad)
 
 
+def _conv_list(body: "ResNetBody"):
+    """(conv, bn) pairs in the executor's order: stem, then per block conv1, conv2, conv3[, downsample]."""
+    out = [(body.conv1, body.bn1)]
+    for _, blk in body.blocks():
+        out += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+        if blk.downsample is not None:
+            out.append((blk.downsample[0], blk.downsample[1]))
+    return out
+
+
+def _ptr_array(tensors):
+    import ctypes as C
+
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
 class ResNetTrunkFn(Function):
+    """Whole trunk = one autograd node = one native executor call per direction (csrc/resnet_exec.hip)."""
+
     @staticmethod
-    def forward(ctx, body: ResNetBody, x: torch.Tensor, dt: torch.dtype, *trainable):
+    def forward(ctx, body: "ResNetBody", x: torch.Tensor, dt: torch.dtype, *trainable):
+        import ctypes as C
+
+        from .. import _hip
+
         assert x.dim() == 4 and x.shape[1] == 3, "frames must be (N,3,H,W)"
+        L = _hip.lib()
+        code = _hip.dtype_code(dt)
         vec = ops.vec_of(dt)
-        save = len(trainable) > 0
-        xn = ops.nchw_to_nhwc(x.detach().float().contiguous(), dt, vec)
-        wf, _, b, _ = _prep(body.conv1, body.bn1, dt, False, cpad=vec)
-        y = ops.conv_fwd(xn, wf, b, 7, 7, 2, 3, relu=True)
-        y = ops.maxpool3x3s2(y)
-        saved = []  # per trainable block: (x_in, h1, h2, out)
-        for name, blk in body.blocks():
-            tw_ = blk.conv1.weight.requires_grad  # one prepared-weight cache entry serves the grad and no_grad passes
-            train = tw_ and save
-            w1, _, b1, _ = _prep(blk.conv1, blk.bn1, dt, tw_)
-            w2, _, b2, _ = _prep(blk.conv2, blk.bn2, dt, tw_)
-            w3, _, b3, _ = _prep(blk.conv3, blk.bn3, dt, tw_)
-            h1 = ops.conv_fwd(y, w1, b1, 1, 1, 1, 0, relu=True)
-            h2 = ops.conv_fwd(h1, w2, b2, 3, 3, blk.stride, 1, relu=True)
-            idt = y
-            if blk.downsample is not None:
-                wd_, _, bd, _ = _prep(blk.downsample[0], blk.downsample[1], dt, tw_)
-                idt = ops.conv_fwd(y, wd_, bd, 1, 1, blk.stride, 0)
-            out = ops.conv_fwd(h2, w3, b3, 1, 1, 1, 0, residual=idt, relu=True)
-            if train:
-                saved.append((y, h1, h2, out))
-            y = out
-        ctx.body, ctx.dt, ctx.saved = body, dt, saved
-        return y
+        save = 1 if len(trainable) > 0 else 0
+        x = x.detach().float().contiguous()
+        N, _, H, W = x.shape
+        convs = _conv_list(body)
+        preps = [prepared(c.weight, dt, bn=bn.fold(), need_dgrad=c.weight.requires_grad, cpad=vec if i == 0 else None)
+                 for i, (c, bn) in enumerate(convs)]
+        nb = (C.c_int * 4)(*body.layers)
+        nbytes = L.td_resnet_fwd_ws_bytes(N, H, W, nb, code, save)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        feat_p = C.c_void_p()
+        hw = (C.c_int * 3)()
+        _hip.check(L.td_resnet_fwd(x.data_ptr(), N, H, W, nb, _ptr_array([p[0] for p in preps]), _ptr_array([p[2] for p in preps]), save,
+                                   ws.data_ptr(), nbytes, C.byref(feat_p), hw, code, _hip.stream_ptr()), "td_resnet_fwd")
+        off = feat_p.value - ws.data_ptr()
+        n_el = N * hw[0] * hw[1] * hw[2]
+        feat = ws[off : off + n_el * dt.itemsize].view(dt).view(N, hw[0], hw[1], hw[2])
+        if not save:
+            return feat.clone()  # let the ring workspace go
+        ctx.body, ctx.dt, ctx.ws, ctx.preps, ctx.dims = body, dt, ws, preps, (N, H, W)
+        return feat.clone()
 
     @staticmethod
     def backward(ctx, dfeat):
-        body, dt, saved = ctx.body, ctx.dt, ctx.saved
-        blocks = [(n, b) for n, b in body.blocks() if b.conv1.weight.requires_grad]
-        assert len(blocks) == len(saved)
-        grads = {}
+        import ctypes as C
 
-        def wgrad(g, xin, conv: ConvWeight, bn: FrozenBatchNorm2d):
-            _, _, _, scale = _prep(conv, bn, dt, True)
-            dwk = ops.conv_wgrad(g, xin, conv.k, conv.k, conv.stride, conv.padding)
-            grads[id(conv.weight)] = ops.wgrad_finalize(dwk, scale, tuple(conv.weight.shape), conv.cin)
+        from .. import _hip
 
-        g_out = ops.relu_bwd(dfeat.contiguous(), saved[-1][3])
-        for bi in range(len(blocks) - 1, -1, -1):
-            _, blk = blocks[bi]
-            x_in, h1, h2, _out = saved[bi]
-            _, w3d, _, _ = _prep(blk.conv3, blk.bn3, dt, True)
-            _, w2d, _, _ = _prep(blk.conv2, blk.bn2, dt, True)
-            wgrad(g_out, h2, blk.conv3, blk.bn3)
-            g_h2 = ops.conv_dgrad(g_out, w3d, h2.shape[1:3], 1, 1, 1, 0, mask_src=h2)
-            wgrad(g_h2, h1, blk.conv2, blk.bn2)
-            g_h1 = ops.conv_dgrad(g_h2, w2d, h1.shape[1:3], 3, 3, blk.stride, 1, mask_src=h1)
-            wgrad(g_h1, x_in, blk.conv1, blk.bn1)
-            if blk.downsample is not None:
-                wgrad(g_out, x_in, blk.downsample[0], blk.downsample[1])
-            if bi == 0:
-                break  # the first trainable block's input comes from frozen layers
-            _, w1d, _, _ = _prep(blk.conv1, blk.bn1, dt, True)
-            if blk.downsample is not None:
-                _, wdd, _, _ = _prep(blk.downsample[0], blk.downsample[1], dt, True)
-                dx = ops.conv_dgrad(g_h1, w1d, x_in.shape[1:3], 1, 1, 1, 0, mask_src=x_in)
-                if blk.stride == 1:
-                    dx = ops.conv_dgrad(g_out, wdd, x_in.shape[1:3], 1, 1, 1, 0, residual=dx, mask_src=x_in)
-                else:
-                    ops.conv1x1s_dgrad_scatter(g_out, wdd, dx, blk.stride, mask_src=x_in)
-            else:
-                dx = ops.conv_dgrad(g_h1, w1d, x_in.shape[1:3], 1, 1, 1, 0, residual=g_out, mask_src=x_in)
-            g_out = dx
-        ctx.saved = None
-        tw = body.trainable_weights()
-        return (None, None, None) + tuple(grads.get(id(p)) for p in tw)
+        body, dt, ws, preps = ctx.body, ctx.dt, ctx.ws, ctx.preps
+        N, H, W = ctx.dims
+        L = _hip.lib()
+        code = _hip.dtype_code(dt)
+        convs = _conv_list(body)
+        first_stage = 4
+        for name, blk in body.blocks():
+            if blk.conv1.weight.requires_grad:
+                first_stage = int(name[5]) - 1
+                break
+        nb = (C.c_int * 4)(*body.layers)
+        dWs = [torch.empty_like(c.weight) if c.weight.requires_grad else None for c, _ in convs]
+        nbytes = L.td_resnet_bwd_ws_bytes(N, H, W, nb, first_stage, code)
+        bws = torch.empty(nbytes, dtype=torch.uint8, device=dfeat.device)
+        _hip.check(L.td_resnet_bwd(dfeat.contiguous().data_ptr(), N, H, W, nb, first_stage, _ptr_array([p[1] for p in preps]),
+                                   _ptr_array([p[3] for p in preps]), _ptr_array(dWs), ws.data_ptr(), bws.data_ptr(), nbytes, code,
+                                   _hip.stream_ptr()), "td_resnet_bwd")
+        ctx.ws = ctx.preps = None
+        by_id = {id(c.weight): g for (c, _), g in zip(convs, dWs)}
+        return (None, None, None) + tuple(by_id.get(id(p)) for p in body.trainable_weights())
 
 
 class BackboneBase(nn.Module):
