@@ -10,6 +10,9 @@ import torch
 from .util.misc import NestedTensor
 
 
+_IDX: dict = {}
+
+
 class FixedTokenizer:
     """Tokenizer stand-in for synthetic clips: returns preset ids (there are no tokenizer files offline)."""
 
@@ -45,19 +48,22 @@ def forward_step(model, criterion, weight_dict: Dict[str, float], batch: dict):
 
     t = max(durations)
     dev = outputs["pred_boxes"].device
-    keep = []
-    for i, (_d, inter) in enumerate(zip(durations, batch["inter_idx"])):
-        keep.extend(range(i * t + inter[0], i * t + inter[1] + 1))
-    keep = torch.tensor(keep, dtype=torch.long, device=dev)
-    outputs["pred_boxes"] = outputs["pred_boxes"][keep]
-    for a in outputs.get("aux_outputs", []):
-        a["pred_boxes"] = a["pred_boxes"][keep]
-    time_mask = None
-    if "pred_sted" in outputs:
+    key = (tuple(durations), tuple(map(tuple, batch["inter_idx"])), str(dev))
+    hit = _IDX.get(key)
+    if hit is None:  # built once per (durations, inter_idx): H2D copies inside the step would synchronise the stream
+        keep = []
+        for i, (_d, inter) in enumerate(zip(durations, batch["inter_idx"])):
+            keep.extend(range(i * t + inter[0], i * t + inter[1] + 1))
         time_mask = torch.zeros(len(durations), t, dtype=torch.bool)
         for i, d in enumerate(durations):
             time_mask[i, :d] = True
-        time_mask = time_mask.to(dev)
+        hit = _IDX[key] = (torch.tensor(keep, dtype=torch.long, device=dev), time_mask.to(dev))
+    keep, time_mask = hit
+    outputs["pred_boxes"] = outputs["pred_boxes"][keep]
+    for a in outputs.get("aux_outputs", []):
+        a["pred_boxes"] = a["pred_boxes"][keep]
+    if "pred_sted" not in outputs:
+        time_mask = None
     targets = [{"boxes": bx[None]} for bx in batch["target_boxes"]]
     assert len(targets) == len(outputs["pred_boxes"])
     loss_dict = criterion(outputs, targets, batch["inter_idx"], time_mask)

@@ -258,7 +258,12 @@ class Transformer(nn.Module):
             b, t, k = len(durations), max(durations), self.stride
             vid = torch.arange(b)
             owner = (vid[:, None] * n_clips_per_video + torch.arange(t)[None, :] // k).reshape(-1)
-            hit = (owner.to(device), vid.repeat_interleave(n_clips_per_video).to(device), vid.repeat_interleave(t).to(device))
+            query_mask = torch.ones(b, t, dtype=torch.bool)
+            query_mask[:, 0] = False  # avoid empty masks (transformer.py:236)
+            for i, dur in enumerate(durations):
+                query_mask[i, :dur] = False
+            voc = vid.repeat_interleave(n_clips_per_video)
+            hit = (owner.to(device), voc.to(device), vid.repeat_interleave(t).to(device), query_mask.to(device), voc.tolist())
             self._idx_cache[key] = hit
         return hit
 
@@ -293,7 +298,9 @@ class Transformer(nn.Module):
         assert n == b * n_clips, "every video of the batch must yield the same number of slow clips"
         src_bm = src.permute(0, 2, 3, 1).reshape(n, hw, d)  # zero-copy when src is channels-last
         pos_bm = pos_embed.permute(0, 2, 3, 1).reshape(n, hw, d)
-        owner, vid_of_clip, vid_of_frame = self._indices(durations, n_clips, dev)
+        # all index / mask tensors of a (durations) pattern are built once and stay on the device: a host->device copy
+        # inside the step is a stream synchronisation point
+        owner, vid_of_clip, vid_of_frame, query_mask, clip_vid_list = self._indices(durations, n_clips, dev)
 
         # time queries (transformer.py:211-238): identical for every video, video-major rows [b*t, d]
         nq = query_embed.shape[0]
@@ -302,18 +309,14 @@ class Transformer(nn.Module):
         q = query_embed[0].float()
         qpos_t = (q[None, :] + self.time_embed(t)[:, 0, :]) if self.use_time_embed else q[None, :].expand(t, -1)
         query_pos_bm = qpos_t[None].expand(b, t, d)  # fp32, autograd reaches query_embed.weight
-        query_mask = torch.ones(b, t, dtype=torch.bool)
-        query_mask[:, 0] = False
-        for i, dur in enumerate(durations):
-            query_mask[i, :dur] = False
-        query_mask = query_mask.to(dev)
+        query_mask = query_mask.clone()
 
         text_attention_mask_orig, text_resized, tokenized = self._encode_text(text, dev)  # [B,L], [B,L,d]
         L = text_resized.shape[1]
         assert n_clips == n // text_resized.shape[0] == mask.shape[0] // text_attention_mask_orig.shape[0]
         text_clip = text_resized[vid_of_clip]  # [n, L, d]
         text_mask_clip = text_attention_mask_orig[vid_of_clip]
-        self._repeat_tokenized(tokenized, vid_of_clip)
+        self._repeat_tokenized(tokenized, vid_of_clip, clip_vid_list)
 
         S = hw + L
         x = torch.cat([src_bm.to(dt), text_clip], dim=1)  # [n, S, d]
@@ -347,14 +350,12 @@ class Transformer(nn.Module):
         }
 
     @staticmethod
-    def _repeat_tokenized(tokenized, vid_of_clip):
+    def _repeat_tokenized(tokenized, vid_of_clip, clip_vid_list):
         """The reference repeats the BatchEncoding per clip in place (transformer.py:275-308)."""
         try:
-            idx = vid_of_clip.tolist() if tokenized["input_ids"].device.type == "cpu" else None
-            sel = vid_of_clip.to(tokenized["input_ids"].device)
             if getattr(tokenized, "_encodings", None) is not None:
-                ids = idx if idx is not None else vid_of_clip.cpu().tolist()
-                tokenized._encodings = [tokenized._encodings[i] for i in ids]
+                tokenized._encodings = [tokenized._encodings[i] for i in clip_vid_list]
+            sel = vid_of_clip.to(tokenized["input_ids"].device)
             tokenized["input_ids"] = tokenized["input_ids"][sel]
             tokenized["attention_mask"] = tokenized["attention_mask"][sel]
         except Exception:

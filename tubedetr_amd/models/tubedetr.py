@@ -176,7 +176,8 @@ def _xyxy(b):
 def _paired_giou(a, b):
     area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
     area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    assert (a[:, 2:] >= a[:, :2]).all() and (b[:, 2:] >= b[:, :2]).all(), "degenerate boxes"
+    # (the reference asserts non-degenerate boxes here, util/box_ops.py:105-106; a device-side assert would
+    #  synchronise the stream every step, so it is left to the data pipeline)
     iwh = (torch.min(a[:, 2:], b[:, 2:]) - torch.max(a[:, :2], b[:, :2])).clamp(min=0)
     inter = iwh[:, 0] * iwh[:, 1]
     union = area_a + area_b - inter
@@ -190,12 +191,14 @@ class SetCriterion(nn.Module):
         super().__init__()
         self.losses = losses
         self.sigma = sigma
+        self._pm_cache: dict = {}
+        self._tgt_cache: dict = {}
 
     def loss_boxes(self, outputs, targets, num_boxes):
         src = outputs["pred_boxes"]
         tgt = torch.cat([t["boxes"] for t in targets], dim=0)
         giou = _paired_giou(_xyxy(src), _xyxy(tgt))
-        return {"loss_bbox": (src - tgt).abs().sum() / max(num_boxes, 1), "loss_giou": (1 - giou).sum() / max(num_boxes, 1)}
+        return {"loss_bbox": (src - tgt).abs().sum() / num_boxes, "loss_giou": (1 - giou).sum() / num_boxes}
 
     def loss_sted(self, outputs, num_boxes, inter_idx, positive_map, time_mask=None):
         sted = outputs["pred_sted"].masked_fill(~time_mask[:, :, None], -1e32)
@@ -203,7 +206,10 @@ class SetCriterion(nn.Module):
         grid = torch.arange(T, device=dev)[None, :]
         total = 0
         for col, which in ((0, 0), (1, 1)):
-            tgt = torch.tensor([x[which] for x in inter_idx], dtype=torch.long, device=dev)
+            key = (tuple(x[which] for x in inter_idx), str(dev))
+            tgt = self._tgt_cache.get(key)
+            if tgt is None:
+                tgt = self._tgt_cache[key] = torch.tensor(list(key[0]), dtype=torch.long, device=dev)
             gauss = (-((grid - tgt[:, None]) ** 2) / (2 * self.sigma ** 2)).exp()
             gauss = F.normalize(gauss + eps, p=1, dim=1)
             p = sted[:, :, col].softmax(1)
@@ -228,19 +234,24 @@ class SetCriterion(nn.Module):
 
     def forward(self, outputs, targets, inter_idx=None, time_mask=None):
         dev = next(iter(outputs.values())).device
-        nb = torch.as_tensor([sum(len(t["boxes"]) for t in targets)], dtype=torch.float, device=dev)
-        world = 1
+        n_local = sum(len(t["boxes"]) for t in targets)
         if torch.distributed.is_available() and torch.distributed.is_initialized():
+            nb = torch.as_tensor([n_local], dtype=torch.float, device=dev)
             torch.distributed.all_reduce(nb)
-            world = torch.distributed.get_world_size()
-        num_boxes = torch.clamp(nb / world, min=1).item()
+            # stays a device scalar: no .item() host sync in the step (the reference syncs here, tubedetr.py:413)
+            num_boxes = torch.clamp(nb / torch.distributed.get_world_size(), min=1)[0]
+        else:
+            num_boxes = float(max(n_local, 1))
         positive_map = None
         if inter_idx is not None and time_mask is not None:
-            positive_map = torch.zeros(time_mask.shape, dtype=torch.bool)
-            for kk, idx in enumerate(inter_idx):
-                if idx[0] >= 0:
-                    positive_map[kk, idx[0] : idx[1] + 1] = True
-            positive_map = positive_map.to(time_mask.device)
+            key = (tuple(map(tuple, inter_idx)), tuple(time_mask.shape), str(time_mask.device))
+            positive_map = self._pm_cache.get(key)
+            if positive_map is None:
+                pm = torch.zeros(time_mask.shape, dtype=torch.bool)
+                for kk, idx in enumerate(inter_idx):
+                    if idx[0] >= 0:
+                        pm[kk, idx[0] : idx[1] + 1] = True
+                positive_map = self._pm_cache[key] = pm.to(time_mask.device)
         losses = {}
         for loss in self.losses:
             losses.update(self.get_loss(loss, outputs, targets, num_boxes, inter_idx, positive_map, time_mask))
