@@ -47,7 +47,7 @@ def make_batch(T, res, k, L, seed, device):
     """SURVEY.md 8d synthetic clip, generated directly in HBM: video ~ N(0,1), slow = video[::k], fast = all frames."""
     g = torch.Generator(device=device).manual_seed(seed)
     video = torch.randn(T, 3, res, res, generator=g, device=device)
-    ids = torch.randint(3, 50000, (1, L), generator=g, device=device)
+    ids = torch.randint(3, 50000, (1, L), generator=torch.Generator().manual_seed(seed))  # token ids start on the host, like a tokenizer's output
     ids[:, 0], ids[:, -1] = 0, 2
     cxcy = torch.rand(T, 2, generator=g, device=device) * 0.6 + 0.2
     wh = torch.rand(T, 2, generator=g, device=device) * 0.3 + 0.1
@@ -58,7 +58,7 @@ def make_batch(T, res, k, L, seed, device):
         "fast_mask": torch.zeros((T, res, res), dtype=torch.bool, device=device),
         "durations": [T],
         "input_ids": ids,
-        "attention_mask": torch.ones(1, L, dtype=torch.long, device=device),
+        "attention_mask": torch.ones(1, L, dtype=torch.long),
         "target_boxes": torch.cat([cxcy, wh], 1),
         "inter_idx": [[0, T - 1]],
     }

@@ -42,6 +42,8 @@ int td_abi_version(void);
 #define TD_PROF_FAMILIES 3
 int td_prof_enable(int on);
 int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
+/* CSV (family,dtype,M,N,K,R,stride,mode|splits,ms) of every recorded launch since td_prof_enable(1). */
+int td_prof_dump(const char* path);
 
 /* Geometry of one implicit-GEMM convolution / linear layer.  rows m enumerate (n, ho, wo);
  * k enumerates (r, s, c) with c fastest; the gathered source is NHWC [N][Hs][Ws][C].
@@ -97,9 +99,11 @@ int td_resnet_fwd(const float* x_nchw, int N, int H, int W, const int* nblocks, 
                   td_stream_t stream);
 /* Backward through the stages >= first_train_stage (0..3; the reference trains layer2-4 = 1, backbone.py:82-89):
  * dfeat = gradient of *feat; fwd_ws = the save=1 workspace of the forward; dW[i] receives the gradient of conv i in
- * the parameter's own [Co][Ci][R][S] fp32 layout (FrozenBN scale un-folded); entries of frozen convs are ignored. */
+ * the parameter's own [Co][Ci][R][S] fp32 layout (FrozenBN scale un-folded); entries of frozen convs are ignored.
+ * The forward may have run over N_fwd >= N frames (slow frames first, then the no_grad "fast" frames in the same
+ * launch sequence); only the first N frames are back-propagated. */
 size_t td_resnet_bwd_ws_bytes(int N, int H, int W, const int* nblocks, int first_train_stage, int dtype);
-int td_resnet_bwd(const void* dfeat, int N, int H, int W, const int* nblocks, int first_train_stage,
+int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, const int* nblocks, int first_train_stage,
                   const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws, void* ws,
                   size_t ws_bytes, int dtype, td_stream_t stream);
 

@@ -35,12 +35,13 @@ class Epilogue(C.Structure):
 _P, _I, _F, _U32, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t
 _SIGS = {
     "td_prof_enable": [_I],
+    "td_prof_dump": [C.c_char_p],
     "td_prof_collect": [_I, _I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "td_conv_gemm": [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P],
     "td_conv_wgrad": [_P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
     "td_resnet_num_convs": [C.POINTER(C.c_int)],
     "td_resnet_fwd": [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ, C.POINTER(_P), C.POINTER(C.c_int), _I, _P],
-    "td_resnet_bwd": [_P, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _I, _P],
+    "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _I, _P],
     "td_weight_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "td_wgrad_finalize": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "td_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

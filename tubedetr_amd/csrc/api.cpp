@@ -26,7 +26,7 @@ int check_launch(const char* what) {
 }
 
 // ---- launch timing for bench.py's roofline leg ----
-struct ProfRec { int family, dtype; double flops; hipEvent_t a, b; };
+struct ProfRec { int family, dtype; double flops; hipEvent_t a, b; int M, N, K, R, stride, mode; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -35,8 +35,8 @@ static hipEvent_t get_event() {
   hipEvent_t e; hipEventCreate(&e); return e;
 }
 bool prof_on() { return g_prof; }
-void prof_begin(int family, int dtype, double flops, hipStream_t st) {
-  ProfRec r{family, dtype, flops, get_event(), get_event()};
+void prof_begin(int family, int dtype, double flops, hipStream_t st, int M, int N, int K, int R, int stride, int mode) {
+  ProfRec r{family, dtype, flops, get_event(), get_event(), M, N, K, R, stride, mode};
   hipEventRecord(r.a, st);
   g_recs.push_back(r);
 }
@@ -64,6 +64,20 @@ extern "C" int td_prof_collect(int family, int dtype, long long* launches, doubl
   if (launches) *launches = n;
   if (ms) *ms = t;
   if (flops) *flops = f;
+  return TD_OK;
+}
+
+extern "C" int td_prof_dump(const char* path) {
+  FILE* f = fopen(path, "w");
+  if (!f) { td::set_error("td_prof_dump: cannot open %s", path); return TD_ERR_INVALID; }
+  fprintf(f, "family,dtype,M,N,K,R,stride,mode,ms\n");
+  for (auto& r : td::g_recs) {
+    hipEventSynchronize(r.b);
+    float e = 0.f;
+    hipEventElapsedTime(&e, r.a, r.b);
+    fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%.5f\n", r.family, r.dtype, r.M, r.N, r.K, r.R, r.stride, r.mode, e);
+  }
+  fclose(f);
   return TD_OK;
 }
 

@@ -246,70 +246,91 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
     compute_tile(smem1);
   }
 
-  // ---- epilogue: lane holds out[m][nb..nb+3] per (i,j) tile ----
+  // ---- epilogue ----
+  // The accumulators (4 consecutive channels of 16 different rows per lane) are transposed through LDS - each wave
+  // owns a [WM][WN] fp32 region of the now idle stage buffers, 16-byte chunks XOR-swizzled by the row - so that
+  // bias / residual / mask loads and the output stores run over whole contiguous row segments (WN channels) instead
+  // of 32-byte pieces at a row stride.
+  constexpr int CPRW = WN / 4;          // 16-byte fp32 chunks per staged row
+  constexpr int RPI = 64 / CPRW;        // rows handled per wave instruction
+  __syncthreads();                      // every wave is done reading the stage buffers
+  float* stg = (float*)((wave < 2 ? smem0 : smem1) + (wave & 1) * (WM * WN * 4));
+  static_assert(2 * WM * WN * 4 <= (BM + BN) * 128, "staging region does not fit the stage buffer");
   const float alpha = p.alpha;
-  const bool vec_ok = (d.ldc & 3) == 0;
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    int m = m0 + wy * WM + j * 16 + lr;
-    if (m >= p.M) continue;
-    size_t orow = m;
-    if (d.out_sp > 1) {
-      int n = m / HoWo;
-      int rem = m - n * HoWo;
-      int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-      orow = ((size_t)n * d.out_H + (size_t)ho * d.out_sp) * d.out_W + (size_t)wo * d.out_sp;
-    }
+    const int row = j * 16 + lr;
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      int nb = n0 + wx * WN + i * 16 + 4 * lg;
-      if (nb >= d.Nc) continue;
-      size_t off = orow * d.ldc + nb;
-      float v[4];
+      const int c = (i * 4 + lg) ^ (row & (CPRW - 1));
+      f32x4 a = acc[i][j];
+      *(float4*)(stg + row * WN + c * 4) = make_float4(a[0] * alpha, a[1] * alpha, a[2] * alpha, a[3] * alpha);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int cc = lane % CPRW, rsub = lane / CPRW;
+  const int n = n0 + wx * WN + cc * 4;
+  const bool vec_ok = ((d.ldc & 3) == 0) && (n + 3 < d.Nc);
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias && n < d.Nc) {
+    if (n + 3 < d.Nc) b4 = *(const float4*)(p.bias + n);
+    else {
+      b4.x = p.bias[n];
+      if (n + 1 < d.Nc) b4.y = p.bias[n + 1];
+      if (n + 2 < d.Nc) b4.z = p.bias[n + 2];
+    }
+  }
+#pragma unroll 4
+  for (int it = 0; it < WM / RPI; ++it) {
+    const int row = it * RPI + rsub;
+    const int m = m0 + wy * WM + row;
+    if (m >= p.M || n >= d.Nc) continue;
+    float4 f = *(const float4*)(stg + row * WN + ((cc ^ (row & (CPRW - 1))) * 4));
+    float v[4] = {f.x + b4.x, f.y + b4.y, f.z + b4.z, f.w + b4.w};
+    size_t orow = m;
+    if (d.out_sp > 1) {
+      int ni = m / HoWo;
+      int rem = m - ni * HoWo;
+      int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+      orow = ((size_t)ni * d.out_H + (size_t)ho * d.out_sp) * d.out_W + (size_t)wo * d.out_sp;
+    }
+    const size_t off = orow * d.ldc + n;
+    if (vec_ok) {
+      if (p.residual) {
+        float r4[4];
+        load4<T>(p.residual, off, r4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
-      if (vec_ok && nb + 3 < d.Nc) {
-        if (p.bias) {
-          float4 b4 = *(const float4*)(p.bias + nb);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
-        if (p.residual) {
-          float r4[4];
-          load4<T>(p.residual, off, r4);
+        for (int r = 0; r < 4; ++r) v[r] += r4[r];
+      }
+      if (p.relu) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += r4[r];
-        }
-        if (p.relu) {
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.sigmoid) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (p.sigmoid) {
+        for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+      }
+      if (p.mask_src) {
+        float m4[4];
+        load4<T>(p.mask_src, off, m4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
-        }
-        if (p.mask_src) {
-          float m4[4];
-          load4<T>(p.mask_src, off, m4);
+        for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.f ? v[r] : 0.f;
+      }
+      if (p.drop_thresh) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.f ? v[r] : 0.f;
-        }
-        if (p.drop_thresh) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
-        }
-        store4<T>(p.out, off, v);
-      } else {
-        const int cnt = min(4, d.Nc - nb);
-        for (int r = 0; r < cnt; ++r) {
-          float x = v[r];
-          if (p.bias) x += p.bias[nb + r];
-          if (p.residual) x += Elem<T>::load(p.residual, off + r);
-          if (p.relu) x = fmaxf(x, 0.f);
-          if (p.sigmoid) x = sigmoidf_(x);
-          if (p.mask_src) x = Elem<T>::load(p.mask_src, off + r) > 0.f ? x : 0.f;
-          if (p.drop_thresh) x = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? x * p.drop_scale : 0.f;
-          Elem<T>::store(p.out, off + r, x);
-        }
+        for (int r = 0; r < 4; ++r) v[r] = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
+      }
+      store4<T>(p.out, off, v);
+    } else {
+      const int cnt = min(4, d.Nc - n);
+      for (int r = 0; r < cnt; ++r) {
+        float x = v[r];
+        if (p.residual) x += Elem<T>::load(p.residual, off + r);
+        if (p.relu) x = fmaxf(x, 0.f);
+        if (p.sigmoid) x = sigmoidf_(x);
+        if (p.mask_src) x = Elem<T>::load(p.mask_src, off + r) > 0.f ? x : 0.f;
+        if (p.drop_thresh) x = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? x * p.drop_scale : 0.f;
+        Elem<T>::store(p.out, off + r, x);
       }
     }
   }
@@ -532,7 +553,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   const int MT = cdiv(p.M, BMsel), NTl = cdiv(d->Nc, BNsel);
   dim3 grid(8 * cdiv(MT, 8) * NTl);
   const bool prof = prof_on();
-  if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : TD_PROF_GEMM_128x128, dtype, 2.0 * p.M * d->Nc * p.K, st);
+  if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : TD_PROF_GEMM_128x128, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
   if (dtype == TD_BF16) {
     if (narrow) conv_gemm_kernel<u16, 128, 64><<<grid, 256, 0, st>>>(p);
     else if (small_m) conv_gemm_kernel<u16, 64, 128><<<grid, 256, 0, st>>>(p);
@@ -576,7 +597,7 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
   dim3 grid(cdiv(d->Nc, 128), cdiv(p.K, 128), splits);
   hipStream_t st = (hipStream_t)stream;
   const bool prof = prof_on();
-  if (prof) prof_begin(TD_PROF_WGRAD, dtype, 2.0 * p.M * d->Nc * p.K, st);
+  if (prof) prof_begin(TD_PROF_WGRAD, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, splits);
   if (dtype == TD_BF16) conv_wgrad_kernel<u16><<<grid, 256, 0, st>>>(p);
   else conv_wgrad_kernel<float><<<grid, 256, 0, st>>>(p);
   if (prof) prof_end(st);

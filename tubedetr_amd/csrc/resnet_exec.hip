@@ -195,15 +195,18 @@ static size_t grad_slot_bytes(const Plan& P, int N, int first_stage) {
 }
 
 extern "C" size_t td_resnet_bwd_ws_bytes(int N, int H, int W, const int* nblocks, int first_train_stage, int dtype) {
-  Plan P = make_plan(N, H, W, nblocks, dtype, 1);
+  Plan P = make_plan(N, H, W, nblocks, dtype, 1);  // (only tensor shapes matter here, not offsets)
   return dwk_bytes(P, first_train_stage, nullptr) + 6 * grad_slot_bytes(P, N, first_train_stage);
 }
 
-extern "C" int td_resnet_bwd(const void* dfeat, int N, int H, int W, const int* nblocks, int first_train_stage,
+extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, const int* nblocks, int first_train_stage,
                              const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws,
                              void* ws, size_t ws_bytes, int dtype, td_stream_t stream) {
   TD_REQUIRE(dfeat && nblocks && w_dgrad && scale && dW && fwd_ws && ws, "td_resnet_bwd: null pointer");
-  Plan P = make_plan(N, H, W, nblocks, dtype, 1);
+  TD_REQUIRE(N >= 1 && N <= N_fwd, "td_resnet_bwd: N=%d must be in 1..N_fwd=%d", N, N_fwd);
+  // activation offsets are those of the forward pass over N_fwd frames; the first N frames of every tensor (a
+  // contiguous prefix, frames are the leading dimension) are the ones that carry gradient
+  Plan P = make_plan(N_fwd, H, W, nblocks, dtype, 1);
   std::vector<size_t> dwoff;
   const size_t dwb = dwk_bytes(P, first_train_stage, &dwoff);
   const size_t slot = grad_slot_bytes(P, N, first_train_stage);

@@ -28,7 +28,7 @@ int check_launch(const char* what);
 
 // bench-only launch timing (api.cpp)
 bool prof_on();
-void prof_begin(int family, int dtype, double flops, hipStream_t st);
+void prof_begin(int family, int dtype, double flops, hipStream_t st, int M = 0, int N = 0, int K = 0, int R = 0, int stride = 0, int mode = 0);
 void prof_end(hipStream_t st);
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }

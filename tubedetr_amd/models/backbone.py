@@ -102,10 +102,11 @@ class ResNetBody(nn.Module):
     def trainable_weights(self) -> List[nn.Parameter]:
         return [p for p in self.parameters() if p.requires_grad]
 
-    def forward(self, x: torch.Tensor, compute_dtype: torch.dtype) -> torch.Tensor:
-        """x (N,3,H,W) fp32 NCHW -> layer4 features [N,h,w,2048] NHWC in ``compute_dtype``."""
+    def forward(self, x: torch.Tensor, compute_dtype: torch.dtype, n_grad=None) -> torch.Tensor:
+        """x (N,3,H,W) fp32 NCHW -> layer4 features [N,h,w,2048] NHWC in ``compute_dtype``.  ``n_grad``: only the first
+        n_grad frames are back-propagated (the rest are the reference's no_grad "fast" frames run in the same pass)."""
         tw = self.trainable_weights() if torch.is_grad_enabled() else []
-        return ResNetTrunkFn.apply(self, x, compute_dtype, *tw)
+        return ResNetTrunkFn.apply(self, x, compute_dtype, x.shape[0] if n_grad is None else int(n_grad), *tw)
 
 
 def _prep(conv: ConvWeight, bn: FrozenBatchNorm2d, dt, need_dgrad, cpad=None):
@@ -132,7 +133,7 @@ class ResNetTrunkFn(Function):
     """Whole trunk = one autograd node = one native executor call per direction (csrc/resnet_exec.hip)."""
 
     @staticmethod
-    def forward(ctx, body: "ResNetBody", x: torch.Tensor, dt: torch.dtype, *trainable):
+    def forward(ctx, body: "ResNetBody", x: torch.Tensor, dt: torch.dtype, n_grad: int, *trainable):
         import ctypes as C
 
         from .. import _hip
@@ -159,7 +160,7 @@ class ResNetTrunkFn(Function):
         feat = ws[off : off + n_el * dt.itemsize].view(dt).view(N, hw[0], hw[1], hw[2])
         if not save:
             return feat.clone()  # let the ring workspace go
-        ctx.body, ctx.dt, ctx.ws, ctx.preps, ctx.dims = body, dt, ws, preps, (N, H, W)
+        ctx.body, ctx.dt, ctx.ws, ctx.preps, ctx.dims = body, dt, ws, preps, (n_grad, N, H, W)
         return feat.clone()
 
     @staticmethod
@@ -169,7 +170,7 @@ class ResNetTrunkFn(Function):
         from .. import _hip
 
         body, dt, ws, preps = ctx.body, ctx.dt, ctx.ws, ctx.preps
-        N, H, W = ctx.dims
+        N, N_fwd, H, W = ctx.dims
         L = _hip.lib()
         code = _hip.dtype_code(dt)
         convs = _conv_list(body)
@@ -182,12 +183,12 @@ class ResNetTrunkFn(Function):
         dWs = [torch.empty_like(c.weight) if c.weight.requires_grad else None for c, _ in convs]
         nbytes = L.td_resnet_bwd_ws_bytes(N, H, W, nb, first_stage, code)
         bws = torch.empty(nbytes, dtype=torch.uint8, device=dfeat.device)
-        _hip.check(L.td_resnet_bwd(dfeat.contiguous().data_ptr(), N, H, W, nb, first_stage, _ptr_array([p[1] for p in preps]),
+        _hip.check(L.td_resnet_bwd(dfeat.contiguous().data_ptr(), N, N_fwd, H, W, nb, first_stage, _ptr_array([p[1] for p in preps]),
                                    _ptr_array([p[3] for p in preps]), _ptr_array(dWs), ws.data_ptr(), bws.data_ptr(), nbytes, code,
                                    _hip.stream_ptr()), "td_resnet_bwd")
         ctx.ws = ctx.preps = None
         by_id = {id(c.weight): g for (c, _), g in zip(convs, dWs)}
-        return (None, None, None) + tuple(by_id.get(id(p)) for p in body.trainable_weights())
+        return (None, None, None, None) + tuple(by_id.get(id(p)) for p in body.trainable_weights())
 
 
 class BackboneBase(nn.Module):
@@ -204,8 +205,8 @@ class BackboneBase(nn.Module):
         self.num_channels = num_channels
         self.compute_dtype = torch.float32
 
-    def forward(self, tensor_list: NestedTensor):
-        feat = self.body(tensor_list.tensors, self.compute_dtype)  # [N,h,w,C] NHWC
+    def forward(self, tensor_list: NestedTensor, n_grad=None):
+        feat = self.body(tensor_list.tensors, self.compute_dtype, n_grad)  # [N,h,w,C] NHWC
         n, h, w, _ = feat.shape
         m = tensor_list.mask
         # F.interpolate(mode="nearest") index rule: floor(dst * float32(in/out))  (backbone.py:101-103)
@@ -249,8 +250,8 @@ class Joiner(nn.Sequential):
         self[0].compute_dtype = dt
         self[1].compute_dtype = dt
 
-    def forward(self, tensor_list: NestedTensor):
-        xs = self[0](tensor_list)
+    def forward(self, tensor_list: NestedTensor, n_grad=None):
+        xs = self[0](tensor_list, n_grad)
         out, pos = [], []
         for _, x in xs.items():
             out.append(x)

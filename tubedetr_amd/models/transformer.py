@@ -269,8 +269,16 @@ class Transformer(nn.Module):
 
     def _encode_text(self, text, device):
         if isinstance(text[0], str):
-            tokenized = self.tokenizer.batch_encode_plus(text, padding="longest", return_tensors="pt").to(device)
-            enc = self.text_encoder(input_ids=tokenized["input_ids"], attention_mask=tokenized["attention_mask"])
+            tokenized = self.tokenizer.batch_encode_plus(text, padding="longest", return_tensors="pt")
+            ids, att = tokenized["input_ids"], tokenized["attention_mask"]
+            # decided on the host copy: HF's mask construction otherwise inspects the device mask (a stream sync)
+            no_padding = bool(att.all()) if att.device.type == "cpu" else False
+            if ids.device.type == "cpu" and device.type == "cuda":  # async H2D from pinned memory: no stream sync
+                tokenized["input_ids"] = ids.pin_memory().to(device, non_blocking=True)
+                tokenized["attention_mask"] = att.pin_memory().to(device, non_blocking=True)
+            else:
+                tokenized = tokenized.to(device)
+            enc = self.text_encoder(input_ids=tokenized["input_ids"], attention_mask=None if no_padding else tokenized["attention_mask"])
             hidden = enc.last_hidden_state  # (B, L, 768) fp32
             Bt, L, _ = hidden.shape
             rows = Fk.cast(hidden.reshape(Bt * L, -1), self.compute_dtype)

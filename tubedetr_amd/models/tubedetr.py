@@ -99,17 +99,29 @@ class TubeDETR(nn.Module):
         if not self.stride:
             raise NotImplementedError("stride=0 is outside the HIP hot path")
         b, t, k = len(durations), max(durations), self.stride
-        features, pos = self.backbone(samples)
-        src, mask = features[-1].decompose()
+        merged = self.fast and samples_fast is not None and torch.is_grad_enabled() and samples_fast.tensors.shape[1:] == samples.tensors.shape[1:]
+        if merged:
+            # slow (grad) and fast (no_grad, tubedetr.py:128-129) frames share the trunk weights: one launch sequence over
+            # both, with the slow frames first; only they are saved-for / reached-by backward.
+            n_slow = samples.tensors.shape[0]
+            both = NestedTensor(torch.cat([samples.tensors, samples_fast.tensors]), torch.cat([samples.mask, samples_fast.mask]))
+            features, pos_all = self.backbone(both, n_slow)
+            src_all, mask_all = features[-1].decompose()
+            src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow]]
+            src_fast_feat, mask_fast = src_all[n_slow:].detach(), mask_all[n_slow:]
+        else:
+            features, pos = self.backbone(samples)
+            src, mask = features[-1].decompose()
         dev = src.device
         dest = self._frame_index(durations, dev)
         identity = dest.numel() == b * t
         fast_src = None
         if self.fast:
-            with torch.no_grad():  # the fast branch does not back-propagate into the backbone (tubedetr.py:128-129)
-                features_fast, _ = self.backbone(samples_fast)
-            src_fast, mask_fast = features_fast[-1].decompose()
-            src_fast = self._project(src_fast)
+            if not merged:
+                with torch.no_grad():  # the fast branch does not back-propagate into the backbone (tubedetr.py:128-129)
+                    features_fast, _ = self.backbone(samples_fast)
+                src_fast_feat, mask_fast = features_fast[-1].decompose()
+            src_fast = self._project(src_fast_feat)
         src = self._project(src)
         n, f, h, w = src.shape
         n_clips = math.ceil(t / k)
