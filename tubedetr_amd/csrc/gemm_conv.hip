@@ -13,6 +13,8 @@
 // Replaces the torch Conv2d/Linear (+FrozenBatchNorm2d/ReLU/residual) calls of the reference hot path:
 // models/backbone.py:60-70,97-98 (torchvision resnet101 body), models/tubedetr.py:80,131,134 (input_proj),
 // models/transformer.py:124-125,387,441-445,613-617,643,661-667,748,764-773 and models/tubedetr.py:37-42.
+#include <type_traits>
+
 #include "td_common.h"
 
 namespace td {
@@ -64,6 +66,17 @@ __device__ __forceinline__ void load4<float>(const char* base, size_t off, float
 template <>
 __device__ __forceinline__ void load4<u16>(const char* base, size_t off, float (&o)[4]) {
   uint2 v = *(const uint2*)(base + off * 2);
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T, typename V>
+__device__ __forceinline__ void unpack4(const V& v, float (&o)[4]);
+template <>
+__device__ __forceinline__ void unpack4<float, float4>(const float4& v, float (&o)[4]) {
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void unpack4<u16, uint2>(const uint2& v, float (&o)[4]) {
   o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
   o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
@@ -253,9 +266,37 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
   // of 32-byte pieces at a row stride.
   constexpr int CPRW = WN / 4;          // 16-byte fp32 chunks per staged row
   constexpr int RPI = 64 / CPRW;        // rows handled per wave instruction
+  constexpr int NIT = WM / RPI;
+  static_assert(2 * WM * WN * 4 <= (BM + BN) * 128, "staging region does not fit the stage buffer");
+  using V4 = typename std::conditional<sizeof(T) == 2, uint2, float4>::type;  // 4 elements of T
+  const int cc = lane % CPRW, rsub = lane / CPRW;
+  const int n = n0 + wx * WN + cc * 4;
+  const bool vec_ok = ((d.ldc & 3) == 0) && (n + 3 < d.Nc);
+  // (1) every residual / mask operand of this lane is requested up front - 2*NIT independent loads in flight instead
+  //     of a load->store chain (the output may alias the residual, so the compiler cannot hoist them itself)
+  size_t offs[NIT];
+  bool live[NIT];
+  V4 res[NIT], msk[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int m = m0 + wy * WM + it * RPI + rsub;
+    live[it] = (m < p.M) && (n < d.Nc);
+    size_t orow = live[it] ? m : 0;
+    if (d.out_sp > 1) {
+      int ni = (int)orow / HoWo;
+      int rem = (int)orow - ni * HoWo;
+      int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+      orow = ((size_t)ni * d.out_H + (size_t)ho * d.out_sp) * d.out_W + (size_t)wo * d.out_sp;
+    }
+    offs[it] = orow * d.ldc + n;
+    if (vec_ok && live[it]) {
+      if (p.residual) res[it] = *(const V4*)(p.residual + offs[it] * ES);
+      if (p.mask_src) msk[it] = *(const V4*)(p.mask_src + offs[it] * ES);
+    }
+  }
+  // (2) transpose the accumulators through LDS
   __syncthreads();                      // every wave is done reading the stage buffers
   float* stg = (float*)((wave < 2 ? smem0 : smem1) + (wave & 1) * (WM * WN * 4));
-  static_assert(2 * WM * WN * 4 <= (BM + BN) * 128, "staging region does not fit the stage buffer");
   const float alpha = p.alpha;
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
@@ -268,9 +309,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int cc = lane % CPRW, rsub = lane / CPRW;
-  const int n = n0 + wx * WN + cc * 4;
-  const bool vec_ok = ((d.ldc & 3) == 0) && (n + 3 < d.Nc);
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias && n < d.Nc) {
     if (n + 3 < d.Nc) b4 = *(const float4*)(p.bias + n);
@@ -280,25 +318,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
       if (n + 2 < d.Nc) b4.z = p.bias[n + 2];
     }
   }
-#pragma unroll 4
-  for (int it = 0; it < WM / RPI; ++it) {
+  // (3) row-contiguous epilogue + stores
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (!live[it]) continue;
     const int row = it * RPI + rsub;
-    const int m = m0 + wy * WM + row;
-    if (m >= p.M || n >= d.Nc) continue;
     float4 f = *(const float4*)(stg + row * WN + ((cc ^ (row & (CPRW - 1))) * 4));
     float v[4] = {f.x + b4.x, f.y + b4.y, f.z + b4.z, f.w + b4.w};
-    size_t orow = m;
-    if (d.out_sp > 1) {
-      int ni = m / HoWo;
-      int rem = m - ni * HoWo;
-      int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-      orow = ((size_t)ni * d.out_H + (size_t)ho * d.out_sp) * d.out_W + (size_t)wo * d.out_sp;
-    }
-    const size_t off = orow * d.ldc + n;
+    const size_t off = offs[it];
     if (vec_ok) {
       if (p.residual) {
         float r4[4];
-        load4<T>(p.residual, off, r4);
+        unpack4<T>(res[it], r4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += r4[r];
       }
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
       }
       if (p.mask_src) {
         float m4[4];
-        load4<T>(p.mask_src, off, m4);
+        unpack4<T>(msk[it], m4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.f ? v[r] : 0.f;
       }
