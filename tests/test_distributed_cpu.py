@@ -1,0 +1,110 @@
+"""World-size-2 `gloo` tests (CPU) of the N>1 path: the data-parallel protocol bench.py / main.py use around the model
+(two forward calls through the DDP wrapper before one backward, find_unused_parameters, gradient averaging), the
+criterion's cross-rank num_boxes normalisation (no host sync), per-rank clip sharding and the max-over-ranks timing."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(fn, world=2):
+    port = _free_port()
+    mp.spawn(_entry, args=(world, port, fn), nprocs=world, join=True)
+
+
+def _entry(rank, world, port, fn):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+class TwoPhase(torch.nn.Module):
+    """Stand-in with TubeDETR's calling convention: encode -> cache, decode(cache) -> outputs; one parameter (like
+    RoBERTa's pooler) never reaches the loss."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.enc = torch.nn.Linear(8, 8)
+        self.dec = torch.nn.Linear(8, 4)
+        self.pooler = torch.nn.Linear(8, 8)
+
+    def forward(self, x, encode_and_save=True, memory_cache=None):
+        if encode_and_save:
+            return {"mem": torch.relu(self.enc(x))}
+        return {"pred": self.dec(memory_cache["mem"])}
+
+
+def _ddp_two_calls(rank, world):
+    model = TwoPhase()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+    g = torch.Generator().manual_seed(1000 * rank)  # per-rank clip, like bench.py's 1000*rank+step seeds
+    x = torch.randn(5, 8, generator=g)
+    cache = ddp(x, encode_and_save=True)
+    out = ddp(x, encode_and_save=False, memory_cache=cache)
+    out["pred"].pow(2).sum().backward()
+    assert model.pooler.weight.grad is None or model.pooler.weight.grad.abs().sum() == 0
+    # reference: average over ranks of the single-process gradients
+    ref = TwoPhase()
+    grads = []
+    for r in range(world):
+        ref.zero_grad()
+        xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(1000 * r))
+        ref(xr, False, ref(xr))["pred"].pow(2).sum().backward()
+        grads.append([p.grad.clone() for p in (ref.enc.weight, ref.dec.weight)])
+    for got, a, b in zip((model.enc.weight.grad, model.dec.weight.grad), grads[0], grads[1]):
+        assert torch.allclose(got, (a + b) / world, atol=1e-6)
+
+
+def _criterion_num_boxes(rank, world):
+    from tubedetr_amd.models.tubedetr import SetCriterion
+
+    crit = SetCriterion(["boxes", "sted", "guided_attn"], sigma=1)
+    T = 4 + 2 * rank  # ranks hold different numbers of annotated frames
+    g = torch.Generator().manual_seed(7 + rank)
+    boxes = torch.rand(T, 4, generator=g) * 0.3 + 0.3
+    out = {"pred_boxes": torch.rand(T, 4, generator=g) * 0.3 + 0.3, "pred_sted": torch.randn(1, T, 2, generator=g),
+           "weights": torch.softmax(torch.randn(1, T, T, generator=g), -1)}
+    targets = [{"boxes": b[None]} for b in boxes]
+    tm = torch.ones(1, T, dtype=torch.bool)
+    ld = crit(out, targets, [[0, T - 1]], tm)
+    num_boxes = (4 + 6) / world  # all-reduced sum / world size (tubedetr.py:407-413)
+    expect = (out["pred_boxes"] - boxes).abs().sum() / num_boxes
+    assert torch.allclose(ld["loss_bbox"], expect, atol=1e-6)
+    assert all(torch.isfinite(v) for v in ld.values())
+
+
+def _timing_max(rank, world):
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == float(world)  # bench.py reports the slowest rank's time
+
+
+@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max])
+def test_world_size_2_gloo(fn):
+    _run(fn)
+
+
+def test_bench_batches_are_sharded_by_rank():
+    import bench
+
+    a = bench.make_batch(4, 32, 2, 5, 1000 * 0 + 3, torch.device("cpu"))
+    b = bench.make_batch(4, 32, 2, 5, 1000 * 1 + 3, torch.device("cpu"))
+    assert a["frames"].shape == (2, 3, 32, 32) and a["frames_fast"].shape == (4, 3, 32, 32)
+    assert torch.equal(a["frames"], a["frames_fast"][::2])           # slow = every k-th fast frame (vidstg.py:250-251)
+    assert not torch.equal(a["frames_fast"], b["frames_fast"])       # different clip per rank
+    assert a["durations"] == [4] and a["inter_idx"] == [[0, 3]] and a["target_boxes"].shape == (4, 4)

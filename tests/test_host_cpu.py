@@ -1,0 +1,92 @@
+"""CPU tests of the host-side mirror of the reference interface (no kernels are launched): state-dict layout, freeze
+rule, NestedTensor, mask down-sampling index rule, criterion vs the oracle, refusal to run without a GPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import tubedetr_amd
+from oracle.tubedetr_oracle import OracleConfig, criterion as oracle_criterion, weight_dict as oracle_weight_dict
+from oracle.weights import is_trainable, state_spec
+from tubedetr_amd.models import build_model
+from tubedetr_amd.util.misc import NestedTensor
+
+
+@pytest.fixture(scope="module")
+def built():
+    torch.manual_seed(0)
+    return build_model(tubedetr_amd.default_args(device="cpu"))
+
+
+def test_state_dict_matches_reference_layout(built):
+    model, _, wd = built
+    spec = state_spec(OracleConfig())  # pinned against the reference's own state_dict in oracle/gen_golden.py
+    sd = model.state_dict()
+    assert len(sd) == 923 and list(sd) == list(spec)
+    assert all(tuple(sd[k].shape) == tuple(spec[k]) for k in spec)
+    assert {k for k, p in model.named_parameters() if p.requires_grad} == {k for k in spec if is_trainable(k)}
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 185234182
+    assert wd == oracle_weight_dict(OracleConfig()) and len(wd) == 24
+    # reference init facts: fast_residual zero-initialised, FrozenBN identity, time table is a buffer
+    assert model.transformer.fast_residual.weight.abs().sum() == 0
+    assert "transformer.time_embed.te" in dict(model.named_buffers())
+    for n in ("backbone", "text_encoder"):
+        assert any(n in k for k, _ in model.named_parameters())
+
+
+def test_flag_variants_build_like_the_reference():
+    m, _, _ = build_model(tubedetr_amd.default_args(device="cpu", fast=False, no_tsa=True))
+    assert not hasattr(m.transformer, "fast_encoder") and len(m.state_dict()) == 919
+    with pytest.raises(NotImplementedError):
+        build_model(tubedetr_amd.default_args(device="cpu", fast_mode="gating"))
+    with pytest.raises(NotImplementedError):
+        build_model(tubedetr_amd.default_args(device="cpu", dilation=True))
+
+
+def test_forward_refuses_cpu(built):
+    model, _, _ = built
+    x = NestedTensor(torch.zeros(2, 3, 64, 64), torch.zeros(2, 64, 64, dtype=torch.bool))
+    with pytest.raises((AssertionError, RuntimeError)):
+        model(x, [4], ["a caption"], encode_and_save=True, samples_fast=NestedTensor(torch.zeros(4, 3, 64, 64), torch.zeros(4, 64, 64, dtype=torch.bool)))
+
+
+def test_nested_tensor_from_clips():
+    clips = [torch.randn(3, 4, 20, 30), torch.randn(3, 2, 24, 28)]
+    nt = NestedTensor.from_tensor_list(clips)
+    assert nt.tensors.shape == (6, 3, 24, 30) and nt.mask.shape == (6, 24, 30)
+    assert torch.equal(nt.tensors[1, :, :20, :30], clips[0][:, 1]) and nt.tensors[0, :, 20:].abs().sum() == 0
+    assert not nt.mask[0, :20, :30].any() and nt.mask[0, 20:].all() and nt.mask[4, :, 28:].all()
+    imgs = NestedTensor.from_tensor_list([torch.randn(3, 10, 12), torch.randn(3, 8, 16)])
+    assert imgs.tensors.shape == (2, 3, 10, 16) and imgs.mask[1, 8:].all() and not imgs.mask[1, :8, :16].any()
+
+
+@pytest.mark.parametrize("size", [(352, 11), (224, 7), (356, 12), (353, 12), (100, 4), (587, 19)])
+def test_mask_downsample_index_rule_matches_interpolate(size):
+    from tubedetr_amd.models.backbone import _nearest_index
+
+    n_in, n_out = size
+    m = torch.rand(1, n_in, n_in) > 0.5
+    ref = F.interpolate(m[None].float(), size=(n_out, n_out)).bool()[0]
+    idx = _nearest_index(n_out, n_in, torch.device("cpu"))
+    assert torch.equal(m[:, idx][:, :, idx], ref)
+
+
+def test_criterion_matches_oracle(built):
+    _, crit, _ = built
+    g = torch.Generator().manual_seed(3)
+    b, T = 2, 6
+    durations = [6, 4]
+    mk = lambda n: torch.cat([torch.rand(n, 2, generator=g) * 0.4 + 0.3, torch.rand(n, 2, generator=g) * 0.2 + 0.1], 1)
+    boxes = mk(sum(durations))
+    layer = lambda: {"pred_boxes": mk(sum(durations)), "pred_sted": torch.randn(b, T, 2, generator=g),
+                     "weights": torch.softmax(torch.randn(b, T, T, generator=g), -1), "ca_weights": torch.rand(b * T, 1, 5, generator=g)}
+    out = layer()
+    out["aux_outputs"] = [layer() for _ in range(5)]
+    tm = torch.zeros(b, T, dtype=torch.bool)
+    for i, d in enumerate(durations):
+        tm[i, :d] = True
+    inter = [[0, 5], [1, 3]]
+    got = crit(out, [{"boxes": x[None]} for x in boxes], inter, tm)
+    ref = oracle_criterion(out, boxes, inter, tm, OracleConfig())
+    assert set(got) == set(ref) and len(got) == 24
+    for k in ref:
+        assert torch.allclose(got[k], ref[k], rtol=1e-5, atol=1e-6), k

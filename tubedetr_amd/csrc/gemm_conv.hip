@@ -579,7 +579,8 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   // tile choice: 128x64 for <=64 output channels; 64x128 when 128x128 would leave the 256 CUs under-filled
   const bool narrow = d->Nc <= 64;
   const int tiles128 = cdiv(p.M, 128) * cdiv(d->Nc, 128);
-  const bool small_m = !narrow && tiles128 < 512;
+  // 64x128 (3 workgroups / CU) also for the short-K, HBM-bound 1x1 layers: more loads in flight per CU
+  const bool small_m = !narrow && (tiles128 < 512 || p.K <= 512);
   const int BMsel = small_m ? 64 : 128, BNsel = narrow ? 64 : 128;
   const int MT = cdiv(p.M, BMsel), NTl = cdiv(d->Nc, BNsel);
   dim3 grid(8 * cdiv(MT, 8) * NTl);
