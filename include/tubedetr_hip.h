@@ -39,7 +39,8 @@ int td_abi_version(void);
 #define TD_PROF_GEMM_128x128 0
 #define TD_PROF_GEMM_128x64 1
 #define TD_PROF_WGRAD 2
-#define TD_PROF_FAMILIES 3
+#define TD_PROF_GEMM_64x128 3
+#define TD_PROF_FAMILIES 4
 int td_prof_enable(int on);
 int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
 /* CSV (family,dtype,M,N,K,R,stride,mode|splits,ms) of every recorded launch since td_prof_enable(1). */

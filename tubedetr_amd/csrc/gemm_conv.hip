@@ -378,77 +378,94 @@ struct WgradParams {
   float* dw;
   td_conv_desc d;
   int M, K, ldg, mper;
+  uint32_t g_bytes, src_bytes;
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// LDS image of one stage: G tile [MK][128 channels] and X tile [MK][128 k] - reduction-major rows exactly as they
+// lie in HBM, filled by buffer_load ... lds (lane-linear destination).  The transposing fragment reads
+// (ds_read_b64_tr_b16) of a 32-lane group touch 8 different rows at one column: rows are a full bank period apart, so
+// the 32-byte (bf16) / 64-byte (fp32) column blocks are XOR-swizzled by swz(row) - on the DMA source address and on
+// the read, never on the DMA destination.
+template <int ES>
+__device__ __forceinline__ int wg_swz(int row) {
+  return ES == 2 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (row & 7);
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;
-  constexpr int MK = 64 / ES;              // reduction rows per stage: 32 (bf16) / 16 (fp32)
-  constexpr int CPR = 128 * ES / 16;       // 16-byte chunks per 128-channel row: 16 / 32
-  constexpr int RSB = 128 * ES + 16 * ES;  // padded row stride in bytes: 288 / 576
-  constexpr int TILEB = MK * RSB;          // 9216 both
-  constexpr int LI = MK * CPR / 256;       // chunks per thread per operand = 2
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILEB];
-  auto sG = [&](int buf) -> char* { return smem + buf * (2 * TILEB); };
-  auto sX = [&](int buf) -> char* { return smem + buf * (2 * TILEB) + TILEB; };
+  constexpr int MK = 128 / ES;             // reduction rows per stage: 64 (bf16) / 32 (fp32)
+  constexpr int ROWB = 128 * ES;           // bytes per row: 256 / 512
+  constexpr int CPR = ROWB / 16;           // 16-byte chunks per row: 16 / 32
+  constexpr int RPI = 64 / CPR;            // rows per wave DMA instruction: 4 / 2
+  constexpr int LI = MK / (4 * RPI);       // DMA instructions per wave per operand per stage: 4 / 4
+  constexpr int SWS = ES == 2 ? 1 : 2;     // log2(16-byte chunks per swizzle block): 32 B / 64 B blocks
+  constexpr int TILEB = MK * ROWB;         // 16 KiB
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  __shared__ __attribute__((aligned(16))) char stage0[2 * TILEB];
+  __shared__ __attribute__((aligned(16))) char stage1[2 * TILEB];
 
   const td_conv_desc& d = p.d;
   const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int co0 = blockIdx.x * 128, kk0 = blockIdx.y * 128;
   const int mbeg = blockIdx.z * p.mper;
   const int mend = min(p.M, mbeg + p.mper);
   if (mbeg >= mend) return;
   const int HoWo = d.Ho * d.Wo;
-  const int ch = t % CPR;       // constant chunk column of this thread
-  const int row0 = t / CPR;     // first row; second row = row0 + 256/CPR
-  constexpr int RSTEP = 256 / CPR;
+  const bool pointwise = (d.R * d.S == 1) && d.stride == 1 && d.pad == 0;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
 
-  // gather column info (fixed per thread)
-  const int kk = kk0 + ch * VEC;
-  const bool kvalid = kk < p.K;
-  int r = 0, s = 0, c = kk;
-  if (d.R * d.S > 1) {
-    int tap = kk / d.C;
-    c = kk - tap * d.C;
-    r = tap / d.S;
-    s = tap - r * d.S;
+  // per-lane DMA bookkeeping: instruction i of this wave fills rows (i*4 + wave)*RPI + lane/CPR, LDS chunk lane%CPR
+  int rloc[LI], gcol[LI], xr[LI], xs[LI], xc[LI];
+  bool gok[LI], xok[LI];
+#pragma unroll
+  for (int i = 0; i < LI; ++i) {
+    const int row = (i * 4 + wave) * RPI + lane / CPR;
+    const int c16 = lane % CPR;
+    const int blk = (c16 >> SWS) ^ wg_swz<ES>(row);                    // logical swizzle block stored at this slot
+    const int col = ((blk << SWS) | (c16 & ((1 << SWS) - 1))) * VEC;   // logical column (elements) inside the tile
+    rloc[i] = row;
+    gcol[i] = co0 + col;
+    gok[i] = gcol[i] < d.Nc;
+    const int kk = kk0 + col;
+    xok[i] = kk < p.K;
+    xr[i] = 0; xs[i] = 0; xc[i] = kk;
+    if (d.R * d.S > 1) {
+      int tap = kk / d.C;
+      xc[i] = kk - tap * d.C;
+      xr[i] = tap / d.S;
+      xs[i] = tap - xr[i] * d.S;
+    }
   }
-  const int co = co0 + ch * VEC;
-  const bool covalid = co < d.Nc;
-
-  uint4 rg[LI], rx[LI];
-  auto load_tile = [&](int mb) {
+  auto issue_stage = [&](char* st, int mb) {
 #pragma unroll
     for (int i = 0; i < LI; ++i) {
-      int m = mb + row0 + RSTEP * i;
-      bool ok = m < mend;
-      uint4 vg = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
-      if (ok && covalid) vg = *(const uint4*)(p.g + ((size_t)m * p.ldg + co) * ES);
-      if (ok && kvalid) {
-        int n = m / HoWo;
-        int rem = m - n * HoWo;
-        int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-        int hs = ho * d.stride - d.pad + r, ws = wo * d.stride - d.pad + s;
-        if ((unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws)
-          vx = *(const uint4*)(p.src + ((size_t)((n * d.Hs + hs) * d.Ws + ws) * d.C + c) * ES);
+      const int m = mb + rloc[i];
+      const bool ok = m < mend;
+      uint32_t og = (ok && gok[i]) ? ((uint32_t)m * (uint32_t)p.ldg + (uint32_t)gcol[i]) * ES : OOB;
+      uint32_t ox = OOB;
+      if (ok && xok[i]) {
+        if (pointwise) {
+          ox = ((uint32_t)m * (uint32_t)d.C + (uint32_t)xc[i]) * ES;
+        } else {
+          int n = m / HoWo;
+          int rem = m - n * HoWo;
+          int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+          int hs = ho * d.stride - d.pad + xr[i], ws = wo * d.stride - d.pad + xs[i];
+          if ((unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws)
+            ox = ((uint32_t)((n * d.Hs + hs) * d.Ws + ws) * (uint32_t)d.C + (uint32_t)xc[i]) * ES;
+        }
       }
-      rg[i] = vg;
-      rx[i] = vx;
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < LI; ++i) {
-      int row = row0 + RSTEP * i;
-      *(uint4*)(sG(buf) + row * RSB + ch * 16) = rg[i];
-      *(uint4*)(sX(buf) + row * RSB + ch * 16) = rx[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(st + (i * 4 + wave) * 1024), 16, og, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st + TILEB + (i * 4 + wave) * 1024), 16, ox, 0, 0, 0);
     }
   };
 
-  const int wave = t >> 6, lane = t & 63;
   const int wy = wave >> 1, wx = wave & 1;  // wy: co direction, wx: kk direction
   const int lr = lane & 15, lg = lane >> 4;
   f32x4 acc[4][4];
@@ -457,56 +474,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nit = (mend - mbeg + MK - 1) / MK;
-  load_tile(mbeg);
-  store_tile(0);
-  __syncthreads();
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nit) load_tile(mbeg + (it + 1) * MK);
+  auto compute_stage = [&](const char* st) {
+    const char* sG = st;
+    const char* sX = st + TILEB;
     if constexpr (ES == 2) {
-      // lane p = 4*j+q of each 16-lane group addresses row (8*lg + 4*h + j), columns 4q..4q+3 of the 16-wide
-      // channel tile; the transposing read hands lane lr the 4 rows {8lg+4h+0..3} of column lr.
       const int jrow = lr >> 2, q = lr & 3;
-      uint4 gf[4], xf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const char* base = sG(buf) + (wy * 64 + i * 16 + 4 * q) * 2;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + (8 * lg + jrow) * RSB));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + (8 * lg + 4 + jrow) * RSB));
-        uint2 l2 = *(uint2*)&lo, h2 = *(uint2*)&hi;
-        gf[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+      for (int ks = 0; ks < MK / 32; ++ks) {
+        uint4 gf[4], xf[4];
+        const int r0 = ks * 32 + 8 * lg + jrow, r1 = r0 + 4;
+        const int f = jrow | ((lg & 1) << 2);  // = wg_swz(r0) = wg_swz(r1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cb = (((wy * 4 + i) ^ f) << 5) + q * 8;
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sG + r0 * ROWB + cb));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sG + r1 * ROWB + cb));
+          uint2 l2 = *(uint2*)&lo, h2 = *(uint2*)&hi;
+          gf[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cb = (((wx * 4 + j) ^ f) << 5) + q * 8;
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sX + r0 * ROWB + cb));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sX + r1 * ROWB + cb));
+          uint2 l2 = *(uint2*)&lo, h2 = *(uint2*)&hi;
+          xf[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&gf[i], *(const bf16x8*)&xf[j], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const char* base = sX(buf) + (wx * 64 + j * 16 + 4 * q) * 2;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + (8 * lg + jrow) * RSB));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + (8 * lg + 4 + jrow) * RSB));
-        uint2 l2 = *(uint2*)&lo, h2 = *(uint2*)&hi;
-        xf[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&gf[i], *(const bf16x8*)&xf[j], acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
       for (int s4 = 0; s4 < MK / 4; ++s4) {
         float gf[4], xf[4];
         const int krow = lg + 4 * s4;
+        const int f = krow & 7;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gf[i] = *(const float*)(sG(buf) + krow * RSB + (wy * 64 + i * 16 + lr) * 4);
+        for (int i = 0; i < 4; ++i) gf[i] = *(const float*)(sG + krow * ROWB + (((wy * 4 + i) ^ f) << 6) + lr * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[j] = *(const float*)(sX(buf) + krow * RSB + (wx * 64 + j * 16 + lr) * 4);
+        for (int j = 0; j < 4; ++j) xf[j] = *(const float*)(sX + krow * ROWB + (((wx * 4 + j) ^ f) << 6) + lr * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[i], xf[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (it + 1 < nit) store_tile(buf ^ 1);
+  };
+
+  const int nit = (mend - mbeg + MK - 1) / MK;
+  issue_stage(stage0, mbeg);
+  for (int it = 0; it < nit; it += 2) {
     __syncthreads();
+    if (it + 1 < nit) issue_stage(stage1, mbeg + (it + 1) * MK);
+    compute_stage(stage0);
+    if (it + 1 >= nit) break;
+    __syncthreads();
+    if (it + 2 < nit) issue_stage(stage0, mbeg + (it + 2) * MK);
+    compute_stage(stage1);
   }
   // D[i=co][j=kk]: lane holds co = base + 4*lg + r, kk = base + lr
 #pragma unroll
@@ -585,7 +612,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   const int MT = cdiv(p.M, BMsel), NTl = cdiv(d->Nc, BNsel);
   dim3 grid(8 * cdiv(MT, 8) * NTl);
   const bool prof = prof_on();
-  if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : TD_PROF_GEMM_128x128, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
+  if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : (small_m ? TD_PROF_GEMM_64x128 : TD_PROF_GEMM_128x128), dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
   if (dtype == TD_BF16) {
     if (narrow) conv_gemm_kernel<u16, 128, 64><<<grid, 256, 0, st>>>(p);
     else if (small_m) conv_gemm_kernel<u16, 64, 128><<<grid, 256, 0, st>>>(p);
@@ -615,11 +642,18 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
   p.M = d->N * d->Ho * d->Wo;
   p.K = d->R * d->S * d->C;
   p.ldg = ldg;
-  const int mk = dtype == TD_BF16 ? 32 : 16;
+  {
+    const double es = dtype == TD_BF16 ? 2.0 : 4.0;
+    const double gb = (double)p.M * ldg * es, sb = (double)d->N * d->Hs * d->Ws * d->C * es;
+    TD_REQUIRE(gb < 4294967000.0 && sb < 4294967000.0, "td_conv_wgrad: operand exceeds the 4 GiB buffer-descriptor range");
+    p.g_bytes = (uint32_t)gb;
+    p.src_bytes = (uint32_t)sb;
+  }
+  const int mk = dtype == TD_BF16 ? 64 : 32;
   if (splits < 1) {
-    // aim for ~1024 workgroups (4 per CU) but keep >= 8 reduction stages per split
+    // enough workgroups to fill the chip (~768), but at least 8 reduction stages (512 / 256 rows) per split
     int tiles = cdiv(d->Nc, 128) * cdiv(p.K, 128);
-    splits = cdiv(1024, tiles);
+    splits = cdiv(768, tiles);
     int maxs = cdiv(p.M, 8 * mk);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
