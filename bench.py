@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--roofline-steps", type=int, default=2)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-baseline sample clip (0 = skip)")
+    ap.add_argument("--keep-prepared-weights", action="store_true", help="diagnostic: reuse prepared bf16 weights across steps")
     ap.add_argument("--no-fast", action="store_true")
     ap.add_argument("--no-tsa", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: run in eval mode")
@@ -150,9 +151,13 @@ def main():
     n_batches = a.warmup + a.steps + a.roofline_steps
     batches = [make_batch(T, res, k, L, 1000 * rank + s, dev) for s in range(min(n_batches, 4))]
 
+    from tubedetr_amd.functional import invalidate_prepared
+
     def step(i):
         b = batches[i % len(batches)]
         tok.batch = b
+        if not a.keep_prepared_weights:
+            invalidate_prepared()  # as after an optimizer step: weights are re-cast / re-folded inside the timed step
         net.zero_grad(set_to_none=True)
         loss, _, _, _ = forward_step(net, criterion, weight_dict, b)
         loss.backward()

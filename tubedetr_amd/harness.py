@@ -64,7 +64,7 @@ def forward_step(model, criterion, weight_dict: Dict[str, float], batch: dict):
         a["pred_boxes"] = a["pred_boxes"][keep]
     if "pred_sted" not in outputs:
         time_mask = None
-    targets = [{"boxes": bx[None]} for bx in batch["target_boxes"]]
+    targets = batch["target_boxes"]  # (n_annotated_frames, 4); the criterion also accepts the reference's list of dicts
     assert len(targets) == len(outputs["pred_boxes"])
     loss_dict = criterion(outputs, targets, batch["inter_idx"], time_mask)
     loss = sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)

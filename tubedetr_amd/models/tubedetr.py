@@ -199,6 +199,10 @@ def _paired_giou(a, b):
 
 
 class SetCriterion(nn.Module):
+    """Same loss names / formulas as the reference (tubedetr.py:270-372, 397-460).  The reference loops over the main
+    output and the 5 auxiliary decoder layers in Python (24 x ~15 tiny kernels + as many autograd nodes); here the six
+    layers are stacked and every loss is evaluated once on the stacked tensors - identical values, 6x fewer launches."""
+
     def __init__(self, losses, sigma=1):
         super().__init__()
         self.losses = losses
@@ -206,34 +210,45 @@ class SetCriterion(nn.Module):
         self._pm_cache: dict = {}
         self._tgt_cache: dict = {}
 
+    # ---- per-loss math on stacked layers: leading dim = decoder layer ----
+    def _boxes(self, src, tgt, num_boxes):  # src (Lyr, n, 4), tgt (n, 4)
+        nl = src.shape[0]
+        giou = _paired_giou(_xyxy(src).reshape(-1, 4), _xyxy(tgt).repeat(nl, 1)).view(nl, -1)
+        return {"loss_bbox": (src - tgt).abs().sum((1, 2)) / num_boxes, "loss_giou": (1 - giou).sum(1) / num_boxes}
+
+    def _sted(self, sted, inter_idx, time_mask):  # sted (Lyr, b, T, 2)
+        sted = sted.masked_fill(~time_mask[None, :, :, None], -1e32)
+        T, dev, eps = sted.shape[2], sted.device, 1e-6
+        key = (tuple(map(tuple, inter_idx)), T, str(dev))
+        gauss = self._tgt_cache.get(key)
+        if gauss is None:  # Gaussian start / end targets (b, T, 2), built once per annotation pattern
+            grid = torch.arange(T)[None, :]
+            gs = []
+            for which in (0, 1):
+                tgt = torch.tensor([x[which] for x in inter_idx], dtype=torch.long)
+                g_ = (-((grid - tgt[:, None]) ** 2) / (2 * self.sigma ** 2)).exp()
+                gs.append(F.normalize(g_ + eps, p=1, dim=1))
+            gauss = self._tgt_cache[key] = torch.stack(gs, -1).to(dev)
+        p = sted.softmax(2)
+        kl = p * ((p + eps) / gauss[None]).log() * time_mask[None, :, :, None]
+        return {"loss_sted": kl.sum(-1).mean((1, 2))}
+
+    def _guided(self, w, positive_map, time_mask):  # w (Lyr, b, T, T)
+        excl = positive_map + (~time_mask)
+        loss = (-(1 - w + 1e-6).log()).masked_fill(excl[None, :, :, None], 0)
+        nb_neg = (~excl).sum(1) + 1e-6
+        return {"loss_guided_attn": (loss.sum(3) / nb_neg[None, :, None]).sum(2).mean(1)}
+
+    # ---- reference-style single-layer entry points (kept for API parity) ----
     def loss_boxes(self, outputs, targets, num_boxes):
-        src = outputs["pred_boxes"]
         tgt = torch.cat([t["boxes"] for t in targets], dim=0)
-        giou = _paired_giou(_xyxy(src), _xyxy(tgt))
-        return {"loss_bbox": (src - tgt).abs().sum() / num_boxes, "loss_giou": (1 - giou).sum() / num_boxes}
+        return {k: v[0] for k, v in self._boxes(outputs["pred_boxes"][None], tgt, max(num_boxes, 1) if not torch.is_tensor(num_boxes) else num_boxes).items()}
 
     def loss_sted(self, outputs, num_boxes, inter_idx, positive_map, time_mask=None):
-        sted = outputs["pred_sted"].masked_fill(~time_mask[:, :, None], -1e32)
-        T, dev, eps = sted.shape[1], sted.device, 1e-6
-        grid = torch.arange(T, device=dev)[None, :]
-        total = 0
-        for col, which in ((0, 0), (1, 1)):
-            key = (tuple(x[which] for x in inter_idx), str(dev))
-            tgt = self._tgt_cache.get(key)
-            if tgt is None:
-                tgt = self._tgt_cache[key] = torch.tensor(list(key[0]), dtype=torch.long, device=dev)
-            gauss = (-((grid - tgt[:, None]) ** 2) / (2 * self.sigma ** 2)).exp()
-            gauss = F.normalize(gauss + eps, p=1, dim=1)
-            p = sted[:, :, col].softmax(1)
-            total = total + p * ((p + eps) / gauss).log() * time_mask
-        return {"loss_sted": total.mean()}
+        return {k: v[0] for k, v in self._sted(outputs["pred_sted"][None], inter_idx, time_mask).items()}
 
     def loss_guided_attn(self, outputs, num_boxes, inter_idx, positive_map, time_mask=None):
-        w = outputs["weights"]
-        excl = positive_map + (~time_mask)
-        loss = (-(1 - w + 1e-6).log()).masked_fill(excl[:, :, None], 0)
-        nb_neg = (~excl).sum(1) + 1e-6
-        return {"loss_guided_attn": (loss.sum(2) / nb_neg[:, None]).sum(1).mean()}
+        return {k: v[0] for k, v in self._guided(outputs["weights"][None], positive_map, time_mask).items()}
 
     def get_loss(self, loss, outputs, targets, num_boxes, inter_idx, positive_map, time_mask, **kw):
         if loss == "boxes":
@@ -246,7 +261,11 @@ class SetCriterion(nn.Module):
 
     def forward(self, outputs, targets, inter_idx=None, time_mask=None):
         dev = next(iter(outputs.values())).device
-        n_local = sum(len(t["boxes"]) for t in targets)
+        if torch.is_tensor(targets):  # already concatenated (n, 4) target boxes
+            tgt_boxes, n_local = targets, targets.shape[0]
+        else:
+            n_local = sum(len(t["boxes"]) for t in targets)
+            tgt_boxes = torch.cat([t["boxes"] for t in targets], dim=0) if "boxes" in self.losses else None
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             nb = torch.as_tensor([n_local], dtype=torch.float, device=dev)
             torch.distributed.all_reduce(nb)
@@ -264,12 +283,21 @@ class SetCriterion(nn.Module):
                     if idx[0] >= 0:
                         pm[kk, idx[0] : idx[1] + 1] = True
                 positive_map = self._pm_cache[key] = pm.to(time_mask.device)
+        aux = outputs.get("aux_outputs", [])
+        layers = list(aux) + [outputs]  # main output last
+        stacked = {}
+        if "boxes" in self.losses:
+            stacked.update(self._boxes(torch.stack([o["pred_boxes"] for o in layers]), tgt_boxes, num_boxes))
+        if "sted" in self.losses:
+            stacked.update(self._sted(torch.stack([o["pred_sted"] for o in layers]), inter_idx, time_mask))
+        if "guided_attn" in self.losses:
+            stacked.update(self._guided(torch.stack([o["weights"] for o in layers]), positive_map, time_mask))
         losses = {}
-        for loss in self.losses:
-            losses.update(self.get_loss(loss, outputs, targets, num_boxes, inter_idx, positive_map, time_mask))
-        for i, aux in enumerate(outputs.get("aux_outputs", [])):
-            for loss in self.losses:
-                losses.update({f"{k}_{i}": v for k, v in self.get_loss(loss, aux, targets, num_boxes, inter_idx, positive_map, time_mask).items()})
+        for k, v in stacked.items():
+            parts = v.unbind(0)
+            losses[k] = parts[-1]
+            for i in range(len(aux)):
+                losses[f"{k}_{i}"] = parts[i]
         return losses
 
 
