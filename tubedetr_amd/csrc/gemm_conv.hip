@@ -103,7 +103,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // (row & 7): the DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE address and
 // again on the fragment read.  Out-of-image taps, rows >= M, channels >= Nc and the K tail are given an
 // out-of-range buffer offset, which the hardware returns as zeros - no divergent control flow in the loop.
-template <typename T, int BM, int BN>
+//
+// NST = 2: two stages, one tile in flight (compute-bound shapes).  NST = 3: three stages and COUNTED waits - at each
+// step only the oldest tile is waited for (s_waitcnt vmcnt(#DMA per tile) + raw s_barrier), the next one stays in
+// flight across the barrier, and the residual / mask operands of the epilogue are requested before the K loop - for
+// the short-K, HBM-bound 1x1 layers whose per-workgroup latency chain would otherwise be 5-6 exposed round trips.
+template <typename T, int BM, int BN, int NST>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;   // elements per 16-byte chunk
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
   // scopes, so fragment reads of one stage do not wait (vmcnt) for the DMA that is filling the other stage.
   __shared__ __attribute__((aligned(16))) char smem0[(BM + BN) * 128];
   __shared__ __attribute__((aligned(16))) char smem1[(BM + BN) * 128];
+  __shared__ __attribute__((aligned(16))) char smem2[NST == 3 ? (BM + BN) * 128 : 16];
 
   const td_conv_desc& d = p.d;
   const int t = threadIdx.x;
@@ -247,23 +253,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
     }
   };
 
-  const int nk = (p.K + BK - 1) / BK;
-  issue_tile(smem0);
-  for (int kt = 0; kt < nk; kt += 2) {
-    __syncthreads();  // tile kt has landed in stage 0 (vmcnt(0) + barrier); all waves are done reading stage 1
-    if (kt + 1 < nk) issue_tile(smem1);
-    compute_tile(smem0);
-    if (kt + 1 >= nk) break;
-    __syncthreads();
-    if (kt + 2 < nk) issue_tile(smem0);
-    compute_tile(smem1);
-  }
-
-  // ---- epilogue ----
+  // ---- epilogue operands (defined before the K loop so NST == 3 can request them early) ----
   // The accumulators (4 consecutive channels of 16 different rows per lane) are transposed through LDS - each wave
-  // owns a [WM][WN] fp32 region of the now idle stage buffers, 16-byte chunks XOR-swizzled by the row - so that
-  // bias / residual / mask loads and the output stores run over whole contiguous row segments (WN channels) instead
-  // of 32-byte pieces at a row stride.
+  // owns a [WM][WN] fp32 region of the idle stage buffers, 16-byte chunks XOR-swizzled by the row - so that bias /
+  // residual / mask loads and the output stores run over whole contiguous row segments (WN channels) instead of
+  // 32-byte pieces at a row stride.
   constexpr int CPRW = WN / 4;          // 16-byte fp32 chunks per staged row
   constexpr int RPI = 64 / CPRW;        // rows handled per wave instruction
   constexpr int NIT = WM / RPI;
@@ -272,28 +266,69 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
   const int cc = lane % CPRW, rsub = lane / CPRW;
   const int n = n0 + wx * WN + cc * 4;
   const bool vec_ok = ((d.ldc & 3) == 0) && (n + 3 < d.Nc);
-  // (1) every residual / mask operand of this lane is requested up front - 2*NIT independent loads in flight instead
-  //     of a load->store chain (the output may alias the residual, so the compiler cannot hoist them itself)
   size_t offs[NIT];
   bool live[NIT];
   V4 res[NIT], msk[NIT];
+  // every residual / mask operand of this lane is requested in one go - 2*NIT independent loads in flight instead of
+  // a load->store chain (the output may alias the residual, so the compiler cannot hoist them itself)
+  auto fetch_epilogue_operands = [&]() {
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int m = m0 + wy * WM + it * RPI + rsub;
-    live[it] = (m < p.M) && (n < d.Nc);
-    size_t orow = live[it] ? m : 0;
-    if (d.out_sp > 1) {
-      int ni = (int)orow / HoWo;
-      int rem = (int)orow - ni * HoWo;
-      int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-      orow = ((size_t)ni * d.out_H + (size_t)ho * d.out_sp) * d.out_W + (size_t)wo * d.out_sp;
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wy * WM + it * RPI + rsub;
+      live[it] = (m < p.M) && (n < d.Nc);
+      size_t orow = live[it] ? m : 0;
+      if (d.out_sp > 1) {
+        int ni = (int)orow / HoWo;
+        int rem = (int)orow - ni * HoWo;
+        int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+        orow = ((size_t)ni * d.out_H + (size_t)ho * d.out_sp) * d.out_W + (size_t)wo * d.out_sp;
+      }
+      offs[it] = orow * d.ldc + n;
+      if (vec_ok && live[it]) {
+        if (p.residual) res[it] = *(const V4*)(p.residual + offs[it] * ES);
+        if (p.mask_src) msk[it] = *(const V4*)(p.mask_src + offs[it] * ES);
+      }
     }
-    offs[it] = orow * d.ldc + n;
-    if (vec_ok && live[it]) {
-      if (p.residual) res[it] = *(const V4*)(p.residual + offs[it] * ES);
-      if (p.mask_src) msk[it] = *(const V4*)(p.mask_src + offs[it] * ES);
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  if constexpr (NST == 2) {
+    issue_tile(smem0);
+    for (int kt = 0; kt < nk; kt += 2) {
+      __syncthreads();  // tile kt has landed in stage 0 (vmcnt(0) + barrier); all waves are done reading stage 1
+      if (kt + 1 < nk) issue_tile(smem1);
+      compute_tile(smem0);
+      if (kt + 1 >= nk) break;
+      __syncthreads();
+      if (kt + 2 < nk) issue_tile(smem0);
+      compute_tile(smem1);
+    }
+    fetch_epilogue_operands();
+  } else {
+    fetch_epilogue_operands();
+    issue_tile(smem0);
+    if (nk > 1) issue_tile(smem1);
+    // wait until at most the DMA of ONE younger tile (AI + BI instructions of this wave) is still in flight
+    auto wait_oldest = [&](bool younger_in_flight) {
+      if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    for (int kt = 0; kt < nk; kt += 3) {
+      wait_oldest(kt + 1 < nk);
+      if (kt + 2 < nk) issue_tile(smem2);
+      compute_tile(smem0);
+      if (kt + 1 >= nk) break;
+      wait_oldest(kt + 2 < nk);
+      if (kt + 3 < nk) issue_tile(smem0);
+      compute_tile(smem1);
+      if (kt + 2 >= nk) break;
+      wait_oldest(kt + 3 < nk);
+      if (kt + 4 < nk) issue_tile(smem1);
+      compute_tile(smem2);
     }
   }
+
   // (2) transpose the accumulators through LDS
   __syncthreads();                      // every wave is done reading the stage buffers
   float* stg = (float*)((wave < 2 ? smem0 : smem1) + (wave & 1) * (WM * WN * 4));
@@ -614,13 +649,13 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   const bool prof = prof_on();
   if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : (small_m ? TD_PROF_GEMM_64x128 : TD_PROF_GEMM_128x128), dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
   if (dtype == TD_BF16) {
-    if (narrow) conv_gemm_kernel<u16, 128, 64><<<grid, 256, 0, st>>>(p);
-    else if (small_m) conv_gemm_kernel<u16, 64, 128><<<grid, 256, 0, st>>>(p);
-    else conv_gemm_kernel<u16, 128, 128><<<grid, 256, 0, st>>>(p);
+    if (narrow) conv_gemm_kernel<u16, 128, 64, 3><<<grid, 256, 0, st>>>(p);
+    else if (small_m) conv_gemm_kernel<u16, 64, 128, 3><<<grid, 256, 0, st>>>(p);
+    else conv_gemm_kernel<u16, 128, 128, 2><<<grid, 256, 0, st>>>(p);
   } else {
-    if (narrow) conv_gemm_kernel<float, 128, 64><<<grid, 256, 0, st>>>(p);
-    else if (small_m) conv_gemm_kernel<float, 64, 128><<<grid, 256, 0, st>>>(p);
-    else conv_gemm_kernel<float, 128, 128><<<grid, 256, 0, st>>>(p);
+    if (narrow) conv_gemm_kernel<float, 128, 64, 3><<<grid, 256, 0, st>>>(p);
+    else if (small_m) conv_gemm_kernel<float, 64, 128, 3><<<grid, 256, 0, st>>>(p);
+    else conv_gemm_kernel<float, 128, 128, 2><<<grid, 256, 0, st>>>(p);
   }
   if (prof) prof_end(st);
   return check_launch("td_conv_gemm");
