@@ -45,6 +45,8 @@ int td_prof_enable(int on);
 int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
 /* CSV (family,dtype,M,N,K,R,stride,mode|splits,ms) of every recorded launch since td_prof_enable(1). */
 int td_prof_dump(const char* path);
+/* Debug: when non-NULL, td_conv_gemm workgroups write 6 cycle stamps each into buf[workgroup*8 + i]. */
+int td_debug_set_stamp_buffer(unsigned long long* buf);
 
 /* Geometry of one implicit-GEMM convolution / linear layer.  rows m enumerate (n, ho, wo);
  * k enumerates (r, s, c) with c fastest; the gathered source is NHWC [N][Hs][Ws][C].

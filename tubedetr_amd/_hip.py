@@ -36,6 +36,7 @@ _P, _I, _F, _U32, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t
 _SIGS = {
     "td_prof_enable": [_I],
     "td_prof_dump": [C.c_char_p],
+    "td_debug_set_stamp_buffer": [_P],
     "td_prof_collect": [_I, _I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "td_conv_gemm": [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P],
     "td_conv_wgrad": [_P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],

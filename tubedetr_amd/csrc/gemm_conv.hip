@@ -26,6 +26,7 @@ struct GemmParams {
   td_conv_desc d;
   int M, K;
   uint32_t src_bytes, w_bytes;
+  unsigned long long* dbg;  // optional per-workgroup cycle stamps (tools/stamp_conv.py)
   const float* bias;
   const char* residual;
   const char* mask_src;
@@ -80,6 +81,35 @@ __device__ __forceinline__ void unpack4<u16, uint2>(const uint2& v, float (&o)[4
   o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
   o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
+// 16 bytes of T <-> floats (8 bf16 or 4 fp32); bf16 packing uses the gfx950 v_cvt_pk_bf16_f32 (round-to-nearest-even)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return *(uint32_t*)&v;
+}
+template <typename T>
+__device__ __forceinline__ void unpack16(const uint4& v, float (&o)[16 / sizeof(T)]);
+template <>
+__device__ __forceinline__ void unpack16<float>(const uint4& v, float (&o)[4]) {
+  o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+}
+template <>
+__device__ __forceinline__ void unpack16<u16>(const uint4& v, float (&o)[8]) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack16(const float (&v)[16 / sizeof(T)]);
+template <>
+__device__ __forceinline__ uint4 pack16<float>(const float (&v)[4]) {
+  return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+template <>
+__device__ __forceinline__ uint4 pack16<u16>(const float (&v)[8]) {
+  return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
 template <typename T>
 __device__ __forceinline__ void store4(char* base, size_t off, const float (&v)[4]);
 template <>
@@ -108,8 +138,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // step only the oldest tile is waited for (s_waitcnt vmcnt(#DMA per tile) + raw s_barrier), the next one stays in
 // flight across the barrier, and the residual / mask operands of the epilogue are requested before the K loop - for
 // the short-K, HBM-bound 1x1 layers whose per-workgroup latency chain would otherwise be 5-6 exposed round trips.
-template <typename T, int BM, int BN, int NST>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
+// PW = pointwise (1x1, stride 1, no padding, dense output rows): the gather degenerates to row m at offset m*K, so all
+// the (n,ho,wo)/(r,s,c) index arithmetic is compiled out.
+template <typename T, int BM, int BN, int NST, bool PW>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm_kernel(GemmParams p) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;   // elements per 16-byte chunk
   constexpr int BK = 128 / ES;   // K elements per tile (128 bytes per row)
@@ -143,21 +175,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
   // per-lane row bookkeeping (fixed for the whole K loop)
   int a_img[AI], a_hb[AI], a_wb[AI];
   bool a_ok[AI];
+  uint32_t a_off[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     int m = m0 + (i * 4 + wave) * 8 + lrow;
     a_ok[i] = m < p.M;
-    int mm = a_ok[i] ? m : 0;
-    int n = mm / HoWo;
-    int rem = mm - n * HoWo;
-    int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-    a_img[i] = n * d.Hs * d.Ws;
-    if (d.mode == 0) {
-      a_hb[i] = ho * d.stride - d.pad;
-      a_wb[i] = wo * d.stride - d.pad;
+    if constexpr (PW) {
+      a_off[i] = a_ok[i] ? (uint32_t)m * (uint32_t)p.K * ES : OOB;
     } else {
-      a_hb[i] = ho + d.pad;
-      a_wb[i] = wo + d.pad;
+      int mm = a_ok[i] ? m : 0;
+      int n = mm / HoWo;
+      int rem = mm - n * HoWo;
+      int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+      a_img[i] = n * d.Hs * d.Ws;
+      if (d.mode == 0) {
+        a_hb[i] = ho * d.stride - d.pad;
+        a_wb[i] = wo * d.stride - d.pad;
+      } else {
+        a_hb[i] = ho + d.pad;
+        a_wb[i] = wo + d.pad;
+      }
     }
   }
   uint32_t b_off[BI];
@@ -169,11 +206,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
   // running decomposition of this lane's k index into (r, s, c)
   int kk = chunk * VEC;
   int kr = 0, ks_ = 0, kc = kk;
-  if (d.R * d.S > 1) {
-    int tap = kk / d.C;
-    kc = kk - tap * d.C;
-    kr = tap / d.S;
-    ks_ = tap - kr * d.S;
+  if constexpr (!PW) {
+    if (d.R * d.S > 1) {
+      int tap = kk / d.C;
+      kc = kk - tap * d.C;
+      kr = tap / d.S;
+      ks_ = tap - kr * d.S;
+    }
   }
 
   auto issue_tile = [&](char* stage) {
@@ -182,26 +221,31 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
     const bool kvalid = kk < p.K;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      int hs, ws;
-      bool ok = a_ok[i] && kvalid;
-      if (d.mode == 0) {
-        hs = a_hb[i] + kr;
-        ws = a_wb[i] + ks_;
+      uint32_t off;
+      if constexpr (PW) {
+        off = (kvalid && a_ok[i]) ? a_off[i] + (uint32_t)kk * ES : OOB;
       } else {
-        int th = a_hb[i] - kr, tw = a_wb[i] - ks_;
-        ok = ok && th >= 0 && tw >= 0;
-        if (d.stride == 1) {
-          hs = th; ws = tw;
-        } else if (d.stride == 2) {
-          ok = ok && (((th | tw) & 1) == 0);
-          hs = th >> 1; ws = tw >> 1;
+        int hs, ws;
+        bool ok = a_ok[i] && kvalid;
+        if (d.mode == 0) {
+          hs = a_hb[i] + kr;
+          ws = a_wb[i] + ks_;
         } else {
-          ok = ok && (th % d.stride == 0) && (tw % d.stride == 0);
-          hs = th / d.stride; ws = tw / d.stride;
+          int th = a_hb[i] - kr, tw = a_wb[i] - ks_;
+          ok = ok && th >= 0 && tw >= 0;
+          if (d.stride == 1) {
+            hs = th; ws = tw;
+          } else if (d.stride == 2) {
+            ok = ok && (((th | tw) & 1) == 0);
+            hs = th >> 1; ws = tw >> 1;
+          } else {
+            ok = ok && (th % d.stride == 0) && (tw % d.stride == 0);
+            hs = th / d.stride; ws = tw / d.stride;
+          }
         }
+        ok = ok && (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
+        off = ok ? ((uint32_t)(a_img[i] + hs * d.Ws + ws) * (uint32_t)d.C + (uint32_t)kc) * ES : OOB;
       }
-      ok = ok && (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
-      uint32_t off = ok ? ((uint32_t)(a_img[i] + hs * d.Ws + ws) * (uint32_t)d.C + (uint32_t)kc) * ES : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stA + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
     }
 #pragma unroll
@@ -211,11 +255,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
     }
     // advance this lane's k by one tile
     kk += BK;
-    kc += BK;
-    if (d.R * d.S > 1) {
-      while (kc >= d.C) {
-        kc -= d.C;
-        if (++ks_ == d.S) { ks_ = 0; ++kr; }
+    if constexpr (!PW) {
+      kc += BK;
+      if (d.R * d.S > 1) {
+        while (kc >= d.C) {
+          kc -= d.C;
+          if (++ks_ == d.S) { ks_ = 0; ++kr; }
+        }
       }
     }
   };
@@ -255,29 +301,30 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
 
   // ---- epilogue operands (defined before the K loop so NST == 3 can request them early) ----
   // The accumulators (4 consecutive channels of 16 different rows per lane) are transposed through LDS - each wave
-  // owns a [WM][WN] fp32 region of the idle stage buffers, 16-byte chunks XOR-swizzled by the row - so that bias /
-  // residual / mask loads and the output stores run over whole contiguous row segments (WN channels) instead of
-  // 32-byte pieces at a row stride.
+  // owns a [WM][WN] fp32 region of the idle stage buffers, 16-byte chunks XOR-swizzled by the row - so that every
+  // lane then owns 16 bytes of ONE output row (8 bf16 / 4 fp32 channels): residual / mask loads and the output
+  // stores are dwordx4 over whole contiguous row segments (stores are issue-bound per instruction, not per byte).
   constexpr int CPRW = WN / 4;          // 16-byte fp32 chunks per staged row
-  constexpr int RPI = 64 / CPRW;        // rows handled per wave instruction
+  constexpr int EPL = 16 / ES;          // output elements per lane per row: 8 (bf16) / 4 (fp32)
+  constexpr int LPR = WN / EPL;         // lanes per output row segment
+  constexpr int RPI = 64 / LPR;         // rows handled per wave instruction
   constexpr int NIT = WM / RPI;
   static_assert(2 * WM * WN * 4 <= (BM + BN) * 128, "staging region does not fit the stage buffer");
-  using V4 = typename std::conditional<sizeof(T) == 2, uint2, float4>::type;  // 4 elements of T
-  const int cc = lane % CPRW, rsub = lane / CPRW;
-  const int n = n0 + wx * WN + cc * 4;
-  const bool vec_ok = ((d.ldc & 3) == 0) && (n + 3 < d.Nc);
+  const int cc = lane % LPR, rsub = lane / LPR;
+  const int n = n0 + wx * WN + cc * EPL;
+  const bool vec_ok = ((d.ldc % EPL) == 0) && (n + EPL - 1 < d.Nc);
   size_t offs[NIT];
   bool live[NIT];
-  V4 res[NIT], msk[NIT];
-  // every residual / mask operand of this lane is requested in one go - 2*NIT independent loads in flight instead of
-  // a load->store chain (the output may alias the residual, so the compiler cannot hoist them itself)
+  uint4 res[NIT], msk[NIT];
+  // every residual / mask operand of this lane is requested in one go - 2*NIT independent 16-byte loads in flight
+  // instead of a load->store chain (the output may alias the residual, so the compiler cannot hoist them itself)
   auto fetch_epilogue_operands = [&]() {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int m = m0 + wy * WM + it * RPI + rsub;
       live[it] = (m < p.M) && (n < d.Nc);
       size_t orow = live[it] ? m : 0;
-      if (d.out_sp > 1) {
+      if (!PW && d.out_sp > 1) {
         int ni = (int)orow / HoWo;
         int rem = (int)orow - ni * HoWo;
         int ho = rem / d.Wo, wo = rem - ho * d.Wo;
@@ -285,17 +332,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
       }
       offs[it] = orow * d.ldc + n;
       if (vec_ok && live[it]) {
-        if (p.residual) res[it] = *(const V4*)(p.residual + offs[it] * ES);
-        if (p.mask_src) msk[it] = *(const V4*)(p.mask_src + offs[it] * ES);
+        if (p.residual) res[it] = *(const uint4*)(p.residual + offs[it] * ES);
+        if (p.mask_src) msk[it] = *(const uint4*)(p.mask_src + offs[it] * ES);
       }
     }
   };
 
   const int nk = (p.K + BK - 1) / BK;
+#define TD_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+  TD_STAMP(0);
   if constexpr (NST == 2) {
     issue_tile(smem0);
     for (int kt = 0; kt < nk; kt += 2) {
       __syncthreads();  // tile kt has landed in stage 0 (vmcnt(0) + barrier); all waves are done reading stage 1
+      if (kt == 0) TD_STAMP(1);
       if (kt + 1 < nk) issue_tile(smem1);
       compute_tile(smem0);
       if (kt + 1 >= nk) break;
@@ -303,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
       if (kt + 2 < nk) issue_tile(smem0);
       compute_tile(smem1);
     }
+    TD_STAMP(2);
     fetch_epilogue_operands();
   } else {
     fetch_epilogue_operands();
@@ -329,8 +380,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
     }
   }
 
-  // (2) transpose the accumulators through LDS
-  __syncthreads();                      // every wave is done reading the stage buffers
+  // (2) transpose the accumulators through LDS.  Raw barrier: the operand loads above stay in flight (a
+  //     __syncthreads() would drain vmcnt); the fragment reads of the K loop are complete once their MFMAs issued.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  TD_STAMP(3);
   float* stg = (float*)((wave < 2 ? smem0 : smem1) + (wave & 1) * (WM * WN * 4));
   const float alpha = p.alpha;
 #pragma unroll
@@ -344,51 +398,52 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias && n < d.Nc) {
-    if (n + 3 < d.Nc) b4 = *(const float4*)(p.bias + n);
-    else {
-      b4.x = p.bias[n];
-      if (n + 1 < d.Nc) b4.y = p.bias[n + 1];
-      if (n + 2 < d.Nc) b4.z = p.bias[n + 2];
-    }
-  }
-  // (3) row-contiguous epilogue + stores
+  float bias[EPL];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) bias[r] = (p.bias && n + r < d.Nc) ? p.bias[n + r] : 0.f;
+  TD_STAMP(4);
+  // (3) row-contiguous epilogue + 16-byte stores
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     if (!live[it]) continue;
     const int row = it * RPI + rsub;
-    float4 f = *(const float4*)(stg + row * WN + ((cc ^ (row & (CPRW - 1))) * 4));
-    float v[4] = {f.x + b4.x, f.y + b4.y, f.z + b4.z, f.w + b4.w};
+    const int sw = row & (CPRW - 1);
+    float v[EPL];
+#pragma unroll
+    for (int q = 0; q < EPL / 4; ++q) {
+      float4 f = *(const float4*)(stg + row * WN + (((cc * (EPL / 4) + q) ^ sw) * 4));
+      v[4 * q + 0] = f.x + bias[4 * q + 0]; v[4 * q + 1] = f.y + bias[4 * q + 1];
+      v[4 * q + 2] = f.z + bias[4 * q + 2]; v[4 * q + 3] = f.w + bias[4 * q + 3];
+    }
     const size_t off = offs[it];
     if (vec_ok) {
       if (p.residual) {
-        float r4[4];
-        unpack4<T>(res[it], r4);
+        float r8[EPL];
+        unpack16<T>(res[it], r8);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += r4[r];
+        for (int r = 0; r < EPL; ++r) v[r] += r8[r];
       }
       if (p.relu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       if (p.sigmoid) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+        for (int r = 0; r < EPL; ++r) v[r] = sigmoidf_(v[r]);
       }
       if (p.mask_src) {
-        float m4[4];
-        unpack4<T>(msk[it], m4);
+        float m8[EPL];
+        unpack16<T>(msk[it], m8);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.f ? v[r] : 0.f;
+        for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
       }
       if (p.drop_thresh) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
+        for (int r = 0; r < EPL; ++r) v[r] = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
       }
-      store4<T>(p.out, off, v);
+      *(uint4*)(p.out + off * ES) = pack16<T>(v);
     } else {
-      const int cnt = min(4, d.Nc - n);
+      const int cnt = min(EPL, d.Nc - n);
       for (int r = 0; r < cnt; ++r) {
         float x = v[r];
         if (p.residual) x += Elem<T>::load(p.residual, off + r);
@@ -400,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmParams p) {
       }
     }
   }
+  TD_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -599,6 +655,9 @@ static int validate(const td_conv_desc* d, int dtype, const char* who) {
 
 using namespace td;
 
+static unsigned long long* g_dbg = nullptr;
+extern "C" int td_debug_set_stamp_buffer(unsigned long long* buf) { g_dbg = buf; return TD_OK; }
+
 extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const td_conv_desc* d, const td_epilogue* e,
                             int dtype, td_stream_t stream) {
   TD_REQUIRE(src && wmat && out && d, "td_conv_gemm: null pointer");
@@ -621,6 +680,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
     p.w_bytes = (uint32_t)wb;
   }
   p.alpha = 1.f;
+  p.dbg = g_dbg;
   if (e) {
     p.bias = e->bias;
     p.residual = (const char*)e->residual;
@@ -648,15 +708,22 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   dim3 grid(8 * cdiv(MT, 8) * NTl);
   const bool prof = prof_on();
   if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : (small_m ? TD_PROF_GEMM_64x128 : TD_PROF_GEMM_128x128), dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
+  const bool pw = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && p.d.out_sp == 1 && d->Hs == d->Ho && d->Ws == d->Wo;
+#define TD_LAUNCH(TT, BMv, BNv)                                                                   \
+  do {                                                                                            \
+    if (pw) conv_gemm_kernel<TT, BMv, BNv, 2, true><<<grid, 256, 0, st>>>(p);                    \
+    else conv_gemm_kernel<TT, BMv, BNv, 2, false><<<grid, 256, 0, st>>>(p);                      \
+  } while (0)
   if (dtype == TD_BF16) {
-    if (narrow) conv_gemm_kernel<u16, 128, 64, 3><<<grid, 256, 0, st>>>(p);
-    else if (small_m) conv_gemm_kernel<u16, 64, 128, 3><<<grid, 256, 0, st>>>(p);
-    else conv_gemm_kernel<u16, 128, 128, 2><<<grid, 256, 0, st>>>(p);
+    if (narrow) TD_LAUNCH(u16, 128, 64);
+    else if (small_m) TD_LAUNCH(u16, 64, 128);
+    else TD_LAUNCH(u16, 128, 128);
   } else {
-    if (narrow) conv_gemm_kernel<float, 128, 64, 3><<<grid, 256, 0, st>>>(p);
-    else if (small_m) conv_gemm_kernel<float, 64, 128, 3><<<grid, 256, 0, st>>>(p);
-    else conv_gemm_kernel<float, 128, 128, 2><<<grid, 256, 0, st>>>(p);
+    if (narrow) TD_LAUNCH(float, 128, 64);
+    else if (small_m) TD_LAUNCH(float, 64, 128);
+    else TD_LAUNCH(float, 128, 128);
   }
+#undef TD_LAUNCH
   if (prof) prof_end(st);
   return check_launch("td_conv_gemm");
 }
