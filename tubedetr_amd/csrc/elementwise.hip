@@ -135,13 +135,20 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T* dy, con
       }
     }
   }
+  // combine the 4 waves of the workgroup in LDS, then one atomic per column per workgroup
+  __shared__ float redg[4][64 * LN_MAXJ], redb[4][64 * LN_MAXJ];
+  const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < LN_MAXJ; ++j) {
-    int c = lane + 64 * j;
-    if (j < nj && c < cols) {
-      if (dgamma) atomicAdd(dgamma + c, pg[j]);
-      if (dbeta) atomicAdd(dbeta + c, pb[j]);
+    if (j < nj) {
+      redg[wv][lane + 64 * j] = pg[j];
+      redb[wv][lane + 64 * j] = pb[j];
     }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    if (dgamma) atomicAdd(dgamma + c, redg[0][c] + redg[1][c] + redg[2][c] + redg[3][c]);
+    if (dbeta) atomicAdd(dbeta + c, redb[0][c] + redb[1][c] + redb[2][c] + redb[3][c]);
   }
 }
 
@@ -156,25 +163,72 @@ __global__ void colsum_kernel(const T* g, float* out, int rows, int cols, int ld
   atomicAdd(out + c, acc);
 }
 
+// vectorised column sums: thread = (column group of 16 bytes, row lane); 16-byte loads, LDS reduction over the 8
+// row lanes, one atomic per column per workgroup
 template <typename T>
-__global__ void add_kernel(const T* a, const T* b, T* y, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) Elem<T>::store(y, i, Elem<T>::load(a, i) + (b ? Elem<T>::load(b, i) : 0.f));
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* g, float* out, int rows, int cols, int ld, int rows_per_block) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[8][32 * VEC + 1];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + cg) * VEC;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  if (c0 < cols) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      uint4 v = *(const uint4*)(g + (size_t)r * ld + c0);
+      const T* e = (const T*)&v;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += Elem<T>::load(e, i);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) red[rl][cg * VEC + i] = acc[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 32 * VEC; c += 256) {
+    const int col = blockIdx.x * 32 * VEC + c;
+    if (col < cols) {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += red[j][c];
+      atomicAdd(out + col, sum);
+    }
+  }
 }
 
-template <typename T>
-__global__ void relu_bwd_kernel(const T* dy, const T* y, T* g, size_t n, float scale) {
+// elementwise kernels move 16 bytes per lane per access (8 bf16 / 4 fp32); OP selects the operation:
+// 0: y = a + b (b optional)   1: y = a * scale where b > 0 else 0 (ReLU backward)   2: y = dropout(a)
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void ew_kernel(const T* a, const T* b, T* y, size_t n, float scale, uint32_t thresh, uint32_t seed) {
+  constexpr int VEC = 16 / sizeof(T);
+  const size_t nv = n / VEC;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) Elem<T>::store(g, i, Elem<T>::load(y, i) > 0.f ? Elem<T>::load(dy, i) * scale : 0.f);
-}
-
-template <typename T>
-__global__ void dropout_kernel(const T* x, T* y, size_t n, uint32_t thresh, float scale, uint32_t seed) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) Elem<T>::store(y, i, dropout_keep(seed, (uint32_t)i, thresh) ? Elem<T>::load(x, i) * scale : 0.f);
+  for (size_t v = i; v < nv; v += stride) {
+    uint4 va = ((const uint4*)a)[v], vb = make_uint4(0, 0, 0, 0), vo;
+    if (b) vb = ((const uint4*)b)[v];
+    const T* ea = (const T*)&va;
+    const T* eb = (const T*)&vb;
+    T* eo = (T*)&vo;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float x = Elem<T>::load(ea, k), r;
+      if (OP == 0) r = x + (b ? Elem<T>::load(eb, k) : 0.f);
+      else if (OP == 1) r = Elem<T>::load(eb, k) > 0.f ? x * scale : 0.f;
+      else r = dropout_keep(seed, (uint32_t)(v * VEC + k), thresh) ? x * scale : 0.f;
+      Elem<T>::store(eo, k, r);
+    }
+    ((uint4*)y)[v] = vo;
+  }
+  for (size_t k = nv * VEC + i; k < n; k += stride) {  // tail
+    float x = Elem<T>::load(a, k), r;
+    if (OP == 0) r = x + (b ? Elem<T>::load(b, k) : 0.f);
+    else if (OP == 1) r = Elem<T>::load(b, k) > 0.f ? x * scale : 0.f;
+    else r = dropout_keep(seed, (uint32_t)k, thresh) ? x * scale : 0.f;
+    Elem<T>::store(y, k, r);
+  }
 }
 
 // one block per image; thread per (y,x) token, loops over channels
@@ -253,7 +307,7 @@ extern "C" int td_add_layernorm_bwd(const void* dy, const void* s, const float* 
   if (rows == 0) return TD_OK;
   hipStream_t st = (hipStream_t)stream;
   unsigned g = (rows + 3) / 4;
-  if (g > 512) g = 512;
+  if (g > 256) g = 256;
   TD_DISPATCH(dtype,
               (add_layernorm_bwd_kernel<u16><<<g, 256, 0, st>>>((const u16*)dy, (const u16*)s, mean, rstd, gamma, (const u16*)extra, (u16*)ds, dgamma, dbeta, rows, cols)),
               (add_layernorm_bwd_kernel<float><<<g, 256, 0, st>>>((const float*)dy, (const float*)s, mean, rstd, gamma, (const float*)extra, (float*)ds, dgamma, dbeta, rows, cols)),
@@ -265,6 +319,16 @@ extern "C" int td_colsum(const void* g, float* out, int rows, int cols, int ld, 
   TD_REQUIRE(g && out, "td_colsum: null pointer");
   if (rows == 0 || cols == 0) return TD_OK;
   hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == TD_BF16 ? 8 : 4;
+  if (cols % vec == 0 && ld % vec == 0) {
+    const int gx = (cols + 32 * vec - 1) / (32 * vec);
+    int rpb = (int)(((long long)rows * gx + 511) / 512);  // ~512 workgroups
+    if (rpb < 64) rpb = 64;
+    dim3 grid(gx, (rows + rpb - 1) / rpb);
+    TD_DISPATCH(dtype, (colsum_vec_kernel<u16><<<grid, 256, 0, st>>>((const u16*)g, out, rows, cols, ld, rpb)),
+                (colsum_vec_kernel<float><<<grid, 256, 0, st>>>((const float*)g, out, rows, cols, ld, rpb)), "td_colsum");
+    return check_launch("td_colsum");
+  }
   // enough row chunks to fill the chip: ~1024 workgroups, at least 8 rows each
   int rpb = (int)(((long long)rows * ((cols + 255) / 256) + 1023) / 1024);
   if (rpb < 8) rpb = 8;
@@ -278,10 +342,11 @@ extern "C" int td_add(const void* a, const void* b, void* y, size_t n, int dtype
   TD_REQUIRE(a && y, "td_add: null pointer");
   if (n == 0) return TD_OK;
   hipStream_t st = (hipStream_t)stream;
-  unsigned g = nblk(n);
+  unsigned g = nblk(n / 4 + 1);
   if (g > 4096) g = 4096;
-  TD_DISPATCH(dtype, (add_kernel<u16><<<g, 256, 0, st>>>((const u16*)a, (const u16*)b, (u16*)y, n)),
-              (add_kernel<float><<<g, 256, 0, st>>>((const float*)a, (const float*)b, (float*)y, n)), "td_add");
+  TD_REQUIRE(((uintptr_t)a | (uintptr_t)y | (uintptr_t)b) % 16 == 0, "td_add: pointers must be 16-byte aligned");
+  TD_DISPATCH(dtype, (ew_kernel<u16, 0><<<g, 256, 0, st>>>((const u16*)a, (const u16*)b, (u16*)y, n, 1.f, 0, 0)),
+              (ew_kernel<float, 0><<<g, 256, 0, st>>>((const float*)a, (const float*)b, (float*)y, n, 1.f, 0, 0)), "td_add");
   return check_launch("td_add");
 }
 
@@ -291,8 +356,9 @@ extern "C" int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, flo
   hipStream_t st = (hipStream_t)stream;
   unsigned gr = nblk(n);
   if (gr > 4096) gr = 4096;
-  TD_DISPATCH(dtype, (relu_bwd_kernel<u16><<<gr, 256, 0, st>>>((const u16*)dy, (const u16*)y, (u16*)g, n, scale)),
-              (relu_bwd_kernel<float><<<gr, 256, 0, st>>>((const float*)dy, (const float*)y, (float*)g, n, scale)), "td_relu_bwd");
+  TD_REQUIRE(((uintptr_t)dy | (uintptr_t)y | (uintptr_t)g) % 16 == 0, "td_relu_bwd: pointers must be 16-byte aligned");
+  TD_DISPATCH(dtype, (ew_kernel<u16, 1><<<gr, 256, 0, st>>>((const u16*)dy, (const u16*)y, (u16*)g, n, scale, 0, 0)),
+              (ew_kernel<float, 1><<<gr, 256, 0, st>>>((const float*)dy, (const float*)y, (float*)g, n, scale, 0, 0)), "td_relu_bwd");
   return check_launch("td_relu_bwd");
 }
 
@@ -306,8 +372,9 @@ extern "C" int td_dropout(const void* x, void* y, size_t n, float p, uint32_t se
   uint32_t thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
   if (p > 0.f && !thresh) thresh = 1;
   float scale = 1.f / (1.f - p);
-  TD_DISPATCH(dtype, (dropout_kernel<u16><<<gr, 256, 0, st>>>((const u16*)x, (u16*)y, n, thresh, scale, seed)),
-              (dropout_kernel<float><<<gr, 256, 0, st>>>((const float*)x, (float*)y, n, thresh, scale, seed)), "td_dropout");
+  TD_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "td_dropout: pointers must be 16-byte aligned");
+  TD_DISPATCH(dtype, (ew_kernel<u16, 2><<<gr, 256, 0, st>>>((const u16*)x, nullptr, (u16*)y, n, scale, thresh, seed)),
+              (ew_kernel<float, 2><<<gr, 256, 0, st>>>((const float*)x, nullptr, (float*)y, n, scale, thresh, seed)), "td_dropout");
   return check_launch("td_dropout");
 }
 

@@ -273,13 +273,23 @@ class Transformer(nn.Module):
             ids, att = tokenized["input_ids"], tokenized["attention_mask"]
             # decided on the host copy: HF's mask construction otherwise inspects the device mask (a stream sync)
             no_padding = bool(att.all()) if att.device.type == "cpu" else False
-            if ids.device.type == "cpu" and device.type == "cuda":  # async H2D from pinned memory: no stream sync
-                tokenized["input_ids"] = ids.pin_memory().to(device, non_blocking=True)
-                tokenized["attention_mask"] = att.pin_memory().to(device, non_blocking=True)
-            else:
-                tokenized = tokenized.to(device)
-            enc = self.text_encoder(input_ids=tokenized["input_ids"], attention_mask=None if no_padding else tokenized["attention_mask"])
-            hidden = enc.last_hidden_state  # (B, L, 768) fp32
+            main = torch.cuda.current_stream(device)
+            side = self._text_stream = getattr(self, "_text_stream", None) or torch.cuda.Stream(device)
+            # RoBERTa (hundreds of tiny launches on 30 tokens) is independent of the visual backbone: it runs on its own
+            # HIP stream, concurrently with the trunk's large GEMM kernels; autograd replays its backward there too.
+            with torch.cuda.stream(side):
+                if ids.device.type == "cpu":  # async H2D from pinned memory, on the side stream: no sync with the trunk
+                    tokenized["input_ids"] = ids.pin_memory().to(device, non_blocking=True)
+                    tokenized["attention_mask"] = att.pin_memory().to(device, non_blocking=True)
+                else:
+                    side.wait_stream(main)
+                    tokenized = tokenized.to(device)
+                enc = self.text_encoder(input_ids=tokenized["input_ids"], attention_mask=None if no_padding else tokenized["attention_mask"])
+                hidden_side = enc.last_hidden_state
+            main.wait_stream(side)
+            for t_ in (hidden_side, tokenized["input_ids"], tokenized["attention_mask"]):
+                t_.record_stream(main)
+            hidden = hidden_side  # (B, L, 768) fp32
             Bt, L, _ = hidden.shape
             rows = Fk.cast(hidden.reshape(Bt * L, -1), self.compute_dtype)
             resized = self.resizer(rows).view(Bt, L, -1)  # batch-major [B, L, d]
