@@ -3,6 +3,8 @@
 // stream - no per-layer host round trips through Python (104 convs forward, ~210 GEMM launches backward).
 // Replaces the module-graph execution of models/backbone.py:97-98 (IntermediateLayerGetter(resnet101) forward) and
 // its autograd backward.  Conv order everywhere: stem, then per block conv1, conv2, conv3[, downsample].
+#include <stdlib.h>
+
 #include <vector>
 
 #include "td_common.h"
@@ -214,9 +216,37 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
   const char* acts = (const char*)fwd_ws;
   char* base = (char*)ws;
   char* ring = base + dwb;
-  int rix = 0;
-  auto galloc = [&]() { return ring + (size_t)(rix++ % 6) * slot; };
   hipStream_t st = (hipStream_t)stream;
+  // Weight gradients do not feed the dgrad chain: they (and their finalize kernels) run on an internal second stream,
+  // concurrently with the next layers' dgrad GEMMs - two latency-bound kernel families sharing the chip.  Fork/join
+  // is by events only (no host sync); the call still appears stream-ordered to the caller.
+  static hipStream_t side = nullptr;
+  static std::vector<hipEvent_t> evpool;
+  static const bool use_side = [] { const char* e = getenv("TD_WGRAD_STREAM"); return !(e && e[0] == '0'); }();
+  if (use_side && !side) {
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
+  }
+  hipStream_t wst = (use_side && side) ? side : st;
+  size_t evi = 0;
+  auto next_event = [&]() -> hipEvent_t {
+    if (evi == evpool.size()) {
+      hipEvent_t e;
+      hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      evpool.push_back(e);
+    }
+    return evpool[evi++];
+  };
+  hipEvent_t slot_busy[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // last side-stream reader of a ring slot
+  int rix = 0;
+  auto galloc = [&]() {
+    const int s_ = rix++ % 6;
+    if (wst != st && slot_busy[s_]) {
+      hipStreamWaitEvent(st, slot_busy[s_], 0);  // do not overwrite a gradient a pending wgrad still reads
+      slot_busy[s_] = nullptr;
+    }
+    return ring + (size_t)s_ * slot;
+  };
+  auto slot_of = [&](const void* g) { return (int)(((const char*)g - ring) / slot); };
   if (hipMemsetAsync(base, 0, dwb, st) != hipSuccess) {
     set_error("td_resnet_bwd: memset failed");
     return TD_ERR_LAUNCH;
@@ -226,9 +256,21 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     const ConvSpec& c = P.convs[ci];
     td_conv_desc d = {N, xin.H, xin.W, xin.C, gt.H, gt.W, c.k, c.k, c.stride, c.pad, 0, c.cout, c.cout, 1, 0, 0};
     float* dwk = (float*)(base + dwoff[ci]);
-    int r = td_conv_wgrad(g, acts + xin.off, dwk, &d, c.cout, dtype, 0, stream);
+    if (wst != st) {  // g (and the memset) were produced on the caller's stream
+      hipEvent_t ready = next_event();
+      hipEventRecord(ready, st);
+      hipStreamWaitEvent(wst, ready, 0);
+    }
+    int r = td_conv_wgrad(g, acts + xin.off, dwk, &d, c.cout, dtype, 0, (td_stream_t)wst);
     if (r) return r;
-    return td_wgrad_finalize(dwk, scale[ci], dW[ci], c.cout, c.cin, c.k, c.k, c.cin, 0, stream);
+    r = td_wgrad_finalize(dwk, scale[ci], dW[ci], c.cout, c.cin, c.k, c.k, c.cin, 0, (td_stream_t)wst);
+    if (r) return r;
+    if (wst != st) {
+      hipEvent_t done = next_event();
+      hipEventRecord(done, wst);
+      slot_busy[slot_of(g)] = done;
+    }
+    return TD_OK;
   };
   auto dgrad = [&](const void* g, const Tens& gt, const Tens& xin, int ci, const void* residual, const void* mask, void* out) -> int {
     const ConvSpec& c = P.convs[ci];
@@ -238,6 +280,13 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     e.residual = residual;
     e.mask_src = mask;
     return td_conv_gemm(g, w_dgrad[ci], out, &d, &e, dtype, stream);
+  };
+  auto join = [&]() {
+    if (wst != st) {
+      hipEvent_t fin = next_event();
+      hipEventRecord(fin, wst);
+      hipStreamWaitEvent(st, fin, 0);
+    }
   };
   int last = (int)P.blocks.size() - 1;
   int first = 0;
@@ -278,5 +327,6 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     }
     g_out = dx;
   }
+  join();
   return TD_OK;
 }
