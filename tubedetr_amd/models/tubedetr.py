@@ -61,6 +61,10 @@ class TubeDETR(nn.Module):
         if sted:
             self.sted_embed = MLP(hidden_dim, hidden_dim, 2, 2, dropout=0.5)
         self._idx_cache: dict = {}
+        # Opt-in (bench.py / callers whose data pipeline guarantees it, like datasets/vidstg.py:250-251 does): the slow
+        # frames ARE the fast frames [::stride] of each video.  The trunk then runs once over the fast frames only
+        # (slow ones first, so backward still walks a contiguous prefix) instead of recomputing the same pixels.
+        self.slow_frames_are_strided_fast = False
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dt: torch.dtype):
@@ -77,6 +81,22 @@ class TubeDETR(nn.Module):
         rows = feat.permute(0, 2, 3, 1).reshape(n * h * w, c)
         y = Fk.linear(rows, self.input_proj.weight.view(self.input_proj.out_channels, c), self.input_proj.bias)
         return y.view(n, h, w, -1).permute(0, 3, 1, 2)
+
+    def _dedupe_index(self, durations, device):
+        """perm: fast-frame indices with each video's slow frames (0, k, 2k, ...) first, in the slow batch order;
+        inv: position of every fast frame inside the permuted batch."""
+        key = ("dedupe", tuple(durations), self.stride, str(device))
+        if key not in self._idx_cache:
+            slow, rest, base = [], [], 0
+            for d in durations:
+                slow += [base + j for j in range(0, d, self.stride)]
+                rest += [base + j for j in range(d) if j % self.stride]
+                base += d
+            perm = torch.tensor(slow + rest, dtype=torch.long)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel())
+            self._idx_cache[key] = (perm.to(device), inv.to(device))
+        return self._idx_cache[key]
 
     def _frame_index(self, durations, device):
         key = (tuple(durations), str(device))
@@ -100,7 +120,17 @@ class TubeDETR(nn.Module):
             raise NotImplementedError("stride=0 is outside the HIP hot path")
         b, t, k = len(durations), max(durations), self.stride
         merged = self.fast and samples_fast is not None and torch.is_grad_enabled() and samples_fast.tensors.shape[1:] == samples.tensors.shape[1:]
-        if merged:
+        if merged and self.slow_frames_are_strided_fast and sum(durations) == samples_fast.tensors.shape[0]:
+            # one trunk pass over the fast frames, permuted so that the slow (= every k-th) frames come first
+            n_slow = samples.tensors.shape[0]
+            perm, inv = self._dedupe_index(durations, samples_fast.tensors.device)
+            assert perm.numel() == samples_fast.tensors.shape[0] and n_slow == sum(math.ceil(d / k) for d in durations)
+            both = NestedTensor(samples_fast.tensors[perm], samples_fast.mask[perm])
+            features, pos_all = self.backbone(both, n_slow)
+            src_all, mask_all = features[-1].decompose()
+            src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow]]
+            src_fast_feat, mask_fast = src_all.detach()[inv], mask_all[inv]
+        elif merged:
             # slow (grad) and fast (no_grad, tubedetr.py:128-129) frames share the trunk weights: one launch sequence over
             # both, with the slow frames first; only they are saved-for / reached-by backward.
             n_slow = samples.tensors.shape[0]
