@@ -153,8 +153,8 @@ def test_dedupe_slow_frames_is_exact():
     from oracle.weights import fill_state, state_spec, synthetic_batch
     from tubedetr_amd.harness import FixedTokenizer, batch_to, forward_step
 
-    cfg = OracleConfig(stride=3)
-    batch = synthetic_batch(T=7, res=64, k=3, L=5, seed=41, durations=[7, 5])
+    cfg = OracleConfig(stride=4)
+    batch = synthetic_batch(T=8, res=64, k=4, L=5, seed=41, durations=[8, 6])
     sd = fill_state(state_spec(cfg), 13)
     dev = torch.device("cuda:0")
     res = {}
