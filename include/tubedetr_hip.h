@@ -117,6 +117,19 @@ int td_weight_prep(const float* W, const float* bn_w, const float* bn_b, const f
                    const float* bias, int Co, int Ci, int R, int S, int Cpad, void* w_fwd, void* w_dgrad,
                    float* bias_out, float* scale_out, int dtype, td_stream_t stream);
 
+/* Batched form of td_weight_prep: ONE launch prepares every layer of a model.  `items_dev` is a device copy of an
+ * array of n td_prep_item (the caller uploads it once; it only holds pointers and sizes, which are stable across
+ * optimizer steps).  blk0 = exclusive prefix sum of the items' workgroup counts ceil(Co_alloc/16)*ceil(Cpad/32);
+ * total_blocks = their sum.  Co_alloc >= Co rows are written (rows >= Co are zero: padded output layers). */
+typedef struct td_prep_item {
+  const float* W;
+  const float *bn_w, *bn_b, *bn_rm, *bn_rv, *bias;
+  void *w_fwd, *w_dgrad;
+  float *bias_out, *scale_out;
+  int Co, Ci, RS, Cpad, Co_alloc, blk0;
+} td_prep_item;
+int td_weight_prep_batch(const td_prep_item* items_dev, int n, int total_blocks, int dtype, td_stream_t stream);
+
 /* dW[co][ci][r][s] (+)= dw_k[co][r][s][ci] * scale[co]  (scale may be NULL). */
 int td_wgrad_finalize(const float* dw_k, const float* scale, float* dW, int Co, int Ci, int R, int S, int Cpad,
                       int accumulate, td_stream_t stream);

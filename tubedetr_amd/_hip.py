@@ -19,6 +19,11 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("N", "Hs", "Ws", "C", "Ho", "Wo", "R", "S", "stride", "pad", "mode", "Nc", "ldc", "out_sp", "out_H", "out_W")]
 
 
+class PrepItem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W", "bn_w", "bn_b", "bn_rm", "bn_rv", "bias", "w_fwd", "w_dgrad", "bias_out", "scale_out")] + \
+               [(n, C.c_int) for n in ("Co", "Ci", "RS", "Cpad", "Co_alloc", "blk0")]
+
+
 class Epilogue(C.Structure):
     _fields_ = [
         ("bias", C.c_void_p),
@@ -43,6 +48,7 @@ _SIGS = {
     "td_resnet_num_convs": [C.POINTER(C.c_int)],
     "td_resnet_fwd": [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ, C.POINTER(_P), C.POINTER(C.c_int), _I, _P],
     "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _I, _P],
+    "td_weight_prep_batch": [_P, _I, _I, _I, _P],
     "td_weight_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "td_wgrad_finalize": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "td_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -101,7 +107,8 @@ def check(rc: int, what: str = ""):
 
 
 def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream (the C getter is ~20x cheaper than torch.cuda.current_stream())."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def dtype_code(dt: torch.dtype) -> int:

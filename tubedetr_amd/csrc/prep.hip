@@ -40,6 +40,72 @@ __global__ void weight_prep_kernel(const float* W, const float* bn_w, const floa
   }
 }
 
+// One launch for all layers: workgroup -> (item, 16-channel co tile, 32-channel ci tile); the W slab of the tile
+// (16 x [32 ci x RS] contiguous floats) goes through LDS so reads and both writes run over contiguous segments.
+template <typename T>
+__global__ __launch_bounds__(256) void prep_batch_kernel(const td_prep_item* items, int n_items) {
+  __shared__ float tile[16][32 * 9 + 1];
+  // locate the item of this workgroup (items are few: linear scan over the prefix sums)
+  int it = 0;
+  {
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (items[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    it = lo;
+  }
+  const td_prep_item I = items[it];
+  const int local = blockIdx.x - I.blk0;
+  const int n_cit = (I.Cpad + 31) / 32;
+  const int cot = local / n_cit, cit = local - cot * n_cit;
+  const int co0 = cot * 16, ci0 = cit * 32;
+  const int RS = I.RS;
+  const int t = threadIdx.x;
+  T* wf = (T*)I.w_fwd;
+  T* wd = (T*)I.w_dgrad;
+  for (int rs0 = 0; rs0 < RS; rs0 += 9) {  // taps in groups of <= 9 (7x7 stem: 6 groups)
+    const int nrs = min(9, RS - rs0);
+    // load: 16 co x (32 ci x nrs taps)
+    for (int idx = t; idx < 16 * 32 * nrs; idx += 256) {
+      const int c = idx / (32 * nrs), k = idx - c * (32 * nrs);
+      const int ci = ci0 + k / nrs, rs = rs0 + k % nrs;
+      const int co = co0 + c;
+      float v = 0.f;
+      if (co < I.Co && ci < I.Ci) {
+        const float sc = I.bn_w ? I.bn_w[co] * rsqrtf(I.bn_rv[co] + 1e-5f) : 1.f;
+        v = I.W[((size_t)co * I.Ci + ci) * RS + rs] * sc;
+      }
+      tile[c][(k / nrs) * 9 + (k % nrs)] = v;
+    }
+    __syncthreads();
+    // forward layout [Co_alloc][RS][Cpad]: runs of 32 ci
+    for (int idx = t; idx < 16 * nrs * 32; idx += 256) {
+      const int cil = idx & 31, r = (idx >> 5) % nrs, c = idx / (32 * nrs);
+      const int co = co0 + c, ci = ci0 + cil;
+      if (co < I.Co_alloc && ci < I.Cpad) Elem<T>::store(wf, ((size_t)co * RS + rs0 + r) * I.Cpad + ci, tile[c][cil * 9 + r]);
+    }
+    // dgrad layout [Ci][RS][Co_alloc]: runs of 16 co
+    if (wd) {
+      for (int idx = t; idx < 32 * nrs * 16; idx += 256) {
+        const int c = idx & 15, r = (idx >> 4) % nrs, cil = idx / (16 * nrs);
+        const int co = co0 + c, ci = ci0 + cil;
+        if (co < I.Co_alloc && ci < I.Ci) Elem<T>::store(wd, ((size_t)ci * RS + rs0 + r) * I.Co_alloc + co, tile[c][cil * 9 + r]);
+      }
+    }
+    __syncthreads();
+  }
+  if (cit == 0 && t < 16) {
+    const int co = co0 + t;
+    if (co < I.Co_alloc) {
+      const bool real = co < I.Co;
+      const float sc = (real && I.bn_w) ? I.bn_w[co] * rsqrtf(I.bn_rv[co] + 1e-5f) : 1.f;
+      if (I.scale_out) I.scale_out[co] = sc;
+      if (I.bias_out) I.bias_out[co] = !real ? 0.f : (I.bn_w ? (I.bn_b[co] - I.bn_rm[co] * sc) : (I.bias ? I.bias[co] : 0.f));
+    }
+  }
+}
+
 __global__ void wgrad_finalize_kernel(const float* dw_k, const float* scale, float* dW, int Co, int Ci, int R, int S,
                                       int Cpad, int accumulate) {
   const size_t n = (size_t)Co * Ci * R * S;
@@ -110,6 +176,15 @@ extern "C" int td_weight_prep(const float* W, const float* bn_w, const float* bn
                                                        (float*)w_fwd, (float*)w_dgrad, bias_out, scale_out);
   else TD_REQUIRE(false, "td_weight_prep: bad dtype");
   return check_launch("td_weight_prep");
+}
+
+extern "C" int td_weight_prep_batch(const td_prep_item* items_dev, int n, int total_blocks, int dtype, td_stream_t stream) {
+  TD_REQUIRE(items_dev && n > 0 && total_blocks > 0, "td_weight_prep_batch: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16) prep_batch_kernel<u16><<<total_blocks, 256, 0, st>>>(items_dev, n);
+  else if (dtype == TD_F32) prep_batch_kernel<float><<<total_blocks, 256, 0, st>>>(items_dev, n);
+  else TD_REQUIRE(false, "td_weight_prep_batch: bad dtype");
+  return check_launch("td_weight_prep_batch");
 }
 
 extern "C" int td_wgrad_finalize(const float* dw_k, const float* scale, float* dW, int Co, int Ci, int R, int S,

@@ -29,25 +29,103 @@ def invalidate_prepared():
     _EPOCH[0] += 1
 
 
+class _PrepEntry:
+    __slots__ = ("base_ref", "offset", "shape", "bn", "dtype", "need_dgrad", "cpad", "co_alloc", "res", "ver", "dims")
+
+
+class _PrepRegistry:
+    """All prepared-weight requests of one (device, dtype): their output buffers persist (overwritten in place, in
+    stream order, whenever the weights change) so the device-side item table is static and ONE td_weight_prep_batch
+    launch refreshes every layer of the model."""
+
+    def __init__(self):
+        self.entries = []
+        self.table_dev = None
+        self.total_blocks = 0
+
+    def _signature(self, e):
+        base = e.base_ref()
+        if base is None:
+            return None
+        return (_EPOCH[0], base._version, base.data_ptr()) + (tuple((b._version, b.data_ptr()) for b in e.bn) if e.bn is not None else ())
+
+    def _build_table(self, device):
+        import ctypes as C
+
+        from . import _hip
+
+        self.entries = [e for e in self.entries if e.base_ref() is not None]
+        items = (_hip.PrepItem * len(self.entries))()
+        blk = 0
+        for it, e in zip(items, self.entries):
+            base = e.base_ref()
+            Co, Ci, RS = e.dims
+            wf, wd, b_out, sc = e.res
+            it.W = base.data_ptr() + e.offset * 4
+            if e.bn is not None:
+                it.bn_w, it.bn_b, it.bn_rm, it.bn_rv = (t.data_ptr() for t in e.bn)
+            it.w_fwd = wf.data_ptr()
+            it.w_dgrad = wd.data_ptr() if wd is not None else None
+            it.bias_out = b_out.data_ptr() if b_out is not None else None
+            it.scale_out = sc.data_ptr() if sc is not None else None
+            it.Co, it.Ci, it.RS, it.Cpad, it.Co_alloc, it.blk0 = Co, Ci, RS, e.cpad, e.co_alloc, blk
+            blk += ((e.co_alloc + 15) // 16) * ((e.cpad + 31) // 32)
+        self.total_blocks = blk
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        self.table_dev = raw.to(device)  # (re)uploaded only when the set of layers changes
+
+    def refresh_all(self, device, dtype):
+        from . import _hip
+
+        if self.table_dev is None or any(e.base_ref() is None for e in self.entries):
+            self._build_table(device)
+        if not self.entries:
+            return
+        _hip.check(_hip.lib().td_weight_prep_batch(self.table_dev.data_ptr(), len(self.entries), self.total_blocks,
+                                                   _hip.dtype_code(dtype), _hip.stream_ptr()), "td_weight_prep_batch")
+        for e in self.entries:
+            e.ver = self._signature(e)
+
+
+_REGISTRIES: dict = {}
+
+
 def prepared(W: Tensor, dtype: torch.dtype, *, bn=None, need_dgrad: bool = True, cpad: Optional[int] = None, pad_out: int = 0):
-    """(w_fwd, w_dgrad, bias_fold, scale) for parameter W (or a row-slice view of one), cached ON the parameter
-    object until it (or the BN buffers) change in place - the cache dies with the parameter, so a recycled device
-    address can never alias a stale entry."""
+    """(w_fwd, w_dgrad, bias_fold, scale) for parameter W (or a row-slice view of one).  The request is cached ON the
+    parameter object (so a recycled device address can never alias a stale entry) and registered in a per-(device,
+    dtype) registry: when any weight has changed, one batched launch refreshes every registered layer."""
+    import weakref
+
     base = W._base if W._base is not None else W
     cache = base.__dict__.setdefault("_td_prepared", {})
     key = (W.storage_offset(), tuple(W.shape), dtype, need_dgrad, cpad, pad_out)
-    ver = (_EPOCH[0], base._version, base.data_ptr()) + (tuple((b._version, b.data_ptr()) for b in bn) if bn is not None else ())
-    hit = cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
-    Wd = W.detach()
-    if pad_out and Wd.shape[0] < pad_out:  # tiny output layers (4 box coords, 2 start/end logits) are padded to the vector width
-        Wp = torch.zeros((pad_out,) + tuple(Wd.shape[1:]), dtype=Wd.dtype, device=Wd.device)
-        Wp[: Wd.shape[0]] = Wd
-        Wd = Wp
-    res = ops.weight_prep(Wd.contiguous(), dtype, bn=[b.detach() for b in bn] if bn is not None else None, need_dgrad=need_dgrad, cpad=cpad)
-    cache[key] = (ver, res)
-    return res
+    e = cache.get(key)
+    reg = _REGISTRIES.setdefault((str(W.device), dtype), _PrepRegistry())
+    if e is None:
+        e = _PrepEntry()
+        if W.dim() == 2:
+            Co, Ci = W.shape
+            RS = 1
+        else:
+            Co, Ci, R, S_ = W.shape
+            RS = R * S_
+        assert W.dtype == torch.float32 and W.is_contiguous()
+        e.base_ref, e.offset, e.shape, e.bn, e.dtype = weakref.ref(base), W.storage_offset(), tuple(W.shape), bn, dtype
+        e.need_dgrad, e.dims = need_dgrad, (Co, Ci, RS)
+        e.cpad = cpad if cpad is not None else ops.pad_to(Ci, ops.vec_of(dtype))
+        e.co_alloc = max(Co, pad_out)
+        dev = W.device
+        wf = torch.empty((e.co_alloc, RS * e.cpad), dtype=dtype, device=dev)
+        wd = torch.empty((Ci, RS * e.co_alloc), dtype=dtype, device=dev) if need_dgrad else None
+        b_out = torch.empty(e.co_alloc, dtype=torch.float32, device=dev) if bn is not None else None
+        sc = torch.empty(e.co_alloc, dtype=torch.float32, device=dev) if bn is not None else None
+        e.res, e.ver = (wf, wd, b_out, sc), None
+        cache[key] = e
+        reg.entries.append(e)
+        reg.table_dev = None  # table must be rebuilt
+    if e.ver != reg._signature(e):
+        reg.refresh_all(W.device, dtype)
+    return e.res
 
 
 _SEED_STATE = {"torch_seed": None, "rng": None}
