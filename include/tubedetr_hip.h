@@ -32,6 +32,11 @@ typedef void* td_stream_t; /* hipStream_t */
 const char* td_last_error(void);
 int td_abi_version(void);
 
+/* Optional device-resident dropout step counter (uint32): when set, every dropout-capable kernel uses
+ * seed + *counter * 0x9E3779B1 - a captured HIP graph then draws fresh masks on each replay (the caller increments
+ * the counter between replays).  NULL (default) = seeds are used as passed.  Process-global. */
+int td_set_dropout_step_counter(const uint32_t* dev_counter);
+
 /* Optional per-kernel-family timing with HIP events recorded on the launch stream around every MFMA kernel
  * launch (bench.py's roofline leg).  td_prof_enable(1) starts collecting (not thread safe: single launching
  * thread), td_prof_collect synchronises the recorded events and returns, per family (TD_PROF_*), the number of

@@ -39,6 +39,7 @@ class Epilogue(C.Structure):
 
 _P, _I, _F, _U32, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t
 _SIGS = {
+    "td_set_dropout_step_counter": [_P],
     "td_prof_enable": [_I],
     "td_prof_dump": [C.c_char_p],
     "td_debug_set_stamp_buffer": [_P],

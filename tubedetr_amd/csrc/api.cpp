@@ -25,6 +25,9 @@ int check_launch(const char* what) {
   return TD_OK;
 }
 
+static const uint32_t* g_drop_ctr = nullptr;
+const uint32_t* dropout_counter() { return g_drop_ctr; }
+
 // ---- launch timing for bench.py's roofline leg ----
 struct ProfRec { int family, dtype; double flops; hipEvent_t a, b; int M, N, K, R, stride, mode; };
 static bool g_prof = false;
@@ -43,6 +46,11 @@ void prof_begin(int family, int dtype, double flops, hipStream_t st, int M, int 
 void prof_end(hipStream_t st) { hipEventRecord(g_recs.back().b, st); }
 
 }  // namespace td
+
+extern "C" int td_set_dropout_step_counter(const uint32_t* dev_counter) {
+  td::g_drop_ctr = dev_counter;
+  return TD_OK;
+}
 
 extern "C" int td_prof_enable(int on) {
   td::g_prof = on != 0;

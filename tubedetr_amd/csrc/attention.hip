@@ -25,6 +25,7 @@ struct MhaParams {
   uint32_t drop_thresh;
   float drop_scale;
   uint32_t seed;
+  const uint32_t* seed_dev;
 };
 
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaParams p) {
       if (kk < Lk) {
         float pr = s[j] * inv;
         p.probs[prow + kk] = pr;
-        if (p.drop_thresh) pr = dropout_keep(p.seed, (uint32_t)(prow + kk), p.drop_thresh) ? pr * p.drop_scale : 0.f;
+        if (p.drop_thresh) pr = dropout_keep(effective_seed(p.seed, p.seed_dev), (uint32_t)(prow + kk), p.drop_thresh) ? pr * p.drop_scale : 0.f;
         myP[kk] = pr;
       }
     }
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaParams p) {
 }
 
 __global__ void avg_heads_kernel(const float* probs, float* wavg, int B, int H, int Lq, int Lk, uint32_t drop_thresh,
-                                 float drop_scale, uint32_t seed) {
+                                 float drop_scale, uint32_t seed, const uint32_t* seed_dev) {
   const size_t n = (size_t)B * Lq * Lk;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
@@ -109,7 +110,7 @@ __global__ void avg_heads_kernel(const float* probs, float* wavg, int B, int H, 
   for (int h = 0; h < H; ++h) {
     size_t pi = (b * H + h) * per + rem;
     float pr = probs[pi];
-    if (drop_thresh) pr = dropout_keep(seed, (uint32_t)pi, drop_thresh) ? pr * drop_scale : 0.f;
+    if (drop_thresh) pr = dropout_keep(effective_seed(seed, seed_dev), (uint32_t)pi, drop_thresh) ? pr * drop_scale : 0.f;
     acc += pr;
   }
   wavg[idx] = acc / H;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaParams p) {
 #pragma unroll
         for (int d = 0; d < HD; ++d) dot += dov[d] * sV[kk * 33 + d];
         if (p.dwavg) dot += p.dwavg[((size_t)b * Lq + qi) * Lk + kk] * invH;
-        if (p.drop_thresh) dot = dropout_keep(p.seed, (uint32_t)(prow + kk), p.drop_thresh) ? dot * p.drop_scale : 0.f;
+        if (p.drop_thresh) dot = dropout_keep(effective_seed(p.seed, p.seed_dev), (uint32_t)(prow + kk), p.drop_thresh) ? dot * p.drop_scale : 0.f;
         dp[j] = dot;
         pr[j] = p.probs[prow + kk];
         delta += pr[j] * dot;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaParams p) {
     const size_t pi = ((size_t)bh * Lq + qq) * Lk + kk;
     float ds = p.ds_ws[pi];
     float pr = p.probs[pi];
-    if (p.drop_thresh) pr = dropout_keep(p.seed, (uint32_t)pi, p.drop_thresh) ? pr * p.drop_scale : 0.f;
+    if (p.drop_thresh) pr = dropout_keep(effective_seed(p.seed, p.seed_dev), (uint32_t)pi, p.drop_thresh) ? pr * p.drop_scale : 0.f;
     const float4* q4 = (const float4*)(sQ + qq * HD + part * 8);
     const float4* o4 = (const float4*)(sO + qq * HD + part * 8);
     float4 a0 = q4[0], a1 = q4[1], o0 = o4[0], o1 = o4[1];
@@ -230,14 +231,31 @@ static int fill(MhaParams& p, int B, int H, int Lq, int Lk, int hd, int ldq, int
   TD_REQUIRE(B >= 1 && H >= 1 && Lq >= 1, "%s: bad sizes", who);
   TD_REQUIRE((double)B * H * Lq * Lk < 4294967295.0, "%s: probs tensor too large for the dropout index", who);
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
-  p.drop_thresh = 0; p.drop_scale = 1.f; p.seed = seed;
+  p.drop_thresh = 0; p.drop_scale = 1.f; p.seed = seed; p.seed_dev = nullptr;
   if (dropout_p > 0.f) {
     TD_REQUIRE(dropout_p < 1.f, "%s: dropout_p must be < 1", who);
     p.drop_thresh = (uint32_t)((double)dropout_p * 4294967296.0);
     if (!p.drop_thresh) p.drop_thresh = 1;
     p.drop_scale = 1.f / (1.f - dropout_p);
+    p.seed_dev = dropout_counter();
   }
   return TD_OK;
+}
+
+// dynamic LDS above 64 KiB needs the attribute once per kernel (done once: not a stream operation, kept out of any
+// graph capture that may be recording the launches)
+static void mha_allow_big_lds() {
+  static const bool done = [] {
+    const int big = 160 * 1024;
+    (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    return true;
+  }();
+  (void)done;
 }
 
 }  // namespace td
@@ -255,20 +273,15 @@ extern "C" int td_mha_fwd(const void* q, const void* k, const void* v, const uin
   hipStream_t st = (hipStream_t)stream;
   size_t lds = (size_t)(2 * Lk * 33 + 4 * Lk) * sizeof(float);
   dim3 grid(B * H, (Lq + QT - 1) / QT);
-  hipError_t e;
-  if (dtype == TD_BF16) {
-    e = hipFuncSetAttribute((const void*)mha_fwd_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    mha_fwd_kernel<u16><<<grid, 256, lds, st>>>(p);
-  } else if (dtype == TD_F32) {
-    e = hipFuncSetAttribute((const void*)mha_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    mha_fwd_kernel<float><<<grid, 256, lds, st>>>(p);
-  } else TD_REQUIRE(false, "td_mha_fwd: bad dtype");
-  (void)e;
+  mha_allow_big_lds();
+  if (dtype == TD_BF16) mha_fwd_kernel<u16><<<grid, 256, lds, st>>>(p);
+  else if (dtype == TD_F32) mha_fwd_kernel<float><<<grid, 256, lds, st>>>(p);
+  else TD_REQUIRE(false, "td_mha_fwd: bad dtype");
   rc = check_launch("td_mha_fwd");
   if (rc) return rc;
   if (wavg) {
     size_t n = (size_t)B * Lq * Lk;
-    avg_heads_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(probs, wavg, B, H, Lq, Lk, p.drop_thresh, p.drop_scale, p.seed);
+    avg_heads_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(probs, wavg, B, H, Lq, Lk, p.drop_thresh, p.drop_scale, p.seed, p.seed_dev);
     rc = check_launch("td_mha_fwd(avg)");
   }
   return rc;
@@ -290,18 +303,13 @@ extern "C" int td_mha_bwd(const void* q, const void* k, const void* v, const voi
   size_t ldsB = (size_t)(2 * Lq * HD) * sizeof(float);
   TD_REQUIRE(ldsA <= 160 * 1024 && ldsB <= 160 * 1024, "td_mha_bwd: Lq/Lk too large for LDS");
   dim3 gridA(B * H, (Lq + QT - 1) / QT), gridB(B * H, (Lk + 63) / 64);
-  hipError_t e;
+  mha_allow_big_lds();
   if (dtype == TD_BF16) {
-    e = hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    e = hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     mha_bwd_dq_kernel<u16><<<gridA, 256, ldsA, st>>>(p);
     mha_bwd_dkv_kernel<u16><<<gridB, 256, ldsB, st>>>(p);
   } else if (dtype == TD_F32) {
-    e = hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    e = hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     mha_bwd_dq_kernel<float><<<gridA, 256, ldsA, st>>>(p);
     mha_bwd_dkv_kernel<float><<<gridB, 256, ldsB, st>>>(p);
   } else TD_REQUIRE(false, "td_mha_bwd: bad dtype");
-  (void)e;
   return check_launch("td_mha_bwd");
 }

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* g, float* out,
 // elementwise kernels move 16 bytes per lane per access (8 bf16 / 4 fp32); OP selects the operation:
 // 0: y = a + b (b optional)   1: y = a * scale where b > 0 else 0 (ReLU backward)   2: y = dropout(a)
 template <typename T, int OP>
-__global__ __launch_bounds__(256) void ew_kernel(const T* a, const T* b, T* y, size_t n, float scale, uint32_t thresh, uint32_t seed) {
+__global__ __launch_bounds__(256) void ew_kernel(const T* a, const T* b, T* y, size_t n, float scale, uint32_t thresh, uint32_t seed_in, const uint32_t* seed_dev) {
+  const uint32_t seed = (OP == 2) ? effective_seed(seed_in, seed_dev) : seed_in;
   constexpr int VEC = 16 / sizeof(T);
   const size_t nv = n / VEC;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,8 +346,8 @@ extern "C" int td_add(const void* a, const void* b, void* y, size_t n, int dtype
   unsigned g = nblk(n / 4 + 1);
   if (g > 4096) g = 4096;
   TD_REQUIRE(((uintptr_t)a | (uintptr_t)y | (uintptr_t)b) % 16 == 0, "td_add: pointers must be 16-byte aligned");
-  TD_DISPATCH(dtype, (ew_kernel<u16, 0><<<g, 256, 0, st>>>((const u16*)a, (const u16*)b, (u16*)y, n, 1.f, 0, 0)),
-              (ew_kernel<float, 0><<<g, 256, 0, st>>>((const float*)a, (const float*)b, (float*)y, n, 1.f, 0, 0)), "td_add");
+  TD_DISPATCH(dtype, (ew_kernel<u16, 0><<<g, 256, 0, st>>>((const u16*)a, (const u16*)b, (u16*)y, n, 1.f, 0, 0, nullptr)),
+              (ew_kernel<float, 0><<<g, 256, 0, st>>>((const float*)a, (const float*)b, (float*)y, n, 1.f, 0, 0, nullptr)), "td_add");
   return check_launch("td_add");
 }
 
@@ -357,8 +358,8 @@ extern "C" int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, flo
   unsigned gr = nblk(n);
   if (gr > 4096) gr = 4096;
   TD_REQUIRE(((uintptr_t)dy | (uintptr_t)y | (uintptr_t)g) % 16 == 0, "td_relu_bwd: pointers must be 16-byte aligned");
-  TD_DISPATCH(dtype, (ew_kernel<u16, 1><<<gr, 256, 0, st>>>((const u16*)dy, (const u16*)y, (u16*)g, n, scale, 0, 0)),
-              (ew_kernel<float, 1><<<gr, 256, 0, st>>>((const float*)dy, (const float*)y, (float*)g, n, scale, 0, 0)), "td_relu_bwd");
+  TD_DISPATCH(dtype, (ew_kernel<u16, 1><<<gr, 256, 0, st>>>((const u16*)dy, (const u16*)y, (u16*)g, n, scale, 0, 0, nullptr)),
+              (ew_kernel<float, 1><<<gr, 256, 0, st>>>((const float*)dy, (const float*)y, (float*)g, n, scale, 0, 0, nullptr)), "td_relu_bwd");
   return check_launch("td_relu_bwd");
 }
 
@@ -373,8 +374,8 @@ extern "C" int td_dropout(const void* x, void* y, size_t n, float p, uint32_t se
   if (p > 0.f && !thresh) thresh = 1;
   float scale = 1.f / (1.f - p);
   TD_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "td_dropout: pointers must be 16-byte aligned");
-  TD_DISPATCH(dtype, (ew_kernel<u16, 2><<<gr, 256, 0, st>>>((const u16*)x, nullptr, (u16*)y, n, scale, thresh, seed)),
-              (ew_kernel<float, 2><<<gr, 256, 0, st>>>((const float*)x, nullptr, (float*)y, n, scale, thresh, seed)), "td_dropout");
+  TD_DISPATCH(dtype, (ew_kernel<u16, 2><<<gr, 256, 0, st>>>((const u16*)x, nullptr, (u16*)y, n, scale, thresh, seed, thresh ? dropout_counter() : nullptr)),
+              (ew_kernel<float, 2><<<gr, 256, 0, st>>>((const float*)x, nullptr, (float*)y, n, scale, thresh, seed, thresh ? dropout_counter() : nullptr)), "td_dropout");
   return check_launch("td_dropout");
 }
 

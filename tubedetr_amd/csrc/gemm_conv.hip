@@ -35,6 +35,7 @@ struct GemmParams {
   uint32_t drop_thresh;
   float drop_scale;
   uint32_t seed;
+  const uint32_t* seed_dev;
 };
 
 template <typename T>
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
 #pragma unroll
   for (int r = 0; r < EPL; ++r) bias[r] = (p.bias && n + r < d.Nc) ? p.bias[n + r] : 0.f;
   TD_STAMP(4);
+  const uint32_t eff_seed = effective_seed(p.seed, p.drop_thresh ? p.seed_dev : nullptr);
   // (3) row-contiguous epilogue + 16-byte stores
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
       }
       if (p.drop_thresh) {
 #pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
+        for (int r = 0; r < EPL; ++r) v[r] = dropout_keep(eff_seed, (uint32_t)(off + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
       }
       *(uint4*)(p.out + off * ES) = pack16<T>(v);
     } else {
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
         if (p.relu) x = fmaxf(x, 0.f);
         if (p.sigmoid) x = sigmoidf_(x);
         if (p.mask_src) x = Elem<T>::load(p.mask_src, off + r) > 0.f ? x : 0.f;
-        if (p.drop_thresh) x = dropout_keep(p.seed, (uint32_t)(off + r), p.drop_thresh) ? x * p.drop_scale : 0.f;
+        if (p.drop_thresh) x = dropout_keep(eff_seed, (uint32_t)(off + r), p.drop_thresh) ? x * p.drop_scale : 0.f;
         Elem<T>::store(p.out, off + r, x);
       }
     }
@@ -694,6 +696,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
       if (p.drop_thresh == 0) p.drop_thresh = 1;
       p.drop_scale = 1.f / (1.f - e->dropout_p);
       p.seed = e->dropout_seed;
+      p.seed_dev = dropout_counter();
     }
   }
   TD_REQUIRE(d->ldc >= d->Nc, "td_conv_gemm: ldc < Nc");

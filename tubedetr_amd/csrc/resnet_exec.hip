@@ -226,7 +226,9 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
   if (use_side && !side) {
     if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
   }
-  hipStream_t wst = (use_side && side) ? side : st;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);  // inside a graph capture everything stays on the captured stream
+  hipStream_t wst = (use_side && side && cap == hipStreamCaptureStatusNone) ? side : st;
   size_t evi = 0;
   auto next_event = [&]() -> hipEvent_t {
     if (evi == evpool.size()) {

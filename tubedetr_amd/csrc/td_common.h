@@ -26,6 +26,11 @@ int check_launch(const char* what);
     }                                   \
   } while (0)
 
+// optional device-side dropout step counter (td_set_dropout_step_counter): kernels add *ptr * golden to their seed, so
+// a captured HIP graph draws fresh masks on every replay without re-recording launches
+const uint32_t* dropout_counter();
+__device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint32_t* ctr) { return ctr ? seed + ctr[0] * 0x9E3779B1u : seed; }
+
 // bench-only launch timing (api.cpp)
 bool prof_on();
 void prof_begin(int family, int dtype, double flops, hipStream_t st, int M = 0, int N = 0, int K = 0, int R = 0, int stride = 0, int mode = 0);

@@ -272,7 +272,8 @@ class Transformer(nn.Module):
             tokenized = self.tokenizer.batch_encode_plus(text, padding="longest", return_tensors="pt")
             ids, att = tokenized["input_ids"], tokenized["attention_mask"]
             # decided on the host copy: HF's mask construction otherwise inspects the device mask (a stream sync)
-            no_padding = bool(att.all()) if att.device.type == "cpu" else False
+            hint = getattr(tokenized, "_td_no_padding", None)  # tokenizers may state it for device-resident ids
+            no_padding = bool(hint) if hint is not None else (bool(att.all()) if att.device.type == "cpu" else False)
             main = torch.cuda.current_stream(device)
             side = self._text_stream = getattr(self, "_text_stream", None) or torch.cuda.Stream(device)
             # RoBERTa (hundreds of tiny launches on 30 tokens) is independent of the visual backbone: it runs on its own
