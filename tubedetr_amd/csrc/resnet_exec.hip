@@ -222,13 +222,14 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
   // is by events only (no host sync); the call still appears stream-ordered to the caller.
   static hipStream_t side = nullptr;
   static std::vector<hipEvent_t> evpool;
-  static const bool use_side = [] { const char* e = getenv("TD_WGRAD_STREAM"); return !(e && e[0] == '0'); }();
+  static const bool use_side = [] { const char* e = getenv("TD_WGRAD_STREAM"); return e && e[0] == '1'; }();  // opt-in: measured neutral (eager) to negative (inside a graph)
   if (use_side && !side) {
     if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
   }
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);  // inside a graph capture everything stays on the captured stream
-  hipStream_t wst = (use_side && side && cap == hipStreamCaptureStatusNone) ? side : st;
+  static const bool side_in_capture = [] { const char* e = getenv("TD_WGRAD_STREAM_CAPTURE"); return e && e[0] == '1'; }();
+  hipStream_t wst = (use_side && side && (cap == hipStreamCaptureStatusNone || side_in_capture)) ? side : st;
   size_t evi = 0;
   auto next_event = [&]() -> hipEvent_t {
     if (evi == evpool.size()) {
