@@ -13,6 +13,8 @@
 // Replaces the torch Conv2d/Linear (+FrozenBatchNorm2d/ReLU/residual) calls of the reference hot path:
 // models/backbone.py:60-70,97-98 (torchvision resnet101 body), models/tubedetr.py:80,131,134 (input_proj),
 // models/transformer.py:124-125,387,441-445,613-617,643,661-667,748,764-773 and models/tubedetr.py:37-42.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "td_common.h"
@@ -756,9 +758,10 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
   }
   const int mk = dtype == TD_BF16 ? 64 : 32;
   if (splits < 1) {
-    // enough workgroups to fill the chip (~768), but at least 8 reduction stages (512 / 256 rows) per split
+    // about one workgroup per CU (TD_WGRAD_BLOCKS, default 256), at least 8 reduction stages (512 / 256 rows) per split
+    static const int target_blocks = [] { const char* e = getenv("TD_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();  // measured: 192-256 workgroups beat 512-1536 (fewer fp32 atomics per output tile)
     int tiles = cdiv(d->Nc, 128) * cdiv(p.K, 128);
-    splits = cdiv(768, tiles);
+    splits = cdiv(target_blocks, tiles);
     int maxs = cdiv(p.M, 8 * mk);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
