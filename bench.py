@@ -255,8 +255,8 @@ def main():
             code = _hip.TD_BF16 if cdt == torch.bfloat16 else _hip.TD_F32
             tname = "unsigned short" if cdt == torch.bfloat16 else "float"
             peak = PEAK_BF16_TFLOPS if cdt == torch.bfloat16 else 157.3
-            fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128>",
-                    1: f"td::conv_gemm_kernel<{tname}, 128, 64>", 2: f"td::conv_wgrad_kernel<{tname}>"}
+            fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128, 2, *>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128, 2, *>",
+                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, 2, *>", 2: f"td::conv_wgrad_kernel<{tname}>"}  # * = both pointwise / generic instances
             per = []
             for fam, kname in fams.items():
                 n, ms, fl = C.c_longlong(), C.c_double(), C.c_double()
