@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--no-dedupe", action="store_true", help="recompute the slow frames inside the fast pass like the reference does")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="capture the step in a HIP graph (N=1 only)")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
+    ap.add_argument("--force-ddp", action="store_true", help="diagnostic: wrap in DistributedDataParallel (RCCL) even with one rank")
     ap.add_argument("--no-fast", action="store_true")
     ap.add_argument("--no-tsa", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: run in eval mode")
@@ -130,8 +131,11 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or a.force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.distributed.init_process_group("nccl", device_id=dev)
 
     import tubedetr_amd
@@ -150,7 +154,7 @@ def main():
     tok = BatchTokenizer()
     model.transformer.tokenizer = tok
     net = model
-    if world > 1:
+    if world > 1 or a.force_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True)  # main.py:372-376
 
     n_batches = a.warmup + a.steps + a.roofline_steps
@@ -182,7 +186,7 @@ def main():
     # ---- optional whole-step HIP graph (single GPU): the ~1500 launches of a step are captured once and replayed, so
     # the host only copies the next clip into the static input buffers and bumps the dropout step counter ----
     execution = "eager"
-    if a.graph and world == 1:
+    if a.graph and world == 1 and not a.force_ddp:
         try:
             static = {k_: (v.clone() if torch.is_tensor(v) else v) for k_, v in batches[0].items()}
             for k_ in ("input_ids", "attention_mask"):
@@ -294,7 +298,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or a.force_ddp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

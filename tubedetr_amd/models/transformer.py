@@ -275,7 +275,12 @@ class Transformer(nn.Module):
             hint = getattr(tokenized, "_td_no_padding", None)  # tokenizers may state it for device-resident ids
             no_padding = bool(hint) if hint is not None else (bool(att.all()) if att.device.type == "cpu" else False)
             main = torch.cuda.current_stream(device)
-            side = self._text_stream = getattr(self, "_text_stream", None) or torch.cuda.Stream(device)
+            import os
+
+            if os.environ.get("TD_TEXT_STREAM", "1") == "0":  # diagnostic: keep the text encoder on the main stream
+                side = main
+            else:
+                side = self._text_stream = getattr(self, "_text_stream", None) or torch.cuda.Stream(device)
             # RoBERTa (hundreds of tiny launches on 30 tokens) is independent of the visual backbone: it runs on its own
             # HIP stream, concurrently with the trunk's large GEMM kernels; autograd replays its backward there too.
             with torch.cuda.stream(side):
