@@ -119,7 +119,9 @@ def main():
     ap.add_argument("--no-dedupe", action="store_true", help="recompute the slow frames inside the fast pass like the reference does")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="capture the step in a HIP graph (N=1 only)")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
-    ap.add_argument("--force-ddp", action="store_true", help="diagnostic: wrap in DistributedDataParallel (RCCL) even with one rank")
+    ap.add_argument("--force-ddp", action="store_true", help="diagnostic: run the N>1 code path (process group + gradient exchange) with one rank")
+    ap.add_argument("--ddp", action="store_true", help="N>1: use torch DistributedDataParallel like main.py:372-376 instead of the flat all-reduce")
+    ap.add_argument("--grad-wire-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the wire")
     ap.add_argument("--no-fast", action="store_true")
     ap.add_argument("--no-tsa", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: run in eval mode")
@@ -154,8 +156,19 @@ def main():
     tok = BatchTokenizer()
     model.transformer.tokenizer = tok
     net = model
-    if world > 1 or a.force_ddp:
+    distributed = world > 1 or a.force_ddp
+    reducer = None
+    if distributed and a.ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True)  # main.py:372-376
+    elif distributed:
+        # replicas start from rank 0's weights (what DDP's constructor does), then exchange gradients with ONE flat
+        # all-reduce per step (tubedetr_amd/distributed.py); the step itself holds no collective
+        from tubedetr_amd.distributed import FlatGradAllReducer, sync_num_boxes
+
+        for t_ in list(model.parameters()) + list(model.buffers()):
+            torch.distributed.broadcast(t_.data, 0)
+        reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32)
+        criterion.external_num_boxes = torch.ones(1, dtype=torch.float32, device=dev)
 
     n_batches = a.warmup + a.steps + a.roofline_steps
     batches = [make_batch(T, res, k, L, 1000 * rank + s, dev) for s in range(min(n_batches, 4))]
@@ -174,8 +187,12 @@ def main():
             invalidate_prepared()  # as after an optimizer step: weights are re-cast / re-folded inside the timed step
         for p_ in params:  # = optimizer.zero_grad(set_to_none=True) without re-walking the module tree
             p_.grad = None
+        if reducer is not None:
+            sync_num_boxes(b["target_boxes"].shape[0], criterion.external_num_boxes)
         loss, _, _, _ = forward_step(net, criterion, weight_dict, b)
         loss.backward()
+        if reducer is not None:
+            reducer.reduce()
         return loss
 
     def fence():
@@ -186,7 +203,7 @@ def main():
     # ---- optional whole-step HIP graph (single GPU): the ~1500 launches of a step are captured once and replayed, so
     # the host only copies the next clip into the static input buffers and bumps the dropout step counter ----
     execution = "eager"
-    if a.graph and world == 1 and not a.force_ddp:
+    if a.graph and not (distributed and a.ddp):
         try:
             static = {k_: (v.clone() if torch.is_tensor(v) else v) for k_, v in batches[0].items()}
             for k_ in ("input_ids", "attention_mask"):
@@ -223,7 +240,11 @@ def main():
                     if torch.is_tensor(v):
                         static[k_].copy_(v, non_blocking=True)
                 counter.add_(1)
+                if reducer is not None:
+                    sync_num_boxes(b_["target_boxes"].shape[0], criterion.external_num_boxes)
                 graph.replay()
+                if reducer is not None:
+                    reducer.reduce()  # the only collective of the step, outside the graph
                 return static_loss
 
             execution = "hip_graph"
@@ -290,7 +311,8 @@ def main():
             "metric": "training clips/sec (fwd+bwd)", "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "execution": execution, "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, 1 clip/GPU, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}",
+            "execution": execution, "gradient_exchange": (None if not distributed else ("torch DDP (find_unused_parameters)" if a.ddp else f"flat all-reduce, {a.grad_wire_dtype} on the wire")),
+            "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, 1 clip/GPU, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}",
                        "global_batch": world, "parallelism": f"dp{world}", "weights": "random init (reference scheme), seed 42+rank"},
             "flops_note": ("slow frames not recomputed in the fast pass (identical pixels): executed trunk-forward work is 100/125 of the "
                            "reference algorithm's; roofline fractions use executed FLOPs, step_frac_of_mfma_peak the reference algorithm's 6.847 TFLOP") if (model.slow_frames_are_strided_fast and not a.no_fast) else None,

@@ -94,7 +94,37 @@ def _timing_max(rank, world):
     assert t.item() == float(world)  # bench.py reports the slowest rank's time
 
 
-@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max])
+def _flat_grad_allreduce(rank, world):
+    """tubedetr_amd.distributed.FlatGradAllReducer == averaging every gradient over the ranks; parameters without a
+    gradient (RoBERTa's pooler in the real model) are exchanged as zeros and keep grad None; bf16 wire stays close."""
+    from tubedetr_amd.distributed import FlatGradAllReducer, sync_num_boxes
+
+    for wire in (torch.float32, torch.bfloat16):
+        model = TwoPhase()
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(1000 * rank))
+        model(x, False, model(x))["pred"].pow(2).sum().backward()
+        assert model.pooler.weight.grad is None
+        red = FlatGradAllReducer(model.parameters(), wire)
+        assert red.numel == sum(p.numel() for p in model.parameters())
+        red.reduce()
+        ref = TwoPhase()
+        want = None
+        for r in range(world):
+            ref.zero_grad()
+            xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(1000 * r))
+            ref(xr, False, ref(xr))["pred"].pow(2).sum().backward()
+            g = [ref.enc.weight.grad.clone(), ref.dec.bias.grad.clone()]
+            want = g if want is None else [a + b for a, b in zip(want, g)]
+        tol = 1e-6 if wire == torch.float32 else 2e-2
+        for got, w in zip((model.enc.weight.grad, model.dec.bias.grad), want):
+            assert torch.allclose(got, w / world, atol=tol * max(1.0, w.abs().max().item())), wire
+        assert model.pooler.weight.grad is None
+    nb = sync_num_boxes(4 + 2 * rank, torch.zeros(1))
+    assert nb.item() == (4 + 6) / world
+    assert sync_num_boxes(0, torch.zeros(1)).item() == 1.0
+
+
+@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce])
 def test_world_size_2_gloo(fn):
     _run(fn)
 

@@ -1,0 +1,69 @@
+"""Data-parallel gradient exchange for the hot path: one clip per GPU, one all-reduce of the gradients per step over
+RCCL / xGMI (``torch.distributed`` backend "nccl" on ROCm; "gloo" in the CPU tests).
+
+The reference wraps the model in ``DistributedDataParallel(find_unused_parameters=True)`` (main.py:372-376): per step
+that walks the autograd graph twice (two forward calls), re-broadcasts 400+ frozen buffers and copies every gradient
+into 25 MB buckets.  The exchange itself is only "average 185 M fp32 gradients", so here it is done directly:
+
+  * gradients are gathered into ONE persistent flat buffer with a fused multi-tensor copy, optionally narrowed to bf16
+    for the wire (halves the bytes each xGMI link carries; RCCL ring all-reduce is per-link bound on this fabric),
+  * a single ``all_reduce`` (no bucketing: 288 GB of HBM makes one 0.74 GB collective cheaper than 30 small ones),
+  * the averaged values are scattered back into the ``.grad`` tensors with one more fused copy.
+
+Parameters that received no gradient (RoBERTa's pooler - the reason the reference needs find_unused_parameters) are
+simply exchanged as zeros.  The forward / backward of the step itself contains no collective, so it can be replayed
+from a HIP graph on every rank; ``SetCriterion``'s num_boxes all-reduce is hoisted out through ``sync_num_boxes``.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradAllReducer:
+    def __init__(self, params: Iterable[torch.nn.Parameter], wire_dtype: torch.dtype = torch.float32, group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.wire_dtype = wire_dtype
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.wire = self.flat if wire_dtype == torch.float32 else torch.zeros(n, dtype=wire_dtype, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off : off + p.numel()].view_as(p))
+            off += p.numel()
+        self.numel = n
+
+    def reduce(self) -> None:
+        """Average the current ``.grad`` of every parameter over the ranks, in place."""
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if self.world > 1:
+            if self.wire is not self.flat:
+                self.wire.copy_(self.flat)
+                dist.all_reduce(self.wire, group=self.group)
+                self.flat.copy_(self.wire)
+            else:
+                dist.all_reduce(self.flat, group=self.group)
+            self.flat.div_(self.world)
+        if have:
+            torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
+
+
+def sync_num_boxes(n_local: int, out: torch.Tensor, group=None) -> torch.Tensor:
+    """clamp(sum over ranks of the annotated-box count / world, min=1) into the device scalar ``out``
+    (models/tubedetr.py:407-413), without a host synchronisation."""
+    out.fill_(float(n_local))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(out, group=group)
+        out.div_(dist.get_world_size(group))
+    out.clamp_(min=1)
+    return out

@@ -239,6 +239,7 @@ class SetCriterion(nn.Module):
         self.sigma = sigma
         self._pm_cache: dict = {}
         self._tgt_cache: dict = {}
+        self.external_num_boxes = None
 
     # ---- per-loss math on stacked layers: leading dim = decoder layer ----
     def _boxes(self, src, tgt, num_boxes):  # src (Lyr, n, 4), tgt (n, 4)
@@ -296,7 +297,11 @@ class SetCriterion(nn.Module):
         else:
             n_local = sum(len(t["boxes"]) for t in targets)
             tgt_boxes = torch.cat([t["boxes"] for t in targets], dim=0) if "boxes" in self.losses else None
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
+        if self.external_num_boxes is not None:
+            # the caller keeps clamp(all_reduce(#boxes)/world, 1) in a device scalar (tubedetr_amd.distributed.
+            # sync_num_boxes) so that the step itself holds no collective (HIP-graph replay on every rank)
+            num_boxes = self.external_num_boxes
+        elif torch.distributed.is_available() and torch.distributed.is_initialized():
             nb = torch.as_tensor([n_local], dtype=torch.float, device=dev)
             torch.distributed.all_reduce(nb)
             # stays a device scalar: no .item() host sync in the step (the reference syncs here, tubedetr.py:413)
