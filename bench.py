@@ -169,6 +169,7 @@ def main():
             torch.distributed.broadcast(t_.data, 0)
         reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32)
         criterion.external_num_boxes = torch.ones(1, dtype=torch.float32, device=dev)
+        reducer.always_communicate = a.force_ddp  # exercise the RCCL call in the 1-rank diagnostic
 
     n_batches = a.warmup + a.steps + a.roofline_steps
     batches = [make_batch(T, res, k, L, 1000 * rank + s, dev) for s in range(min(n_batches, 4))]

@@ -37,6 +37,7 @@ class FlatGradAllReducer:
             self.views.append(self.flat[off : off + p.numel()].view_as(p))
             off += p.numel()
         self.numel = n
+        self.always_communicate = False  # diagnostic: issue the collective even in a 1-rank group
 
     def reduce(self) -> None:
         """Average the current ``.grad`` of every parameter over the ranks, in place."""
@@ -46,7 +47,7 @@ class FlatGradAllReducer:
             torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        if self.world > 1:
+        if self.world > 1 or self.always_communicate:
             if self.wire is not self.flat:
                 self.wire.copy_(self.flat)
                 dist.all_reduce(self.wire, group=self.group)
