@@ -294,8 +294,8 @@ class MHAFn(Function):
         dt = q_in.dtype
         dev = q_in.device
         g = ops.dropout(dout.contiguous(), p_out, seed_out) if p_out > 0 else dout.contiguous()
-        dW_in = torch.zeros((3 * E, E), dtype=torch.float32, device=dev)
-        db_in = torch.zeros(3 * E, dtype=torch.float32, device=dev)
+        dW_in = ops.zeros_f32((3 * E, E), dev)
+        db_in = ops.zeros_f32(3 * E, dev)
         dW_out = ops.linear_wgrad(g, ctxv.view(B * Lq, E))
         db_out = ops.colsum(g)
         dctx = ops.linear_fwd(g, wo_d).view(B, Lq, E)

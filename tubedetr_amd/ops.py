@@ -17,6 +17,41 @@ from ._hip import ConvDesc, Epilogue, check, dtype_code, ptr, stream_ptr
 Tensor = torch.Tensor
 
 
+class _ZeroArena:
+    """Pre-zeroed fp32 arena for the accumulate-into outputs of the backward kernels (weight / bias / LayerNorm
+    gradients are produced with atomics): one fill per ~128 MB instead of one torch.zeros launch per gradient
+    (~200 per step).  Slices are handed out once and never reused; the arena lives as long as any slice does.  An arena
+    created inside a HIP-graph capture is re-zeroed by the captured fill on every replay and is never used outside it."""
+
+    CHUNK = 32 * 1024 * 1024  # floats
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.captured = False
+
+    def take(self, shape, device) -> torch.Tensor:
+        n = 1
+        for d_ in shape:
+            n *= int(d_)
+        n_al = (n + 63) // 64 * 64  # keep 256-byte alignment of every slice
+        capturing = torch.cuda.is_current_stream_capturing() if device.type == "cuda" else False
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel() or self.captured != capturing:
+            self.buf = torch.zeros(max(self.CHUNK, n_al), dtype=torch.float32, device=device)
+            self.off = 0
+            self.captured = capturing
+        out = self.buf[self.off : self.off + n].view(shape)
+        self.off += n_al
+        return out
+
+
+_ARENA = _ZeroArena()
+
+
+def zeros_f32(shape, device) -> torch.Tensor:
+    return _ARENA.take(tuple(shape) if not isinstance(shape, int) else (shape,), device)
+
+
 def vec_of(dt: torch.dtype) -> int:
     return 8 if dt == torch.bfloat16 else 4
 
@@ -81,7 +116,7 @@ def conv_wgrad(g: Tensor, x: Tensor, R: int, S: int, stride: int, pad: int, *, o
     """dw_k [Co, R*S*C] fp32 (+)= sum_m g[m][co] * im2col(x)[m][k].  `out` (fp32) is accumulated into."""
     N, H, W, Cs = x.shape
     _, Ho, Wo, Co = g.shape
-    dw = out if out is not None else torch.zeros((Co, R * S * Cs), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else zeros_f32((Co, R * S * Cs), x.device)
     d = _desc(N, H, W, Cs, Ho, Wo, R, S, stride, pad, 0, Co, Co)
     check(_hip.lib().td_conv_wgrad(ptr(g), ptr(x), ptr(dw), C.byref(d), Co, dtype_code(x.dtype), splits, stream_ptr()), "td_conv_wgrad")
     return dw
@@ -102,7 +137,7 @@ def linear_wgrad(g: Tensor, x: Tensor, *, out: Optional[Tensor] = None, splits: 
     """dW [N,K] fp32 (+)= g^T @ x   with g [M,N], x [M,K]."""
     M, K = x.shape
     Nn = g.shape[1]
-    dw = out if out is not None else torch.zeros((Nn, K), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else zeros_f32((Nn, K), x.device)
     d = _desc(1, M, 1, K, M, 1, 1, 1, 1, 0, 0, Nn, Nn)
     check(_hip.lib().td_conv_wgrad(ptr(g), ptr(x), ptr(dw), C.byref(d), g.shape[1], dtype_code(x.dtype), splits, stream_ptr()), "td_conv_wgrad")
     return dw
@@ -179,8 +214,8 @@ def add_layernorm_fwd(x: Tensor, r: Optional[Tensor], gamma: Tensor, beta: Tenso
 def add_layernorm_bwd(dy: Tensor, s: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, extra: Optional[Tensor] = None):
     rows, cols = dy.shape
     ds = torch.empty_like(dy)
-    dgamma = torch.zeros(cols, dtype=torch.float32, device=dy.device)
-    dbeta = torch.zeros(cols, dtype=torch.float32, device=dy.device)
+    dgamma = zeros_f32(cols, dy.device)
+    dbeta = zeros_f32(cols, dy.device)
     check(_hip.lib().td_add_layernorm_bwd(ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(extra), ptr(ds), ptr(dgamma), ptr(dbeta),
                                           rows, cols, dtype_code(dy.dtype), stream_ptr()), "td_add_layernorm_bwd")
     return ds, dgamma, dbeta
@@ -188,7 +223,7 @@ def add_layernorm_bwd(dy: Tensor, s: Tensor, mean: Tensor, rstd: Tensor, gamma: 
 
 def colsum(g: Tensor, out: Optional[Tensor] = None) -> Tensor:
     rows, cols = g.shape
-    o = out if out is not None else torch.zeros(cols, dtype=torch.float32, device=g.device)
+    o = out if out is not None else zeros_f32(cols, g.device)
     check(_hip.lib().td_colsum(ptr(g), ptr(o), rows, cols, cols, dtype_code(g.dtype), stream_ptr()), "td_colsum")
     return o
 
