@@ -20,26 +20,26 @@ Tensor = torch.Tensor
 class _ZeroArena:
     """Pre-zeroed fp32 arena for the accumulate-into outputs of the backward kernels (weight / bias / LayerNorm
     gradients are produced with atomics): one fill per ~128 MB instead of one torch.zeros launch per gradient
-    (~200 per step).  Slices are handed out once and never reused; the arena lives as long as any slice does.  An arena
-    created inside a HIP-graph capture is re-zeroed by the captured fill on every replay and is never used outside it."""
+    (~200 per step).  Slices are handed out once and never reused; the arena lives as long as any slice does."""
 
     CHUNK = 32 * 1024 * 1024  # floats
 
     def __init__(self):
         self.buf = None
         self.off = 0
-        self.captured = False
 
     def take(self, shape, device) -> torch.Tensor:
         n = 1
         for d_ in shape:
             n *= int(d_)
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture every gradient gets its own captured fill node (sharing one arena between the
+            # capture's private pool and later eager steps faulted on ROCm 7.0)
+            return torch.zeros(shape, dtype=torch.float32, device=device)
         n_al = (n + 63) // 64 * 64  # keep 256-byte alignment of every slice
-        capturing = torch.cuda.is_current_stream_capturing() if device.type == "cuda" else False
-        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel() or self.captured != capturing:
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             self.buf = torch.zeros(max(self.CHUNK, n_al), dtype=torch.float32, device=device)
             self.off = 0
-            self.captured = capturing
         out = self.buf[self.off : self.off + n].view(shape)
         self.off += n_al
         return out
@@ -48,7 +48,12 @@ class _ZeroArena:
 _ARENA = _ZeroArena()
 
 
+_USE_ARENA = __import__("os").environ.get("TD_ZERO_ARENA", "1") != "0"
+
+
 def zeros_f32(shape, device) -> torch.Tensor:
+    if not _USE_ARENA:
+        return torch.zeros(shape, dtype=torch.float32, device=device)
     return _ARENA.take(tuple(shape) if not isinstance(shape, int) else (shape,), device)
 
 
