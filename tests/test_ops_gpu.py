@@ -232,7 +232,8 @@ def test_pos_sine_matches_oracle(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("cfg", [(3, 8, 151, 151, True), (1, 8, 100, 100, True), (7, 8, 1, 151, True), (2, 8, 37, 70, False)])
+@pytest.mark.parametrize("cfg", [(3, 8, 151, 151, True), (1, 8, 100, 100, True), (7, 8, 1, 151, True), (2, 8, 37, 70, False),
+                                 (2, 8, 20, 50, True), (2, 4, 70, 200, True), (40, 8, 151, 151, False), (1, 8, 33, 300, True)])
 def test_mha_core_fwd_bwd(cfg, dt):
     from tubedetr_amd import ops
 
@@ -268,6 +269,31 @@ def test_mha_core_fwd_bwd(cfg, dt):
         assert rel_err(got, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("cfg", [(3, 8, 151, 151), (1, 8, 100, 100), (5, 8, 1, 151), (2, 8, 40, 200)])
+def test_mha_dropout_same_mask_in_both_dtypes(cfg):
+    """The counter-based dropout mask is a function of (seed, element index) only: the exact-fp32 VALU kernels and the
+    bf16 MFMA kernels must draw the same mask in forward and in both backward kernels."""
+    from tubedetr_amd import ops
+
+    B, H, Lq, Lk = cfg
+    E = H * 32
+    g = torch.Generator().manual_seed(19)
+    q, k, v, dout = (rnd(sh, g, torch.bfloat16) for sh in ((B, Lq, E), (B, Lk, E), (B, Lk, E), (B, Lq, E)))
+    dwavg = torch.randn(B, Lq, Lk, generator=g).to(dev())
+    res = {}
+    for dt in DT:
+        qd, kd, vd, dd = (t.to(dev(), dt) for t in (q, k, v, dout))
+        out, probs, wavg = ops.mha_fwd(qd, kd, vd, None, H, 0.2, need_wavg=True, dropout_p=0.3, seed=1234)
+        dq, dk, dv = ops.mha_bwd(qd, kd, vd, dd, probs, dwavg, H, 0.2, torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd),
+                                 dropout_p=0.3, seed=1234)
+        res[dt] = (out, wavg, dq, dk, dv)
+    for got, ref in zip(res[torch.bfloat16], res[torch.float32]):
+        assert rel_err(got, ref) < 2e-2
+    assert (res[torch.float32][1] == 0).float().mean().item() < 0.05  # wavg averages 8 independently dropped heads
+    out_nodrop, _, _ = ops.mha_fwd(q.to(dev()), k.to(dev()), v.to(dev()), None, H, 0.2)
+    assert rel_err(res[torch.bfloat16][0], out_nodrop) > 0.05  # dropout really applied on the MFMA path
+
+
 def test_mha_strided_qkv_views():
     """q/k packed in one [B,L,2E] buffer (the fused QK projection output) and v separate."""
     from tubedetr_amd import ops
@@ -279,3 +305,13 @@ def test_mha_strided_qkv_views():
     o1, p1, _ = ops.mha_fwd(qk[..., :E], qk[..., E:], v, None, H, 0.17)
     o2, p2, _ = ops.mha_fwd(qk[..., :E].contiguous(), qk[..., E:].contiguous(), v, None, H, 0.17)
     assert torch.equal(o1, o2) and torch.equal(p1, p2)
+    qkb, vb = qk.bfloat16(), v.bfloat16()  # MFMA path: packed views keep 16-byte alignment
+    o1, p1, _ = ops.mha_fwd(qkb[..., :E], qkb[..., E:], vb, None, H, 0.17)
+    o2, p2, _ = ops.mha_fwd(qkb[..., :E].contiguous(), qkb[..., E:].contiguous(), vb, None, H, 0.17)
+    assert torch.equal(o1, o2) and torch.equal(p1, p2)
+    dq = torch.empty_like(qkb)
+    dout = torch.randn(B, L, E, generator=g).to(dev()).bfloat16()
+    ops.mha_bwd(qkb[..., :E], qkb[..., E:], vb, dout, p1, None, H, 0.17, dq[..., :E], dq[..., E:], torch.empty_like(vb))
+    d2q, d2k, _ = ops.mha_bwd(qkb[..., :E].contiguous(), qkb[..., E:].contiguous(), vb, dout, p2, None, H, 0.17,
+                              torch.empty_like(vb), torch.empty_like(vb), torch.empty_like(vb))
+    assert torch.equal(dq[..., :E], d2q) and torch.equal(dq[..., E:], d2k)

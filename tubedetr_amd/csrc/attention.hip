@@ -6,6 +6,7 @@
 // (channel, key-half).  fp32 math on the VALU in both dtypes (inputs/outputs are T).
 // Reference: torch nn.MultiheadAttention at models/transformer.py:613,638-640,661-662,713-740.
 #include "td_common.h"
+#include <stdlib.h>
 
 namespace td {
 
@@ -224,6 +225,286 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 MFMA path (v_mfma_f32_16x16x32_bf16), used for every bf16 problem with Lk <= 256.  One wavefront owns 16 query
+// rows.  Scores are produced TRANSPOSED, S^T[key][query] = K Q^T (head dim 32 = exactly one MFMA K step), so that the
+// accumulator layout (lane = query column, 4 consecutive keys per register quad) is already the B-operand layout of
+// the second product O^T = V^T P^T / dQ^T = K^T dS^T: probabilities never leave registers.  Two 16-key tiles form one
+// 32-deep reduction step in the permuted key order {tile0: 4g..4g+3, tile1: 4g..4g+3}; the A operand (V^T or K^T, kept
+// transposed in LDS as [channel][key], row stride = odd multiple of 16 B -> conflict-free ds_read_b64) is read in the
+// same order.  Softmax statistics need two cross-lane steps (xor 16, 32).  fp32 accumulation; P / dS are rounded to
+// bf16 only as MFMA operands, the stored probabilities stay fp32.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint4 ldg16(const u16* p) { return *(const uint4*)p; }
+
+// rows [n_rows][32] of one head (global, row stride ld) -> LDS transposed [32][stride], rows >= n_valid zero-filled
+__device__ __forceinline__ void stage_transposed(u16* dst, int stride, const u16* src, size_t ld, int n_valid, int n_rows, int t, int nthr) {
+  for (int idx = t; idx < n_rows * 4; idx += nthr) {
+    const int row = idx >> 2, c = idx & 3;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (row < n_valid) val = ldg16(src + (size_t)row * ld + c * 8);
+    const u16* e = (const u16*)&val;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[(c * 8 + i) * stride + row] = e[i];
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(MhaParams p) {
+  constexpr int KP = NT * 16, VS = KP + 8;
+  __shared__ __attribute__((aligned(16))) u16 sVt[32 * VS];
+  __shared__ __attribute__((aligned(16))) float sBias[KP];
+  const int Lk = p.Lk, Lq = p.Lq, nthr = blockDim.x, nw = nthr >> 6;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const u16* Q = (const u16*)p.q;
+  const u16* K = (const u16*)p.k;
+  const u16* V = (const u16*)p.v;
+  const int qb = (blockIdx.y * nw + wave) * 16, qj = qb + li;
+  const bool qv = qj < Lq;
+  uint4 bq = make_uint4(0, 0, 0, 0);
+  if (qv) bq = ldg16(Q + (size_t)(b * Lq + qj) * p.ldq + h * HD + 8 * g);
+  uint4 ak[NT];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    const int key = tt * 16 + li;
+    ak[tt] = make_uint4(0, 0, 0, 0);
+    if (key < Lk) ak[tt] = ldg16(K + (size_t)(b * Lk + key) * p.ldk + h * HD + 8 * g);
+  }
+  stage_transposed(sVt, VS, V + (size_t)b * Lk * p.ldv + h * HD, p.ldv, Lk, KP, t, nthr);
+  for (int key = t; key < KP; key += nthr) sBias[key] = (key < Lk && !(p.kpm && p.kpm[b * Lk + key])) ? 0.f : -INFINITY;
+  __syncthreads();
+  if (qb >= Lq) return;
+  f32x4 s[NT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    s[tt] = mfma_bf16(ak[tt], bq, z);
+    const float4 bias = *(const float4*)&sBias[tt * 16 + 4 * g];
+    s[tt][0] = s[tt][0] * p.scale + bias.x;
+    s[tt][1] = s[tt][1] * p.scale + bias.y;
+    s[tt][2] = s[tt][2] * p.scale + bias.z;
+    s[tt][3] = s[tt][3] * p.scale + bias.w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tt][r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[tt][r] = __expf(s[tt][r] - mx);
+      sum += s[tt][r];
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  const uint32_t seed = effective_seed(p.seed, p.seed_dev);
+  const size_t prow = ((size_t)bh * Lq + qj) * Lk;
+  f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int u = 0; u < NT / 2; ++u) {
+    bf16x8 bp;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = (2 * u + hh) * 16 + 4 * g + r;
+        float pr = s[2 * u + hh][r] * inv;
+        if (qv && key < Lk) p.probs[prow + key] = pr;
+        if (p.drop_thresh) pr = dropout_keep(seed, (uint32_t)(prow + key), p.drop_thresh) ? pr * p.drop_scale : 0.f;
+        bp[hh * 4 + r] = (__bf16)pr;
+      }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      uint4 av;
+      const uint2 lo = *(const uint2*)&sVt[(m * 16 + li) * VS + (2 * u) * 16 + 4 * g];
+      const uint2 hi = *(const uint2*)&sVt[(m * 16 + li) * VS + (2 * u + 1) * 16 + 4 * g];
+      av.x = lo.x; av.y = lo.y; av.z = hi.x; av.w = hi.y;
+      o[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&av, bp, o[m], 0, 0, 0);
+    }
+  }
+  if (qv) {
+    u16* O = (u16*)p.out + (size_t)(b * Lq + qj) * p.ldo + h * HD + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      bf16x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = (__bf16)o[m][r];
+      *(bf16x4*)(O + m * 16) = w;
+    }
+  }
+}
+
+// backward A (MFMA): dP^T = V dO^T, dS^T = P^T * (dP^T - delta), dQ^T = K^T dS^T; writes dS (fp32) for kernel B.
+template <int NT>
+__global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(MhaParams p) {
+  constexpr int KP = NT * 16, VS = KP + 8;
+  __shared__ __attribute__((aligned(16))) u16 sKt[32 * VS];
+  const int Lk = p.Lk, Lq = p.Lq, nthr = blockDim.x, nw = nthr >> 6;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const u16* K = (const u16*)p.k;
+  const u16* V = (const u16*)p.v;
+  const u16* DO = (const u16*)p.dout;
+  const int qb = (blockIdx.y * nw + wave) * 16, qj = qb + li;
+  const bool qv = qj < Lq;
+  uint4 bdo = make_uint4(0, 0, 0, 0);
+  if (qv) bdo = ldg16(DO + (size_t)(b * Lq + qj) * p.ldo + h * HD + 8 * g);
+  uint4 av[NT];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    const int key = tt * 16 + li;
+    av[tt] = make_uint4(0, 0, 0, 0);
+    if (key < Lk) av[tt] = ldg16(V + (size_t)(b * Lk + key) * p.ldv + h * HD + 8 * g);
+  }
+  stage_transposed(sKt, VS, K + (size_t)b * Lk * p.ldk + h * HD, p.ldk, Lk, KP, t, nthr);
+  __syncthreads();
+  if (qb >= Lq) return;
+  const uint32_t seed = effective_seed(p.seed, p.seed_dev);
+  const size_t prow = ((size_t)bh * Lq + qj) * Lk;
+  const size_t wrow = ((size_t)b * Lq + qj) * Lk;
+  const float invH = 1.f / p.H;
+  f32x4 dp[NT], pr[NT];
+  float delta = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    dp[tt] = mfma_bf16(av[tt], bdo, z);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = tt * 16 + 4 * g + r;
+      float prv = 0.f, d = 0.f;
+      if (qv && key < Lk) {
+        prv = p.probs[prow + key];
+        d = dp[tt][r];
+        if (p.dwavg) d += p.dwavg[wrow + key] * invH;
+        if (p.drop_thresh) d = dropout_keep(seed, (uint32_t)(prow + key), p.drop_thresh) ? d * p.drop_scale : 0.f;
+      }
+      pr[tt][r] = prv;
+      dp[tt][r] = d;
+      delta += prv * d;
+    }
+  }
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+  f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int u = 0; u < NT / 2; ++u) {
+    bf16x8 bs;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tt = 2 * u + hh, key = tt * 16 + 4 * g + r;
+        const float ds = pr[tt][r] * (dp[tt][r] - delta);
+        if (qv && key < Lk) p.ds_ws[prow + key] = ds;
+        bs[hh * 4 + r] = (__bf16)ds;
+      }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      uint4 ak;
+      const uint2 lo = *(const uint2*)&sKt[(m * 16 + li) * VS + (2 * u) * 16 + 4 * g];
+      const uint2 hi = *(const uint2*)&sKt[(m * 16 + li) * VS + (2 * u + 1) * 16 + 4 * g];
+      ak.x = lo.x; ak.y = lo.y; ak.z = hi.x; ak.w = hi.y;
+      dq[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&ak, bs, dq[m], 0, 0, 0);
+    }
+  }
+  if (qv) {
+    u16* DQ = (u16*)p.dq + (size_t)(b * Lq + qj) * p.ldq + h * HD + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      bf16x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = (__bf16)(dq[m][r] * p.scale);
+      *(bf16x4*)(DQ + m * 16) = w;
+    }
+  }
+}
+
+// backward B (MFMA): one wavefront per 16-key tile; dV^T = dO^T dropout(P), dK^T = scale * Q^T dS, reduction over queries
+// in chunks of 32 (A = dO^T / Q^T from transposed LDS, B = P / dS columns read straight from the fp32 tensors).
+__global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(MhaParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Lk = p.Lk, Lq = p.Lq, nthr = blockDim.x, nw = nthr >> 6;
+  const int QP = cdiv(Lq, 32) * 32, QS = QP + 8;
+  u16* sQt = (u16*)sm;
+  u16* sOt = sQt + 32 * QS;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  stage_transposed(sQt, QS, (const u16*)p.q + (size_t)b * Lq * p.ldq + h * HD, p.ldq, Lq, QP, t, nthr);
+  stage_transposed(sOt, QS, (const u16*)p.dout + (size_t)b * Lq * p.ldo + h * HD, p.ldo, Lq, QP, t, nthr);
+  __syncthreads();
+  const int kt = blockIdx.y * nw + wave;
+  if (kt * 16 >= Lk) return;
+  const int key = kt * 16 + li;
+  const bool kv = key < Lk;
+  const uint32_t seed = effective_seed(p.seed, p.seed_dev);
+  f32x4 dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int qc = 0; qc < QP; qc += 32) {
+    bf16x8 bp, bs;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int qq = qc + 8 * g + i;
+      float pr = 0.f, ds = 0.f;
+      if (kv && qq < Lq) {
+        const size_t pi = ((size_t)bh * Lq + qq) * Lk + key;
+        pr = p.probs[pi];
+        ds = p.ds_ws[pi];
+        if (p.drop_thresh) pr = dropout_keep(seed, (uint32_t)pi, p.drop_thresh) ? pr * p.drop_scale : 0.f;
+      }
+      bp[i] = (__bf16)pr;
+      bs[i] = (__bf16)ds;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const bf16x8 ao = *(const bf16x8*)&sOt[(m * 16 + li) * QS + qc + 8 * g];
+      const bf16x8 aq = *(const bf16x8*)&sQt[(m * 16 + li) * QS + qc + 8 * g];
+      dv[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp, dv[m], 0, 0, 0);
+      dk[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bs, dk[m], 0, 0, 0);
+    }
+  }
+  if (kv) {
+    u16* DK = (u16*)p.dk + (size_t)(b * Lk + key) * p.ldk + h * HD + 4 * g;
+    u16* DV = (u16*)p.dv + (size_t)(b * Lk + key) * p.ldv + h * HD + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      bf16x4 wk, wv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        wk[r] = (__bf16)(dk[m][r] * p.scale);
+        wv[r] = (__bf16)dv[m][r];
+      }
+      *(bf16x4*)(DK + m * 16) = wk;
+      *(bf16x4*)(DV + m * 16) = wv;
+    }
+  }
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static bool mfma_path_ok(const MhaParams& p, int dtype, bool bwd) {
+  static const bool off = [] { const char* e = getenv("TD_MHA_VALU"); return e && e[0] == '1'; }();
+  if (off || dtype != TD_BF16 || p.Lk > 256 || p.Lq > 448) return false;
+  if ((p.ldq | p.ldk | p.ldv | p.ldo) & 7) return false;
+  if (!aligned16(p.q) || !aligned16(p.k) || !aligned16(p.v)) return false;
+  if (!bwd && ((uintptr_t)p.out & 7)) return false;
+  if (bwd && (!aligned16(p.dout) || ((uintptr_t)p.dq & 7) || ((uintptr_t)p.dk & 7) || ((uintptr_t)p.dv & 7))) return false;
+  return true;
+}
+// wavefronts per workgroup: 4 when that still leaves >= 256 workgroups, else fewer (small problems want more, smaller
+// workgroups: the temporal self-attention is 8 heads x 100 queries in total)
+static int pick_waves(int BH, int tiles) {
+  int nw = 4;
+  while (nw > 1 && (BH * cdiv(tiles, nw) < 256 || nw > tiles)) nw >>= 1;
+  return nw;
+}
 static int fill(MhaParams& p, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
                 float dropout_p, uint32_t seed, const char* who) {
   TD_REQUIRE(hd == HD, "%s: head dim %d unsupported (only 32)", who, hd);
@@ -274,7 +555,14 @@ extern "C" int td_mha_fwd(const void* q, const void* k, const void* v, const uin
   size_t lds = (size_t)(2 * Lk * 33 + 4 * Lk) * sizeof(float);
   dim3 grid(B * H, (Lq + QT - 1) / QT);
   mha_allow_big_lds();
-  if (dtype == TD_BF16) mha_fwd_kernel<u16><<<grid, 256, lds, st>>>(p);
+  if (mfma_path_ok(p, dtype, false)) {
+    const int qt = cdiv(Lq, 16), nw = pick_waves(B * H, qt);
+    dim3 g2(B * H, cdiv(qt, nw));
+    if (Lk <= 64) mha_fwd_mfma_kernel<4><<<g2, 64 * nw, 0, st>>>(p);
+    else if (Lk <= 128) mha_fwd_mfma_kernel<8><<<g2, 64 * nw, 0, st>>>(p);
+    else if (Lk <= 160) mha_fwd_mfma_kernel<10><<<g2, 64 * nw, 0, st>>>(p);
+    else mha_fwd_mfma_kernel<16><<<g2, 64 * nw, 0, st>>>(p);
+  } else if (dtype == TD_BF16) mha_fwd_kernel<u16><<<grid, 256, lds, st>>>(p);
   else if (dtype == TD_F32) mha_fwd_kernel<float><<<grid, 256, lds, st>>>(p);
   else TD_REQUIRE(false, "td_mha_fwd: bad dtype");
   rc = check_launch("td_mha_fwd");
@@ -304,7 +592,17 @@ extern "C" int td_mha_bwd(const void* q, const void* k, const void* v, const voi
   TD_REQUIRE(ldsA <= 160 * 1024 && ldsB <= 160 * 1024, "td_mha_bwd: Lq/Lk too large for LDS");
   dim3 gridA(B * H, (Lq + QT - 1) / QT), gridB(B * H, (Lk + 63) / 64);
   mha_allow_big_lds();
-  if (dtype == TD_BF16) {
+  if (mfma_path_ok(p, dtype, true)) {
+    const int qt = cdiv(Lq, 16), nwq = pick_waves(B * H, qt);
+    dim3 gA(B * H, cdiv(qt, nwq));
+    if (Lk <= 64) mha_bwd_dq_mfma_kernel<4><<<gA, 64 * nwq, 0, st>>>(p);
+    else if (Lk <= 128) mha_bwd_dq_mfma_kernel<8><<<gA, 64 * nwq, 0, st>>>(p);
+    else if (Lk <= 160) mha_bwd_dq_mfma_kernel<10><<<gA, 64 * nwq, 0, st>>>(p);
+    else mha_bwd_dq_mfma_kernel<16><<<gA, 64 * nwq, 0, st>>>(p);
+    const int ktl = cdiv(Lk, 16), nwk = pick_waves(B * H, ktl);
+    const int QS = cdiv(Lq, 32) * 32 + 8;
+    mha_bwd_dkv_mfma_kernel<<<dim3(B * H, cdiv(ktl, nwk)), 64 * nwk, (size_t)2 * 32 * QS * sizeof(u16), st>>>(p);
+  } else if (dtype == TD_BF16) {
     mha_bwd_dq_kernel<u16><<<gridA, 256, ldsA, st>>>(p);
     mha_bwd_dkv_kernel<u16><<<gridB, 256, ldsB, st>>>(p);
   } else if (dtype == TD_F32) {
