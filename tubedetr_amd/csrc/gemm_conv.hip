@@ -488,8 +488,11 @@ __device__ __forceinline__ int wg_swz(int row) {
   return ES == 2 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (row & 7);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
+// NSTG = 2: two 32-KiB stages, one in flight, two workgroups per CU.  NSTG = 4: four stages (128 KiB of the CU's 160 KiB
+// LDS, one workgroup per CU), three in flight behind counted s_waitcnt vmcnt - the launch has about one workgroup per
+// CU anyway (fp32 atomics per output tile limit the split count), so bytes in flight per CU are what is left to raise.
+template <typename T, int NSTG>
+__global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;
   constexpr int MK = 128 / ES;             // reduction rows per stage: 64 (bf16) / 32 (fp32)
@@ -502,6 +505,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
   constexpr uint32_t OOB = 0xFFFFFFF0u;
   __shared__ __attribute__((aligned(16))) char stage0[2 * TILEB];
   __shared__ __attribute__((aligned(16))) char stage1[2 * TILEB];
+  __shared__ __attribute__((aligned(16))) char stage2[NSTG == 4 ? 2 * TILEB : 16];
+  __shared__ __attribute__((aligned(16))) char stage3[NSTG == 4 ? 2 * TILEB : 16];
 
   const td_conv_desc& d = p.d;
   const int t = threadIdx.x;
@@ -620,15 +625,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
   };
 
   const int nit = (mend - mbeg + MK - 1) / MK;
-  issue_stage(stage0, mbeg);
-  for (int it = 0; it < nit; it += 2) {
-    __syncthreads();
-    if (it + 1 < nit) issue_stage(stage1, mbeg + (it + 1) * MK);
-    compute_stage(stage0);
-    if (it + 1 >= nit) break;
-    __syncthreads();
-    if (it + 2 < nit) issue_stage(stage0, mbeg + (it + 2) * MK);
-    compute_stage(stage1);
+  if constexpr (NSTG == 2) {
+    issue_stage(stage0, mbeg);
+    for (int it = 0; it < nit; it += 2) {
+      __syncthreads();
+      if (it + 1 < nit) issue_stage(stage1, mbeg + (it + 1) * MK);
+      compute_stage(stage0);
+      if (it + 1 >= nit) break;
+      __syncthreads();
+      if (it + 2 < nit) issue_stage(stage0, mbeg + (it + 2) * MK);
+      compute_stage(stage1);
+    }
+  } else {
+    // every step issues exactly one stage (rows past mend are all-OOB = zero fill, no traffic), so "the stage I am about
+    // to read has landed" is always "at most two stages = 4*LI DMA instructions of this wave still outstanding"
+#define TD_WG_STEP(cur, nxt, j)                                                        \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LI) : "memory");                      \
+  __builtin_amdgcn_s_barrier();                                                       \
+  issue_stage(nxt, mbeg + ((j) + 3) * MK);                                            \
+  if ((j) >= 0) compute_stage(cur);
+    // software-pipeline warm-up folded into the loop (steps -3..-1 only issue): every stage buffer has exactly one
+    // static DMA site, which keeps the compiler's own LDS-DMA wait counts exact
+    for (int it = -3; it < nit; it += 4) {
+      TD_WG_STEP(stage1, stage0, it)
+      if (it + 1 >= nit) break;
+      TD_WG_STEP(stage2, stage1, it + 1)
+      if (it + 2 >= nit) break;
+      TD_WG_STEP(stage3, stage2, it + 2)
+      if (it + 3 >= nit) break;
+      TD_WG_STEP(stage0, stage3, it + 3)
+    }
+#undef TD_WG_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing zero-fill DMAs must not outlive the workgroup's LDS
   }
   // D[i=co][j=kk]: lane holds co = base + 4*lg + r, kk = base + lr
 #pragma unroll
@@ -757,11 +785,12 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
     p.src_bytes = (uint32_t)sb;
   }
   const int mk = dtype == TD_BF16 ? 64 : 32;
+  static const int nstg = [] { const char* e = getenv("TD_WGRAD_STAGES"); return (e && atoi(e) == 2) ? 2 : 4; }();
   if (splits < 1) {
     // about one workgroup per CU (TD_WGRAD_BLOCKS, default 256), at least 8 reduction stages (512 / 256 rows) per split
     static const int target_blocks = [] { const char* e = getenv("TD_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();  // measured: 192-256 workgroups beat 512-1536 (fewer fp32 atomics per output tile)
     int tiles = cdiv(d->Nc, 128) * cdiv(p.K, 128);
-    splits = cdiv(target_blocks, tiles);
+    splits = nstg == 4 ? target_blocks / tiles : cdiv(target_blocks, tiles);  // 4 stages: one workgroup per CU, never a second round
     int maxs = cdiv(p.M, 8 * mk);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
@@ -772,8 +801,13 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
   hipStream_t st = (hipStream_t)stream;
   const bool prof = prof_on();
   if (prof) prof_begin(TD_PROF_WGRAD, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, splits);
-  if (dtype == TD_BF16) conv_wgrad_kernel<u16><<<grid, 256, 0, st>>>(p);
-  else conv_wgrad_kernel<float><<<grid, 256, 0, st>>>(p);
+  if (nstg == 4) {
+    if (dtype == TD_BF16) conv_wgrad_kernel<u16, 4><<<grid, 256, 0, st>>>(p);
+    else conv_wgrad_kernel<float, 4><<<grid, 256, 0, st>>>(p);
+  } else {
+    if (dtype == TD_BF16) conv_wgrad_kernel<u16, 2><<<grid, 256, 0, st>>>(p);
+    else conv_wgrad_kernel<float, 2><<<grid, 256, 0, st>>>(p);
+  }
   if (prof) prof_end(st);
   return check_launch("td_conv_wgrad");
 }
