@@ -474,6 +474,8 @@ struct WgradParams {
   td_conv_desc d;
   int M, K, ldg, mper;
   uint32_t g_bytes, src_bytes;
+  int dbg;
+  unsigned long long* stamps;  // debug: 40 cycle stamps per workgroup (tools/stamp_wgrad.py)
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -491,7 +493,7 @@ __device__ __forceinline__ int wg_swz(int row) {
 // NSTG = 2: two 32-KiB stages, one in flight, two workgroups per CU.  NSTG = 4: four stages (128 KiB of the CU's 160 KiB
 // LDS, one workgroup per CU), three in flight behind counted s_waitcnt vmcnt - the launch has about one workgroup per
 // CU anyway (fp32 atomics per output tile limit the split count), so bytes in flight per CU are what is left to raise.
-template <typename T, int NSTG>
+template <typename T, int NSTG, bool PW>
 __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;
@@ -511,12 +513,13 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
   const td_conv_desc& d = p.d;
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const unsigned long long t_start = __builtin_readcyclecounter();
   const int co0 = blockIdx.x * 128, kk0 = blockIdx.y * 128;
   const int mbeg = blockIdx.z * p.mper;
   const int mend = min(p.M, mbeg + p.mper);
   if (mbeg >= mend) return;
   const int HoWo = d.Ho * d.Wo;
-  const bool pointwise = (d.R * d.S == 1) && d.stride == 1 && d.pad == 0;
+  constexpr bool pointwise = PW;  // 1x1, stride 1, no padding: im2col row == source row
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
 
@@ -542,25 +545,41 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
       xs[i] = tap - xr[i] * d.S;
     }
   }
-  auto issue_stage = [&](char* st, int mb) {
+  // running (row, frame, ho, wo) of each DMA row of this lane; stages are issued strictly in order, MK rows apart, so the
+  // im2col coordinates advance by a constant (dN, dH, dW) with one carry each - no divisions, no divergent branches in
+  // the loop (the compiler can then interleave the address arithmetic with the MFMAs of the stage being consumed)
+  int mcur[LI], rn[LI], rho[LI], rwo[LI];
+  const int dN = MK / HoWo, dH = (MK - dN * HoWo) / d.Wo, dW = MK - dN * HoWo - dH * d.Wo;
+#pragma unroll
+  for (int i = 0; i < LI; ++i) {
+    mcur[i] = mbeg + rloc[i];
+    rn[i] = mcur[i] / HoWo;
+    const int rem = mcur[i] - rn[i] * HoWo;
+    rho[i] = rem / d.Wo;
+    rwo[i] = rem - rho[i] * d.Wo;
+  }
+  auto issue_stage = [&](char* st) {
 #pragma unroll
     for (int i = 0; i < LI; ++i) {
-      const int m = mb + rloc[i];
+      const int m = mcur[i];
       const bool ok = m < mend;
-      uint32_t og = (ok && gok[i]) ? ((uint32_t)m * (uint32_t)p.ldg + (uint32_t)gcol[i]) * ES : OOB;
-      uint32_t ox = OOB;
-      if (ok && xok[i]) {
-        if (pointwise) {
-          ox = ((uint32_t)m * (uint32_t)d.C + (uint32_t)xc[i]) * ES;
-        } else {
-          int n = m / HoWo;
-          int rem = m - n * HoWo;
-          int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-          int hs = ho * d.stride - d.pad + xr[i], ws = wo * d.stride - d.pad + xs[i];
-          if ((unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws)
-            ox = ((uint32_t)((n * d.Hs + hs) * d.Ws + ws) * (uint32_t)d.C + (uint32_t)xc[i]) * ES;
-        }
+      const uint32_t og = (ok && gok[i]) ? ((uint32_t)m * (uint32_t)p.ldg + (uint32_t)gcol[i]) * ES : OOB;
+      uint32_t ox;
+      if constexpr (pointwise) {
+        ox = (ok && xok[i]) ? ((uint32_t)m * (uint32_t)d.C + (uint32_t)xc[i]) * ES : OOB;
+      } else {
+        const int hs = rho[i] * d.stride - d.pad + xr[i], ws = rwo[i] * d.stride - d.pad + xs[i];
+        const bool in = ok && xok[i] && (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
+        ox = in ? ((uint32_t)((rn[i] * d.Hs + hs) * d.Ws + ws) * (uint32_t)d.C + (uint32_t)xc[i]) * ES : OOB;
+        rwo[i] += dW;
+        const int c1 = rwo[i] >= d.Wo;
+        rwo[i] -= c1 ? d.Wo : 0;
+        rho[i] += dH + c1;
+        const int c2 = rho[i] >= d.Ho;
+        rho[i] -= c2 ? d.Ho : 0;
+        rn[i] += dN + c2;
       }
+      mcur[i] += MK;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(st + (i * 4 + wave) * 1024), 16, og, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st + TILEB + (i * 4 + wave) * 1024), 16, ox, 0, 0, 0);
     }
@@ -578,19 +597,22 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
     const char* sG = st;
     const char* sX = st + TILEB;
     if constexpr (ES == 2) {
+      // all fragment reads of the stage are issued before the first MFMA: one wavefront per SIMD has nobody to hide the
+      // LDS latency behind, so the second half's reads must fly while the first half multiplies
+      constexpr int KS = MK / 32;
       const int jrow = lr >> 2, q = lr & 3;
+      const int f = jrow | ((lg & 1) << 2);  // = wg_swz(r0) = wg_swz(r1)
+      uint4 gf[KS][4], xf[KS][4];
 #pragma unroll
-      for (int ks = 0; ks < MK / 32; ++ks) {
-        uint4 gf[4], xf[4];
+      for (int ks = 0; ks < KS; ++ks) {
         const int r0 = ks * 32 + 8 * lg + jrow, r1 = r0 + 4;
-        const int f = jrow | ((lg & 1) << 2);  // = wg_swz(r0) = wg_swz(r1)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int cb = (((wy * 4 + i) ^ f) << 5) + q * 8;
           bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sG + r0 * ROWB + cb));
           bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sG + r1 * ROWB + cb));
           uint2 l2 = *(uint2*)&lo, h2 = *(uint2*)&hi;
-          gf[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+          gf[ks][i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -598,14 +620,16 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
           bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sX + r0 * ROWB + cb));
           bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sX + r1 * ROWB + cb));
           uint2 l2 = *(uint2*)&lo, h2 = *(uint2*)&hi;
-          xf[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+          xf[ks][j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
         }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&gf[i], *(const bf16x8*)&xf[j], acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&gf[ks][i], *(const bf16x8*)&xf[ks][j], acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
       for (int s4 = 0; s4 < MK / 4; ++s4) {
@@ -625,15 +649,19 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
   };
 
   const int nit = (mend - mbeg + MK - 1) / MK;
+  unsigned long long* stp = p.stamps ? p.stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 40 : nullptr;
+#define TD_WSTAMP(i) do { if (stp && t == 0) stp[i] = __builtin_readcyclecounter(); } while (0)
+  if (stp && t == 0) stp[0] = t_start;
+  TD_WSTAMP(1);
   if constexpr (NSTG == 2) {
-    issue_stage(stage0, mbeg);
+    issue_stage(stage0);
     for (int it = 0; it < nit; it += 2) {
       __syncthreads();
-      if (it + 1 < nit) issue_stage(stage1, mbeg + (it + 1) * MK);
+      if (it + 1 < nit) issue_stage(stage1);
       compute_stage(stage0);
       if (it + 1 >= nit) break;
       __syncthreads();
-      if (it + 2 < nit) issue_stage(stage0, mbeg + (it + 2) * MK);
+      if (it + 2 < nit) issue_stage(stage0);
       compute_stage(stage1);
     }
   } else {
@@ -642,8 +670,8 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
 #define TD_WG_STEP(cur, nxt, j)                                                        \
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LI) : "memory");                      \
   __builtin_amdgcn_s_barrier();                                                       \
-  issue_stage(nxt, mbeg + ((j) + 3) * MK);                                            \
-  if ((j) >= 0) compute_stage(cur);
+  issue_stage(nxt);                                                                   \
+  if ((j) >= 0) { compute_stage(cur); if ((j) < 32) TD_WSTAMP(4 + (j)); }
     // software-pipeline warm-up folded into the loop (steps -3..-1 only issue): every stage buffer has exactly one
     // static DMA site, which keeps the compiler's own LDS-DMA wait counts exact
     for (int it = -3; it < nit; it += 4) {
@@ -659,6 +687,8 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing zero-fill DMAs must not outlive the workgroup's LDS
   }
   // D[i=co][j=kk]: lane holds co = base + 4*lg + r, kk = base + lr
+  TD_WSTAMP(2);
+  if (p.dbg == 1 && acc[0][0][0] != 12345.f) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -671,6 +701,8 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
         if (coo < d.Nc) atomicAdd(p.dw + (size_t)coo * p.K + kko, acc[i][j][rr]);
       }
     }
+  TD_WSTAMP(3);
+#undef TD_WSTAMP
 }
 
 static int validate(const td_conv_desc* d, int dtype, const char* who) {
@@ -777,6 +809,8 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
   p.M = d->N * d->Ho * d->Wo;
   p.K = d->R * d->S * d->C;
   p.ldg = ldg;
+  { static const int dbg = [] { const char* e = getenv("TD_WGRAD_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+  p.stamps = g_dbg;
   {
     const double es = dtype == TD_BF16 ? 2.0 : 4.0;
     const double gb = (double)p.M * ldg * es, sb = (double)d->N * d->Hs * d->Ws * d->C * es;
@@ -801,13 +835,20 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
   hipStream_t st = (hipStream_t)stream;
   const bool prof = prof_on();
   if (prof) prof_begin(TD_PROF_WGRAD, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, splits);
+  const bool pw = (d->R * d->S == 1) && d->stride == 1 && d->pad == 0;
+#define TD_WG_LAUNCH(TT, NS)                                                    \
+  do {                                                                          \
+    if (pw) conv_wgrad_kernel<TT, NS, true><<<grid, 256, 0, st>>>(p);           \
+    else conv_wgrad_kernel<TT, NS, false><<<grid, 256, 0, st>>>(p);             \
+  } while (0)
   if (nstg == 4) {
-    if (dtype == TD_BF16) conv_wgrad_kernel<u16, 4><<<grid, 256, 0, st>>>(p);
-    else conv_wgrad_kernel<float, 4><<<grid, 256, 0, st>>>(p);
+    if (dtype == TD_BF16) TD_WG_LAUNCH(u16, 4);
+    else TD_WG_LAUNCH(float, 4);
   } else {
-    if (dtype == TD_BF16) conv_wgrad_kernel<u16, 2><<<grid, 256, 0, st>>>(p);
-    else conv_wgrad_kernel<float, 2><<<grid, 256, 0, st>>>(p);
+    if (dtype == TD_BF16) TD_WG_LAUNCH(u16, 2);
+    else TD_WG_LAUNCH(float, 2);
   }
+#undef TD_WG_LAUNCH
   if (prof) prof_end(st);
   return check_launch("td_conv_wgrad");
 }
