@@ -94,6 +94,23 @@ int td_conv_gemm(const void* src, const void* wmat, void* out, const td_conv_des
 int td_conv_wgrad(const void* g, const void* src, float* dw, const td_conv_desc* d, int ldg, int dtype, int splits,
                   td_stream_t stream);
 
+/* Batched weight gradients: ONE launch (two when 1x1 and 3x3 jobs are mixed) computes the weight gradients of many
+ * conv layers.  dW of every job is written in the parameter's own [Nc][ci_real][R][S] fp32 layout with `scale[co]`
+ * (the FrozenBN factor, may be NULL) folded in - overwritten, not accumulated.  With thousands of output tiles in flight
+ * a job needs no reduction splits (no atomics, no accumulator memset, no finalize pass) unless its M is very long.
+ * `jobs` is a host array, consumed before the call returns.  Replaces the same autograd call sites as td_conv_wgrad,
+ * for all convs of the trunk at once (torchvision resnet Bottleneck backward, models/backbone.py:94-98). */
+typedef struct td_wgrad_job {
+  const void* g;      /* [M][ldg] output gradient rows */
+  const void* src;    /* the layer's input activation (NHWC) */
+  float* dW;          /* [Nc][ci_real][R][S] fp32 */
+  const float* scale; /* [Nc] or NULL */
+  td_conv_desc d;     /* forward geometry (mode 0) */
+  int ldg;
+  int ci_real;        /* input channels of the parameter (d.C may be padded) */
+} td_wgrad_job;
+int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, td_stream_t stream);
+
 /* Native executor of the bottleneck-ResNet trunk (replaces the module-graph execution of torchvision resnet101 through
  * IntermediateLayerGetter, models/backbone.py:94-98, and its autograd backward).  Conv order in every array: stem,
  * then per block conv1, conv2, conv3[, downsample] (td_resnet_num_convs entries).  x_nchw: (N,3,H,W) fp32 frames;

@@ -82,6 +82,41 @@ def test_conv_fwd_dgrad_wgrad(cfg, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+def test_conv_wgrad_batch_matches_autograd(dt):
+    """All weight gradients of a mixed set of layers in one batched launch: parameter-layout output, FrozenBN scale
+    folded, un-split jobs (plain stores) and split jobs (long M: atomics on a zeroed output) side by side, stale
+    output buffers overwritten."""
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(21)
+    cfgs = CONVS + [(40, 64, 28, 28, 64, 1, 1, 0), (30, 64, 24, 24, 128, 3, 1, 1)]  # the last two are long enough to split
+    jobs, refs = [], []
+    for i, (N, Ci, H, W, Co, R, st, pad) in enumerate(cfgs):
+        x = rnd((N, Ci, H, W), g, dt)
+        Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+        gy = rnd((N, Co, Ho, Wo), g, dt)
+        w = torch.zeros(Co, Ci, R, R, requires_grad=True)
+        F.conv2d(x, w, None, stride=st, padding=pad).backward(gy)
+        scale = (torch.rand(Co, generator=g) + 0.5) if i % 2 == 0 else None
+        refs.append(w.grad * (scale.view(-1, 1, 1, 1) if scale is not None else 1.0))
+        jobs.append((nhwc(gy, dt), nhwc(x, dt), R, R, st, pad, scale.to(dev()) if scale is not None else None, Ci))
+    outs = ops.conv_wgrad_batch(jobs)
+    for got, ref, cfg in zip(outs, refs, cfgs):
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) < TOL[dt], cfg
+    # padded source channels (the stem: 3 real channels stored as 8): only ci_real channels are written
+    N, H, W, Co = 2, 30, 34, 64
+    x = rnd((N, 3, H, W), g, dt)
+    gy = rnd((N, Co, 15, 17), g, dt)
+    w = torch.zeros(Co, 3, 7, 7, requires_grad=True)
+    F.conv2d(x, w, None, stride=2, padding=3).backward(gy)
+    xp = torch.zeros(N, 8, H, W)
+    xp[:, :3] = x
+    (dw,) = ops.conv_wgrad_batch([(nhwc(gy, dt), nhwc(xp, dt), 7, 7, 2, 3, None, 3)])
+    assert rel_err(dw, w.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_frozen_bn_fold_and_mask_epilogues(dt):
     from tubedetr_amd import ops
 

@@ -24,6 +24,11 @@ class PrepItem(C.Structure):
                [(n, C.c_int) for n in ("Co", "Ci", "RS", "Cpad", "Co_alloc", "blk0")]
 
 
+class WgradJob(C.Structure):
+    """td_wgrad_job (include/tubedetr_hip.h)."""
+    _fields_ = [("g", C.c_void_p), ("src", C.c_void_p), ("dW", C.c_void_p), ("scale", C.c_void_p), ("d", ConvDesc), ("ldg", C.c_int), ("ci_real", C.c_int)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [
         ("bias", C.c_void_p),
@@ -46,6 +51,7 @@ _SIGS = {
     "td_prof_collect": [_I, _I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "td_conv_gemm": [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P],
     "td_conv_wgrad": [_P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
+    "td_conv_wgrad_batch": [C.POINTER(WgradJob), _I, _I, _P],
     "td_resnet_num_convs": [C.POINTER(C.c_int)],
     "td_resnet_fwd": [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ, C.POINTER(_P), C.POINTER(C.c_int), _I, _P],
     "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _I, _P],

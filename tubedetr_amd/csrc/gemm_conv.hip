@@ -18,6 +18,8 @@
 #include <type_traits>
 
 #include "td_common.h"
+#include <algorithm>
+#include <vector>
 
 namespace td {
 
@@ -471,9 +473,14 @@ struct WgradParams {
   const char* g;
   const char* src;
   float* dw;
+  const float* scale;  // out_mode 1/2: per-output-channel factor folded into the result (FrozenBN scale), may be null
   td_conv_desc d;
   int M, K, ldg, mper;
   uint32_t g_bytes, src_bytes;
+  int out_mode;  // 0: dw = [Nc][K] (K = R*S*C), fp32 atomics.  1: dw = the parameter's own [Nc][ci_real][R][S], atomics.
+                 // 2: as 1 with plain stores (the job has a single split: nobody else touches the tile)
+  int ci_real;   // input channels of the parameter (C may be padded)
+  int tn, tk, first;  // batched launch: tile grid of this job and its first workgroup index
   int dbg;
   unsigned long long* stamps;  // debug: 40 cycle stamps per workgroup (tools/stamp_wgrad.py)
 };
@@ -494,7 +501,7 @@ __device__ __forceinline__ int wg_swz(int row) {
 // LDS, one workgroup per CU), three in flight behind counted s_waitcnt vmcnt - the launch has about one workgroup per
 // CU anyway (fp32 atomics per output tile limit the split count), so bytes in flight per CU are what is left to raise.
 template <typename T, int NSTG, bool PW>
-__global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int bz) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;
   constexpr int MK = 128 / ES;             // reduction rows per stage: 64 (bf16) / 32 (fp32)
@@ -514,8 +521,8 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const unsigned long long t_start = __builtin_readcyclecounter();
-  const int co0 = blockIdx.x * 128, kk0 = blockIdx.y * 128;
-  const int mbeg = blockIdx.z * p.mper;
+  const int co0 = bx * 128, kk0 = by * 128;
+  const int mbeg = bz * p.mper;
   const int mend = min(p.M, mbeg + p.mper);
   if (mbeg >= mend) return;
   const int HoWo = d.Ho * d.Wo;
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
   };
 
   const int nit = (mend - mbeg + MK - 1) / MK;
-  unsigned long long* stp = p.stamps ? p.stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 40 : nullptr;
+  unsigned long long* stp = p.stamps ? p.stamps + (size_t)(p.first + bx + p.tn * (by + p.tk * bz)) * 40 : nullptr;
 #define TD_WSTAMP(i) do { if (stp && t == 0) stp[i] = __builtin_readcyclecounter(); } while (0)
   if (stp && t == 0) stp[0] = t_start;
   TD_WSTAMP(1);
@@ -689,20 +696,69 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(Wgra
   // D[i=co][j=kk]: lane holds co = base + 4*lg + r, kk = base + lr
   TD_WSTAMP(2);
   if (p.dbg == 1 && acc[0][0][0] != 12345.f) return;
+  if (p.out_mode == 0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int kko = kk0 + wx * 64 + j * 16 + lr;
+        if (kko >= p.K) continue;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          int coo = co0 + wy * 64 + i * 16 + 4 * lg + rr;
+          if (coo < d.Nc) atomicAdd(p.dw + (size_t)coo * p.K + kko, acc[i][j][rr]);
+        }
+      }
+  } else {
+    // straight into the parameter's [Nc][ci_real][R][S] layout with the FrozenBN scale folded (what wgrad_finalize did)
+    const int RS = d.R * d.S;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int kko = kk0 + wx * 64 + j * 16 + lr;
+      const int kko = kk0 + wx * 64 + j * 16 + lr;
       if (kko >= p.K) continue;
+      const int tap = kko / d.C, ci = kko - tap * d.C;
+      if (ci >= p.ci_real) continue;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        int coo = co0 + wy * 64 + i * 16 + 4 * lg + rr;
-        if (coo < d.Nc) atomicAdd(p.dw + (size_t)coo * p.K + kko, acc[i][j][rr]);
-      }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int coo = co0 + wy * 64 + i * 16 + 4 * lg + rr;
+          if (coo >= d.Nc) continue;
+          const float v = acc[i][j][rr] * (p.scale ? p.scale[coo] : 1.f);
+          float* dst = p.dw + ((size_t)coo * p.ci_real + ci) * RS + tap;
+          if (p.out_mode == 2) *dst = v;
+          else atomicAdd(dst, v);
+        }
     }
+  }
   TD_WSTAMP(3);
 #undef TD_WSTAMP
+}
+
+template <typename T, int NSTG, bool PW>
+__global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
+  wgrad_body<T, NSTG, PW>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Batched form: one launch covers the weight gradients of many layers (jobs sorted by first workgroup index; a
+// workgroup finds its job by binary search, then its (co tile, k tile, split)).  With every trainable conv of a ResNet
+// stage in one launch there are thousands of tiles, so a job needs no (or few) splits: no atomics, no accumulator
+// memset, no separate finalize pass - and no per-layer tail where 256 CUs wait on the slowest workgroup.
+template <typename T, int NSTG, bool PW>
+__global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_batch_kernel(const WgradParams* __restrict__ jobs, int n_jobs) {
+  const int w = blockIdx.x;
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first <= w) lo = mid;
+    else hi = mid - 1;
+  }
+  const WgradParams p = jobs[lo];
+  int local = w - p.first;
+  const int bx = local % p.tn;
+  local /= p.tn;
+  const int by = local % p.tk;
+  wgrad_body<T, NSTG, PW>(p, bx, by, local / p.tk);
 }
 
 static int validate(const td_conv_desc* d, int dtype, const char* who) {
@@ -793,49 +849,77 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   return check_launch("td_conv_gemm");
 }
 
-extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td_conv_desc* d, int ldg, int dtype,
-                             int splits, td_stream_t stream) {
-  TD_REQUIRE(g && src && dw && d, "td_conv_wgrad: null pointer");
-  int rc = validate(d, dtype, "td_conv_wgrad");
+static int wgrad_stages() {
+  static const int nstg = [] { const char* e = getenv("TD_WGRAD_STAGES"); return (e && atoi(e) == 2) ? 2 : 4; }();
+  return nstg;
+}
+
+// fills everything of p except the output fields; returns the split count through *splits_io
+static int wgrad_fill(WgradParams& p, const void* g, const void* src, const td_conv_desc* d, int ldg, int dtype, int* splits_io,
+                      int auto_mode, const char* who) {
+  int rc = validate(d, dtype, who);
   if (rc) return rc;
   const int vec = dtype == TD_BF16 ? 8 : 4;
-  TD_REQUIRE(d->mode == 0, "td_conv_wgrad: forward geometry expected");
-  TD_REQUIRE(d->Nc % vec == 0 && ldg % vec == 0, "td_conv_wgrad: Nc=%d / ldg=%d must be multiples of %d", d->Nc, ldg, vec);
-  WgradParams p;
+  TD_REQUIRE(d->mode == 0, "%s: forward geometry expected", who);
+  TD_REQUIRE(d->Nc % vec == 0 && ldg % vec == 0, "%s: Nc=%d / ldg=%d must be multiples of %d", who, d->Nc, ldg, vec);
+  memset(&p, 0, sizeof(p));
   p.g = (const char*)g;
   p.src = (const char*)src;
-  p.dw = dw;
   p.d = *d;
   p.M = d->N * d->Ho * d->Wo;
   p.K = d->R * d->S * d->C;
   p.ldg = ldg;
-  { static const int dbg = [] { const char* e = getenv("TD_WGRAD_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
-  p.stamps = g_dbg;
+  p.ci_real = d->C;
+  {
+    static const int dbg = [] { const char* e = getenv("TD_WGRAD_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
+  }
   {
     const double es = dtype == TD_BF16 ? 2.0 : 4.0;
     const double gb = (double)p.M * ldg * es, sb = (double)d->N * d->Hs * d->Ws * d->C * es;
-    TD_REQUIRE(gb < 4294967000.0 && sb < 4294967000.0, "td_conv_wgrad: operand exceeds the 4 GiB buffer-descriptor range");
+    TD_REQUIRE(gb < 4294967000.0 && sb < 4294967000.0, "%s: operand exceeds the 4 GiB buffer-descriptor range", who);
     p.g_bytes = (uint32_t)gb;
     p.src_bytes = (uint32_t)sb;
   }
   const int mk = dtype == TD_BF16 ? 64 : 32;
-  static const int nstg = [] { const char* e = getenv("TD_WGRAD_STAGES"); return (e && atoi(e) == 2) ? 2 : 4; }();
+  p.tn = cdiv(d->Nc, 128);
+  p.tk = cdiv(p.K, 128);
+  int splits = *splits_io;
   if (splits < 1) {
-    // about one workgroup per CU (TD_WGRAD_BLOCKS, default 256), at least 8 reduction stages (512 / 256 rows) per split
-    static const int target_blocks = [] { const char* e = getenv("TD_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();  // measured: 192-256 workgroups beat 512-1536 (fewer fp32 atomics per output tile)
-    int tiles = cdiv(d->Nc, 128) * cdiv(p.K, 128);
-    splits = nstg == 4 ? target_blocks / tiles : cdiv(target_blocks, tiles);  // 4 stages: one workgroup per CU, never a second round
-    int maxs = cdiv(p.M, 8 * mk);
-    if (splits > maxs) splits = maxs;
+    if (auto_mode == 0) {
+      // single launch: about one workgroup per CU (TD_WGRAD_BLOCKS, default 256), at least 8 reduction stages per split.
+      // measured: 192-256 workgroups beat 512-1536 (fewer fp32 atomics per output tile)
+      static const int target_blocks = [] { const char* e = getenv("TD_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
+      const int tiles = p.tn * p.tk;
+      splits = wgrad_stages() == 4 ? target_blocks / tiles : cdiv(target_blocks, tiles);  // 4 stages: one workgroup per CU, never a second round
+      const int maxs = cdiv(p.M, 8 * mk);
+      if (splits > maxs) splits = maxs;
+    } else {
+      // batched launch: the tiles of all jobs fill the chip; split only to bound the longest work item (192 stages)
+      splits = cdiv(p.M, 192 * mk);
+    }
     if (splits < 1) splits = 1;
   }
   p.mper = cdiv(cdiv(p.M, splits), mk) * mk;
-  splits = cdiv(p.M, p.mper);
-  dim3 grid(cdiv(d->Nc, 128), cdiv(p.K, 128), splits);
+  *splits_io = cdiv(p.M, p.mper);
+  return TD_OK;
+}
+
+extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td_conv_desc* d, int ldg, int dtype,
+                             int splits, td_stream_t stream) {
+  TD_REQUIRE(g && src && dw && d, "td_conv_wgrad: null pointer");
+  WgradParams p;
+  int rc = wgrad_fill(p, g, src, d, ldg, dtype, &splits, 0, "td_conv_wgrad");
+  if (rc) return rc;
+  p.dw = dw;
+  p.out_mode = 0;
+  p.stamps = g_dbg;
+  dim3 grid(p.tn, p.tk, splits);
   hipStream_t st = (hipStream_t)stream;
   const bool prof = prof_on();
   if (prof) prof_begin(TD_PROF_WGRAD, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, splits);
   const bool pw = (d->R * d->S == 1) && d->stride == 1 && d->pad == 0;
+  const int nstg = wgrad_stages();
 #define TD_WG_LAUNCH(TT, NS)                                                    \
   do {                                                                          \
     if (pw) conv_wgrad_kernel<TT, NS, true><<<grid, 256, 0, st>>>(p);           \
@@ -851,4 +935,150 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
 #undef TD_WG_LAUNCH
   if (prof) prof_end(st);
   return check_launch("td_conv_wgrad");
+}
+
+// ---- batched weight gradients ----
+namespace {
+struct JobUpload {  // pinned staging + device copy of one batch's job table
+  WgradParams* host = nullptr;
+  WgradParams* dev = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;
+  bool busy = false;
+};
+constexpr int kUploadRing = 8;
+JobUpload g_ring[kUploadRing];
+int g_ring_next = 0;
+
+// Buffers for job tables uploaded inside a stream capture: the captured copy node re-reads its pinned source on every
+// replay, so such a table gets a buffer pair nobody ever reuses.  Allocation is illegal while capturing, hence the
+// spares are created by the eager calls that precede any capture (a framework warms up before it captures).
+std::vector<JobUpload> g_spares;
+
+bool alloc_upload(JobUpload& u, size_t n) {
+  u.cap = std::max<size_t>(n, 256);
+  return hipHostMalloc((void**)&u.host, u.cap * sizeof(WgradParams), hipHostMallocDefault) == hipSuccess &&
+         hipMalloc((void**)&u.dev, u.cap * sizeof(WgradParams)) == hipSuccess;
+}
+
+int upload_jobs(const std::vector<WgradParams>& jobs, hipStream_t st, const WgradParams** dev_out) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  JobUpload local;
+  JobUpload* u;
+  if (capturing) {
+    size_t k = 0;
+    while (k < g_spares.size() && g_spares[k].cap < jobs.size()) ++k;
+    if (k == g_spares.size()) {
+      set_error("td_conv_wgrad_batch: no pre-allocated job table for a stream capture (run one step eagerly before capturing)");
+      return TD_ERR_INVALID;
+    }
+    local = g_spares[k];
+    g_spares.erase(g_spares.begin() + k);
+    u = &local;
+  } else {
+    u = &g_ring[g_ring_next];
+    g_ring_next = (g_ring_next + 1) % kUploadRing;
+    if (u->busy) {
+      (void)hipEventSynchronize(u->done);  // eight batches ago: long finished unless the host runs far ahead
+      u->busy = false;
+    }
+    if (u->cap < jobs.size()) {
+      if (u->host) (void)hipHostFree(u->host);
+      if (u->dev) (void)hipFree(u->dev);
+      if (!alloc_upload(*u, jobs.size())) {
+        set_error("td_conv_wgrad_batch: job table allocation failed");
+        return TD_ERR_LAUNCH;
+      }
+    }
+    while (g_spares.size() < 8) {
+      JobUpload sp;
+      if (!alloc_upload(sp, jobs.size())) break;
+      g_spares.push_back(sp);
+    }
+  }
+  memcpy(u->host, jobs.data(), jobs.size() * sizeof(WgradParams));
+  if (hipMemcpyAsync(u->dev, u->host, jobs.size() * sizeof(WgradParams), hipMemcpyHostToDevice, st) != hipSuccess) {
+    set_error("td_conv_wgrad_batch: job table upload failed");
+    return TD_ERR_LAUNCH;
+  }
+  if (!capturing) {
+    if (!u->done) (void)hipEventCreateWithFlags(&u->done, hipEventDisableTiming);
+    (void)hipEventRecord(u->done, st);
+    u->busy = true;
+  }
+  *dev_out = u->dev;
+  return TD_OK;
+}
+}  // namespace
+
+extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, td_stream_t stream) {
+  TD_REQUIRE(jobs && n_jobs >= 1, "td_conv_wgrad_batch: no jobs");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<WgradParams> tab[2];  // [0] general geometry, [1] pointwise
+  double flops = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const td_wgrad_job& j = jobs[i];
+    TD_REQUIRE(j.g && j.src && j.dW, "td_conv_wgrad_batch: job %d has a null pointer", i);
+    WgradParams p;
+    int splits = 0;
+    int rc = wgrad_fill(p, j.g, j.src, &j.d, j.ldg, dtype, &splits, 1, "td_conv_wgrad_batch");
+    if (rc) return rc;
+    TD_REQUIRE(j.ci_real >= 1 && j.ci_real <= j.d.C, "td_conv_wgrad_batch: job %d: ci_real=%d out of range", i, j.ci_real);
+    p.dw = j.dW;
+    p.scale = j.scale;
+    p.ci_real = j.ci_real;
+    p.out_mode = splits == 1 ? 2 : 1;
+    p.first = splits;  // (temporarily: the split count, replaced by the first workgroup index below)
+    if (splits > 1 &&
+        hipMemsetAsync(j.dW, 0, (size_t)j.d.Nc * j.ci_real * j.d.R * j.d.S * sizeof(float), st) != hipSuccess) {
+      set_error("td_conv_wgrad_batch: memset failed");
+      return TD_ERR_LAUNCH;
+    }
+    const bool pw = (j.d.R * j.d.S == 1) && j.d.stride == 1 && j.d.pad == 0;
+    tab[pw ? 1 : 0].push_back(p);
+    flops += 2.0 * p.M * j.d.Nc * p.K;
+  }
+  const bool prof = prof_on();
+  if (prof) prof_begin(TD_PROF_WGRAD, dtype, flops, st, 0, 0, 0, 0, 0, n_jobs);
+  const int nstg = wgrad_stages();
+  for (int pw = 0; pw < 2; ++pw) {
+    std::vector<WgradParams>& t = tab[pw];
+    if (t.empty()) continue;
+    // longest work items first: the tail of the launch is then made of short ones
+    std::stable_sort(t.begin(), t.end(), [](const WgradParams& a, const WgradParams& b) {
+      return (double)a.mper * a.d.R * a.d.S > (double)b.mper * b.d.R * b.d.S;
+    });
+    long long total = 0;
+    for (auto& p : t) {
+      const int splits = p.first;
+      p.first = (int)total;
+      p.stamps = g_dbg;
+      total += (long long)p.tn * p.tk * splits;
+    }
+    TD_REQUIRE(total < 2147483647LL, "td_conv_wgrad_batch: too many work items");
+    const WgradParams* dev = nullptr;
+    int rc = upload_jobs(t, st, &dev);
+    if (rc) return rc;
+    const int n = (int)t.size();
+    const unsigned grid = (unsigned)total;
+#define TD_WGB_LAUNCH(TT, NS)                                                                \
+  do {                                                                                       \
+    if (pw) conv_wgrad_batch_kernel<TT, NS, true><<<grid, 256, 0, st>>>(dev, n);             \
+    else conv_wgrad_batch_kernel<TT, NS, false><<<grid, 256, 0, st>>>(dev, n);               \
+  } while (0)
+    if (nstg == 4) {
+      if (dtype == TD_BF16) TD_WGB_LAUNCH(u16, 4);
+      else TD_WGB_LAUNCH(float, 4);
+    } else {
+      if (dtype == TD_BF16) TD_WGB_LAUNCH(u16, 2);
+      else TD_WGB_LAUNCH(float, 2);
+    }
+#undef TD_WGB_LAUNCH
+    rc = check_launch("td_conv_wgrad_batch");
+    if (rc) return rc;
+  }
+  if (prof) prof_end(st);
+  return TD_OK;
 }

@@ -196,8 +196,29 @@ static size_t grad_slot_bytes(const Plan& P, int N, int first_stage) {
   return m;
 }
 
+// batched weight gradients (default): every gradient activation stays alive until the single td_conv_wgrad_batch launch
+// at the end of the pass, so they are bump-allocated instead of cycling through the ring
+static bool wgrad_batched() {
+  static const bool on = [] { const char* e = getenv("TD_WGRAD_BATCH"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static size_t all_grad_bytes(const Plan& P, int N, int first_stage) {
+  size_t tot = 0;
+  bool top = true;
+  for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
+    const BlockPlan& b = P.blocks[bi];
+    if (b.stage < first_stage) break;
+    auto sz = [&](const Tens& t) { return align256((size_t)N * t.H * t.W * t.C * P.es); };
+    if (top) tot += sz(b.out);
+    top = false;
+    tot += sz(b.h2) + sz(b.h1) + sz(b.in);
+  }
+  return tot;
+}
+
 extern "C" size_t td_resnet_bwd_ws_bytes(int N, int H, int W, const int* nblocks, int first_train_stage, int dtype) {
   Plan P = make_plan(N, H, W, nblocks, dtype, 1);  // (only tensor shapes matter here, not offsets)
+  if (wgrad_batched()) return all_grad_bytes(P, N, first_train_stage);
   return dwk_bytes(P, first_train_stage, nullptr) + 6 * grad_slot_bytes(P, N, first_train_stage);
 }
 
@@ -212,10 +233,13 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
   std::vector<size_t> dwoff;
   const size_t dwb = dwk_bytes(P, first_train_stage, &dwoff);
   const size_t slot = grad_slot_bytes(P, N, first_train_stage);
-  TD_REQUIRE(ws_bytes >= dwb + 6 * slot, "td_resnet_bwd: workspace too small");
+  const bool batched = wgrad_batched();
+  TD_REQUIRE(ws_bytes >= (batched ? all_grad_bytes(P, N, first_train_stage) : dwb + 6 * slot), "td_resnet_bwd: workspace too small");
   const char* acts = (const char*)fwd_ws;
   char* base = (char*)ws;
-  char* ring = base + dwb;
+  char* ring = batched ? base : base + dwb;
+  size_t bump = 0;
+  std::vector<td_wgrad_job> jobs;
   hipStream_t st = (hipStream_t)stream;
   // Weight gradients do not feed the dgrad chain: they (and their finalize kernels) run on an internal second stream,
   // concurrently with the next layers' dgrad GEMMs - two latency-bound kernel families sharing the chip.  Fork/join
@@ -241,7 +265,12 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
   };
   hipEvent_t slot_busy[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // last side-stream reader of a ring slot
   int rix = 0;
-  auto galloc = [&]() {
+  auto galloc = [&](const Tens& t) {
+    if (batched) {
+      char* q = base + bump;
+      bump += align256((size_t)N * t.H * t.W * t.C * P.es);
+      return q;
+    }
     const int s_ = rix++ % 6;
     if (wst != st && slot_busy[s_]) {
       hipStreamWaitEvent(st, slot_busy[s_], 0);  // do not overwrite a gradient a pending wgrad still reads
@@ -250,7 +279,7 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     return ring + (size_t)s_ * slot;
   };
   auto slot_of = [&](const void* g) { return (int)(((const char*)g - ring) / slot); };
-  if (hipMemsetAsync(base, 0, dwb, st) != hipSuccess) {
+  if (!batched && hipMemsetAsync(base, 0, dwb, st) != hipSuccess) {
     set_error("td_resnet_bwd: memset failed");
     return TD_ERR_LAUNCH;
   }
@@ -258,6 +287,18 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
   auto wgrad = [&](const void* g, const Tens& gt, const Tens& xin, int ci) -> int {
     const ConvSpec& c = P.convs[ci];
     td_conv_desc d = {N, xin.H, xin.W, xin.C, gt.H, gt.W, c.k, c.k, c.stride, c.pad, 0, c.cout, c.cout, 1, 0, 0};
+    if (batched) {
+      td_wgrad_job j;
+      j.g = g;
+      j.src = acts + xin.off;
+      j.dW = dW[ci];
+      j.scale = scale[ci];
+      j.d = d;
+      j.ldg = c.cout;
+      j.ci_real = c.cin;
+      jobs.push_back(j);
+      return TD_OK;
+    }
     float* dwk = (float*)(base + dwoff[ci]);
     if (wst != st) {  // g (and the memset) were produced on the caller's stream
       hipEvent_t ready = next_event();
@@ -296,21 +337,21 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
   while (first <= last && P.blocks[first].stage < first_train_stage) ++first;
   if (first > last) return TD_OK;
   const Tens& fo = P.blocks[last].out;
-  char* g_out = galloc();
+  char* g_out = galloc(fo);
   if ((rc = td_relu_bwd(dfeat, acts + fo.off, g_out, (size_t)N * fo.H * fo.W * fo.C, 1.f, dtype, stream))) return rc;
   for (int bi = last; bi >= first; --bi) {
     const BlockPlan& b = P.blocks[bi];
     const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
     if ((rc = wgrad(g_out, b.out, b.h2, c3))) return rc;
-    char* g_h2 = galloc();
+    char* g_h2 = galloc(b.h2);
     if ((rc = dgrad(g_out, b.out, b.h2, c3, nullptr, acts + b.h2.off, g_h2))) return rc;
     if ((rc = wgrad(g_h2, b.h2, b.h1, c2))) return rc;
-    char* g_h1 = galloc();
+    char* g_h1 = galloc(b.h1);
     if ((rc = dgrad(g_h2, b.h2, b.h1, c2, nullptr, acts + b.h1.off, g_h1))) return rc;
     if ((rc = wgrad(g_h1, b.h1, b.in, c1))) return rc;
     if (cd >= 0 && (rc = wgrad(g_out, b.out, b.in, cd))) return rc;
     if (bi == first) break;  // the first trainable block's input comes from frozen layers
-    char* dx = galloc();
+    char* dx = galloc(b.in);
     const void* xin = acts + b.in.off;
     if (cd >= 0) {
       if ((rc = dgrad(g_h1, b.h1, b.in, c1, nullptr, xin, dx))) return rc;
@@ -331,5 +372,6 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     g_out = dx;
   }
   join();
+  if (batched && !jobs.empty()) return td_conv_wgrad_batch(jobs.data(), (int)jobs.size(), dtype, stream);
   return TD_OK;
 }

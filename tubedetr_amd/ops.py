@@ -127,6 +127,26 @@ def conv_wgrad(g: Tensor, x: Tensor, R: int, S: int, stride: int, pad: int, *, o
     return dw
 
 
+def conv_wgrad_batch(jobs) -> list:
+    """jobs: iterable of (g NHWC [N,Ho,Wo,Co], x NHWC [N,H,W,C], R, S, stride, pad, scale [Co] fp32 | None, ci_real).
+    One launch (two when pointwise and spatial kernels are mixed); returns dW per job in the parameter layout
+    [Co, ci_real, R, S] fp32 with `scale` folded in."""
+    jobs = list(jobs)
+    arr = (_hip.WgradJob * len(jobs))()
+    outs = []
+    for a, (g, x, R, S, stride, pad, scale, ci_real) in zip(arr, jobs):
+        N, H, W, Cs = x.shape
+        _, Ho, Wo, Co = g.shape
+        assert g.is_contiguous() and x.is_contiguous() and g.dtype == x.dtype
+        dw = torch.empty((Co, ci_real, R, S), dtype=torch.float32, device=x.device)
+        outs.append(dw)
+        a.g, a.src, a.dW, a.scale = g.data_ptr(), x.data_ptr(), dw.data_ptr(), (scale.data_ptr() if scale is not None else None)
+        a.d = _desc(N, H, W, Cs, Ho, Wo, R, S, stride, pad, 0, Co, Co)
+        a.ldg, a.ci_real = Co, ci_real
+    check(_hip.lib().td_conv_wgrad_batch(arr, len(jobs), dtype_code(jobs[0][0].dtype), stream_ptr()), "td_conv_wgrad_batch")
+    return outs
+
+
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, residual=None, relu=False, sigmoid=False,
                mask_src=None, dropout_p=0.0, seed=0, alpha=1.0, out: Optional[Tensor] = None) -> Tensor:
     """x [M,K], w [N,K] (K contiguous)  ->  [M,N] = epilogue(alpha * x @ w^T + bias + residual)."""
