@@ -501,7 +501,7 @@ __device__ __forceinline__ int wg_swz(int row) {
 // LDS, one workgroup per CU), three in flight behind counted s_waitcnt vmcnt - the launch has about one workgroup per
 // CU anyway (fp32 atomics per output tile limit the split count), so bytes in flight per CU are what is left to raise.
 template <typename T, int NSTG, bool PW>
-__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int bz, const int lin) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;
   constexpr int MK = 128 / ES;             // reduction rows per stage: 64 (bf16) / 32 (fp32)
@@ -656,7 +656,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
   };
 
   const int nit = (mend - mbeg + MK - 1) / MK;
-  unsigned long long* stp = p.stamps ? p.stamps + (size_t)(p.first + bx + p.tn * (by + p.tk * bz)) * 40 : nullptr;
+  unsigned long long* stp = p.stamps ? p.stamps + (size_t)lin * 40 : nullptr;
 #define TD_WSTAMP(i) do { if (stp && t == 0) stp[i] = __builtin_readcyclecounter(); } while (0)
   if (stp && t == 0) stp[0] = t_start;
   TD_WSTAMP(1);
@@ -737,28 +737,37 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 
 template <typename T, int NSTG, bool PW>
 __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
-  wgrad_body<T, NSTG, PW>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+  wgrad_body<T, NSTG, PW>(p, blockIdx.x, blockIdx.y, blockIdx.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
-// Batched form: one launch covers the weight gradients of many layers (jobs sorted by first workgroup index; a
-// workgroup finds its job by binary search, then its (co tile, k tile, split)).  With every trainable conv of a ResNet
-// stage in one launch there are thousands of tiles, so a job needs no (or few) splits: no atomics, no accumulator
-// memset, no separate finalize pass - and no per-layer tail where 256 CUs wait on the slowest workgroup.
+// Batched form: one launch covers the weight gradients of many layers.  With every trainable conv of the trunk in one
+// launch there are thousands of tiles, so a job needs no (or few) splits: no atomics, no accumulator memset, no separate
+// finalize pass - and no per-layer tail where 256 CUs wait on the slowest workgroup.
+// Workgroup w runs on XCD w % 8 (round-robin dispatch): each job is owned by ONE XCD (host-side longest-first
+// balancing), so the 32 CUs that share an L2 stream the same gradient / activation rows at about the same time and every
+// operand row is fetched into that L2 once instead of once per tile.  Within its XCD a workgroup finds its job by
+// binary search over the job's first slot.
+struct WgradXcdIndex {
+  int start[9];  // job table range of XCD x: [start[x], start[x+1])
+  int slots[8];  // work items of XCD x
+};
+
 template <typename T, int NSTG, bool PW>
-__global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_batch_kernel(const WgradParams* __restrict__ jobs, int n_jobs) {
-  const int w = blockIdx.x;
-  int lo = 0, hi = n_jobs - 1;
+__global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_batch_kernel(const WgradParams* __restrict__ jobs, WgradXcdIndex xi) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  if (slot >= xi.slots[xcd]) return;
+  int lo = xi.start[xcd], hi = xi.start[xcd + 1] - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].first <= w) lo = mid;
+    if (jobs[mid].first <= slot) lo = mid;
     else hi = mid - 1;
   }
   const WgradParams p = jobs[lo];
-  int local = w - p.first;
+  int local = slot - p.first;
   const int bx = local % p.tn;
   local /= p.tn;
   const int by = local % p.tk;
-  wgrad_body<T, NSTG, PW>(p, bx, by, local / p.tk);
+  wgrad_body<T, NSTG, PW>(p, bx, by, local / p.tk, blockIdx.x);
 }
 
 static int validate(const td_conv_desc* d, int dtype, const char* who) {
@@ -1046,27 +1055,58 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
   for (int pw = 0; pw < 2; ++pw) {
     std::vector<WgradParams>& t = tab[pw];
     if (t.empty()) continue;
-    // longest work items first: the tail of the launch is then made of short ones
-    std::stable_sort(t.begin(), t.end(), [](const WgradParams& a, const WgradParams& b) {
-      return (double)a.mper * a.d.R * a.d.S > (double)b.mper * b.d.R * b.d.S;
-    });
-    long long total = 0;
-    for (auto& p : t) {
-      const int splits = p.first;
-      p.first = (int)total;
-      p.stamps = g_dbg;
-      total += (long long)p.tn * p.tk * splits;
+    // one XCD per job, longest job first onto the least loaded XCD; inside an XCD the long work items come first so
+    // that the tail of the launch is made of short ones
+    const int nj = (int)t.size();
+    std::vector<int> order(nj), owner(nj);
+    std::vector<double> cost(nj);
+    for (int i = 0; i < nj; ++i) {
+      order[i] = i;
+      cost[i] = (double)t[i].tn * t[i].tk * t[i].first /*splits*/ * (double)t[i].mper * (pw ? 1.0 : 1.5);
     }
-    TD_REQUIRE(total < 2147483647LL, "td_conv_wgrad_batch: too many work items");
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i : order) {
+      int best = 0;
+      for (int x = 1; x < 8; ++x)
+        if (load[x] < load[best]) best = x;
+      owner[i] = best;
+      load[best] += cost[i];
+    }
+    std::vector<WgradParams> sorted;
+    sorted.reserve(nj);
+    WgradXcdIndex xi;
+    long long max_slots = 0;
+    for (int x = 0; x < 8; ++x) {
+      xi.start[x] = (int)sorted.size();
+      std::vector<int> mine;
+      for (int i = 0; i < nj; ++i)
+        if (owner[i] == x) mine.push_back(i);
+      std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) {
+        return (double)t[a].mper * t[a].d.R * t[a].d.S > (double)t[b].mper * t[b].d.R * t[b].d.S;
+      });
+      long long slots = 0;
+      for (int i : mine) {
+        WgradParams p = t[i];
+        const int splits = p.first;
+        p.first = (int)slots;
+        p.stamps = g_dbg;
+        slots += (long long)p.tn * p.tk * splits;
+        sorted.push_back(p);
+      }
+      TD_REQUIRE(slots < 200000000LL, "td_conv_wgrad_batch: too many work items");
+      xi.slots[x] = (int)slots;
+      max_slots = std::max(max_slots, slots);
+    }
+    xi.start[8] = (int)sorted.size();
     const WgradParams* dev = nullptr;
-    int rc = upload_jobs(t, st, &dev);
+    int rc = upload_jobs(sorted, st, &dev);
     if (rc) return rc;
-    const int n = (int)t.size();
-    const unsigned grid = (unsigned)total;
+    const unsigned grid = (unsigned)(8 * max_slots);
 #define TD_WGB_LAUNCH(TT, NS)                                                                \
   do {                                                                                       \
-    if (pw) conv_wgrad_batch_kernel<TT, NS, true><<<grid, 256, 0, st>>>(dev, n);             \
-    else conv_wgrad_batch_kernel<TT, NS, false><<<grid, 256, 0, st>>>(dev, n);               \
+    if (pw) conv_wgrad_batch_kernel<TT, NS, true><<<grid, 256, 0, st>>>(dev, xi);            \
+    else conv_wgrad_batch_kernel<TT, NS, false><<<grid, 256, 0, st>>>(dev, xi);              \
   } while (0)
     if (nstg == 4) {
       if (dtype == TD_BF16) TD_WGB_LAUNCH(u16, 4);
