@@ -38,6 +38,7 @@ WORKLOADS = {
     "cfg2": (64, 224, 2, 20),
     "cfg1": (8, 224, 5, 20),
 }
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 # algorithmic GFLOP per clip fwd+bwd
 ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
@@ -285,17 +286,45 @@ def main():
             tname = "unsigned short" if cdt == torch.bfloat16 else "float"
             peak = PEAK_BF16_TFLOPS if cdt == torch.bfloat16 else 157.3
             fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128, 2, *>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128, 2, *>",
-                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, 2, *>", 2: f"td::conv_wgrad_kernel<{tname}>"}  # * = both pointwise / generic instances
+                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, 2, *>", 2: f"td::conv_wgrad_kernel|conv_wgrad_batch_kernel<{tname}>"}  # * = both pointwise / generic instances
+            # PMC-measured HBM traffic per launch of the same command (tools/pmc_traffic.py, committed under profiles/):
+            # counters cannot be read from inside the process being timed
+            pmc = {}
+            try:
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+            except Exception:
+                pass
+            # an (event, event) pair around nothing: what the bracketing itself adds to every launch; subtracted below so
+            # that the averages can be compared with rocprofv3's kernel durations (profiles/)
+            cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+            for e0_, e1_ in cal:
+                e0_.record()
+                e1_.record()
+            torch.cuda.synchronize()
+            ev_over_ms = sorted(e0_.elapsed_time(e1_) for e0_, e1_ in cal)[len(cal) // 2]
             per = []
             for fam, kname in fams.items():
-                n, ms, fl = C.c_longlong(), C.c_double(), C.c_double()
+                n, ms, fl, by = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
                 _hip.check(L_.td_prof_collect(fam, code, C.byref(n), C.byref(ms), C.byref(fl)), "td_prof_collect")
+                _hip.check(L_.td_prof_collect_bytes(fam, code, C.byref(by)), "td_prof_collect_bytes")
                 if n.value:
-                    ach = fl.value / (ms.value * 1e-3) / 1e12
-                    per.append({"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n.value // a.roofline_steps,
-                                "avg_launch_us": round(ms.value * 1e3 / n.value, 2), "kernel_ms_per_step": round(ms.value / a.roofline_steps, 3),
-                                "algorithmic_gflop_per_step": round(fl.value / a.roofline_steps / 1e9, 1)})
+                    ms.value = max(ms.value - n.value * ev_over_ms, 0.5 * ms.value)
+                    tfl = fl.value / (ms.value * 1e-3) / 1e12
+                    gbs = by.value / (ms.value * 1e-3) / 1e9
+                    hbm_bound = gbs / PEAK_HBM_GBS > tfl / peak  # the roof this family sits closer to
+                    t_ = pmc.get(kname if fam != 2 else "td::conv_wgrad_batch_kernel<%s>" % tname)
+                    traffic = (t_["fetch_bytes_per_launch"] + t_["write_bytes_per_launch"]) if (t_ and t_.get("fetch_bytes_per_launch") and t_.get("write_bytes_per_launch")) else None
+                    rec = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
+                           "achieved": round(gbs if hbm_bound else tfl, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
+                           "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tfl / peak), 4),
+                           "traffic": traffic if fam != 2 else None,
+                           "traffic_note": ("HBM bytes per launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE averaged over the family's launches "
+                                            "(profiles/r01_pmc_traffic.json)") if (traffic and fam != 2) else None,
+                           "algorithmic_bytes_per_launch": round(by.value / n.value), "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfl, 2),
+                           "launches_per_step": n.value // a.roofline_steps, "event_pair_overhead_us_subtracted": round(ev_over_ms * 1e3, 2),
+                           "avg_launch_us": round(ms.value * 1e3 / n.value, 2), "kernel_ms_per_step": round(ms.value / a.roofline_steps, 3),
+                           "algorithmic_gflop_per_step": round(fl.value / a.roofline_steps / 1e9, 1)}
+                    per.append(rec)
             L_.td_prof_enable(0)
             if per:
                 per.sort(key=lambda r: -r["kernel_ms_per_step"])

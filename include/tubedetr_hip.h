@@ -48,6 +48,8 @@ int td_set_dropout_step_counter(const uint32_t* dev_counter);
 #define TD_PROF_FAMILIES 4
 int td_prof_enable(int on);
 int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
+/* Sum of the ALGORITHMIC HBM bytes of the same launches (each operand / result tensor counted once per launch). */
+int td_prof_collect_bytes(int family, int dtype, double* bytes);
 /* CSV (family,dtype,M,N,K,R,stride,mode|splits,ms) of every recorded launch since td_prof_enable(1). */
 int td_prof_dump(const char* path);
 /* Debug: when non-NULL, td_conv_gemm workgroups write 6 cycle stamps each into buf[workgroup*8 + i]. */

@@ -1,0 +1,52 @@
+"""Per-kernel-family HBM traffic from rocprofv3 PMC passes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and
+WRITE_SIZE cannot share a pass; on gfx950 FETCH_SIZE counts a 16-byte/lane streaming read at half its bytes -> x2;
+both are in KiB).  Input: the two per-kernel aggregates written by the collection command in profiles/README.md
+(kernel,counter,dispatches,sum).  Output: profiles/<round>_pmc_traffic.json, read by bench.py for `roofline.traffic`.
+
+usage: python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE.csv gpurun_out/pmc_WRITE_SIZE.csv profiles/r01_pmc_traffic.json"""
+import csv, json, re, sys
+
+
+def family(name):
+    m = re.search(r"td::conv_gemm_kernel<([^,]+), (\d+), (\d+), (\d+), (true|false)>", name)
+    if m:
+        return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, *>"
+    m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)
+    if m:
+        return f"td::{m.group(1)}<{m.group(2)}>"
+    m = re.search(r"(?<![a-z_])(td::[a-z0-9_]+)", name)
+    return m.group(1) if m else None
+
+
+def load(path):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        f = family(r["kernel"])
+        if f is None:
+            continue
+        a = out.setdefault(f, [0, 0.0])
+        a[0] += int(r["dispatches"])
+        a[1] += float(r["sum"])
+    return out
+
+
+def main():
+    fetch, write, dst = sys.argv[1:4]
+    F, W = load(fetch), load(write)
+    res = {"_doc": "bytes per launch = counter sum (KiB) * 1024 / dispatches; fetch doubled (gfx950 16-B/lane streaming-read correction); "
+                   "Infinity-Cache hits are counted by these memory-side counters",
+           "_command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --no-graph --steps 1 --warmup 1 --cpu-frames 0 --roofline-steps 0"}
+    for f in sorted(set(F) | set(W)):
+        nf, sf = F.get(f, [0, 0.0])
+        nw, sw = W.get(f, [0, 0.0])
+        res[f] = {"dispatches": nf or nw,
+                  "fetch_bytes_per_launch": round(sf * 1024 * 2 / nf) if nf else None,
+                  "write_bytes_per_launch": round(sw * 1024 / nw) if nw else None}
+    json.dump(res, open(dst, "w"), indent=1)
+    for f, v in res.items():
+        if isinstance(v, dict) and v["fetch_bytes_per_launch"]:
+            print(f"{f:70s} n={v['dispatches']:5d} fetch {v['fetch_bytes_per_launch']/1e6:9.2f} MB  write {(v['write_bytes_per_launch'] or 0)/1e6:9.2f} MB per launch")
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,7 @@ _SIGS = {
     "td_prof_dump": [C.c_char_p],
     "td_debug_set_stamp_buffer": [_P],
     "td_prof_collect": [_I, _I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "td_prof_collect_bytes": [_I, _I, C.POINTER(C.c_double)],
     "td_conv_gemm": [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P],
     "td_conv_wgrad": [_P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
     "td_conv_wgrad_batch": [C.POINTER(WgradJob), _I, _I, _P],

@@ -29,7 +29,7 @@ static const uint32_t* g_drop_ctr = nullptr;
 const uint32_t* dropout_counter() { return g_drop_ctr; }
 
 // ---- launch timing for bench.py's roofline leg ----
-struct ProfRec { int family, dtype; double flops; hipEvent_t a, b; int M, N, K, R, stride, mode; };
+struct ProfRec { int family, dtype; double flops; hipEvent_t a, b; int M, N, K, R, stride, mode; double bytes = 0; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -44,6 +44,7 @@ void prof_begin(int family, int dtype, double flops, hipStream_t st, int M, int 
   g_recs.push_back(r);
 }
 void prof_end(hipStream_t st) { hipEventRecord(g_recs.back().b, st); }
+void prof_set_bytes(double bytes) { if (!g_recs.empty()) g_recs.back().bytes = bytes; }
 
 }  // namespace td
 
@@ -72,6 +73,14 @@ extern "C" int td_prof_collect(int family, int dtype, long long* launches, doubl
   if (launches) *launches = n;
   if (ms) *ms = t;
   if (flops) *flops = f;
+  return TD_OK;
+}
+
+extern "C" int td_prof_collect_bytes(int family, int dtype, double* bytes) {
+  double b = 0;
+  for (auto& r : td::g_recs)
+    if (r.family == family && r.dtype == dtype) b += r.bytes;
+  if (bytes) *bytes = b;
   return TD_OK;
 }
 

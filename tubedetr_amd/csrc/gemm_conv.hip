@@ -838,6 +838,15 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   dim3 grid(8 * cdiv(MT, 8) * NTl);
   const bool prof = prof_on();
   if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : (small_m ? TD_PROF_GEMM_64x128 : TD_PROF_GEMM_128x128), dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
+  if (prof) {
+    // algorithmic HBM bytes: every operand / result tensor once (the gathered source counted as the tensor it is read from)
+    const double es = dtype == TD_BF16 ? 2.0 : 4.0;
+    const double rows_out = d->out_sp > 1 ? (double)d->N * d->out_H * d->out_W : (double)p.M;
+    double by = ((double)d->N * d->Hs * d->Ws * d->C + (double)d->Nc * p.K + (double)p.M * d->Nc) * es;
+    if (e && e->residual) by += rows_out * d->Nc * es;
+    if (e && e->mask_src) by += rows_out * d->Nc * es;
+    prof_set_bytes(by);
+  }
   const bool pw = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && p.d.out_sp == 1 && d->Hs == d->Ho && d->Ws == d->Wo;
 #define TD_LAUNCH(TT, BMv, BNv)                                                                   \
   do {                                                                                            \
@@ -927,6 +936,7 @@ extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td
   hipStream_t st = (hipStream_t)stream;
   const bool prof = prof_on();
   if (prof) prof_begin(TD_PROF_WGRAD, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, splits);
+  if (prof) prof_set_bytes(((double)p.M * ldg + (double)d->N * d->Hs * d->Ws * d->C) * (dtype == TD_BF16 ? 2.0 : 4.0) + (double)d->Nc * p.K * 4.0);
   const bool pw = (d->R * d->S == 1) && d->stride == 1 && d->pad == 0;
   const int nstg = wgrad_stages();
 #define TD_WG_LAUNCH(TT, NS)                                                    \
@@ -1026,7 +1036,7 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
   TD_REQUIRE(jobs && n_jobs >= 1, "td_conv_wgrad_batch: no jobs");
   hipStream_t st = (hipStream_t)stream;
   std::vector<WgradParams> tab[2];  // [0] general geometry, [1] pointwise
-  double flops = 0;
+  double flops = 0, abytes = 0;
   for (int i = 0; i < n_jobs; ++i) {
     const td_wgrad_job& j = jobs[i];
     TD_REQUIRE(j.g && j.src && j.dW, "td_conv_wgrad_batch: job %d has a null pointer", i);
@@ -1048,9 +1058,13 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
     const bool pw = (j.d.R * j.d.S == 1) && j.d.stride == 1 && j.d.pad == 0;
     tab[pw ? 1 : 0].push_back(p);
     flops += 2.0 * p.M * j.d.Nc * p.K;
+    abytes += ((double)p.M * j.ldg + (double)j.d.N * j.d.Hs * j.d.Ws * j.d.C) * (dtype == TD_BF16 ? 2.0 : 4.0) + (double)j.d.Nc * j.ci_real * j.d.R * j.d.S * 4.0;
   }
   const bool prof = prof_on();
-  if (prof) prof_begin(TD_PROF_WGRAD, dtype, flops, st, 0, 0, 0, 0, 0, n_jobs);
+  if (prof) {
+    prof_begin(TD_PROF_WGRAD, dtype, flops, st, 0, 0, 0, 0, 0, n_jobs);
+    prof_set_bytes(abytes);
+  }
   const int nstg = wgrad_stages();
   for (int pw = 0; pw < 2; ++pw) {
     std::vector<WgradParams>& t = tab[pw];

@@ -35,6 +35,7 @@ __device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint32_t
 bool prof_on();
 void prof_begin(int family, int dtype, double flops, hipStream_t st, int M = 0, int N = 0, int K = 0, int R = 0, int stride = 0, int mode = 0);
 void prof_end(hipStream_t st);
+void prof_set_bytes(double algorithmic_bytes);  // of the launch recorded by the last prof_begin
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

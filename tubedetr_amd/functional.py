@@ -49,30 +49,47 @@ class _PrepRegistry:
             return None
         return (_EPOCH[0], base._version, base.data_ptr()) + (tuple((b._version, b.data_ptr()) for b in e.bn) if e.bn is not None else ())
 
-    def _build_table(self, device):
-        import ctypes as C
+    @staticmethod
+    def _fill(it, e, blk):
+        base = e.base_ref()
+        Co, Ci, RS = e.dims
+        wf, wd, b_out, sc = e.res
+        it.W = base.data_ptr() + e.offset * 4
+        if e.bn is not None:
+            it.bn_w, it.bn_b, it.bn_rm, it.bn_rv = (t.data_ptr() for t in e.bn)
+        it.w_fwd = wf.data_ptr()
+        it.w_dgrad = wd.data_ptr() if wd is not None else None
+        it.bias_out = b_out.data_ptr() if b_out is not None else None
+        it.scale_out = sc.data_ptr() if sc is not None else None
+        it.Co, it.Ci, it.RS, it.Cpad, it.Co_alloc, it.blk0 = Co, Ci, RS, e.cpad, e.co_alloc, blk
+        return ((e.co_alloc + 15) // 16) * ((e.cpad + 31) // 32)
 
+    def _build_table(self, device):
         from . import _hip
 
         self.entries = [e for e in self.entries if e.base_ref() is not None]
         items = (_hip.PrepItem * len(self.entries))()
         blk = 0
         for it, e in zip(items, self.entries):
-            base = e.base_ref()
-            Co, Ci, RS = e.dims
-            wf, wd, b_out, sc = e.res
-            it.W = base.data_ptr() + e.offset * 4
-            if e.bn is not None:
-                it.bn_w, it.bn_b, it.bn_rm, it.bn_rv = (t.data_ptr() for t in e.bn)
-            it.w_fwd = wf.data_ptr()
-            it.w_dgrad = wd.data_ptr() if wd is not None else None
-            it.bias_out = b_out.data_ptr() if b_out is not None else None
-            it.scale_out = sc.data_ptr() if sc is not None else None
-            it.Co, it.Ci, it.RS, it.Cpad, it.Co_alloc, it.blk0 = Co, Ci, RS, e.cpad, e.co_alloc, blk
-            blk += ((e.co_alloc + 15) // 16) * ((e.cpad + 31) // 32)
+            blk += self._fill(it, e, blk)
         self.total_blocks = blk
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
         self.table_dev = raw.to(device)  # (re)uploaded only when the set of layers changes
+
+    def refresh_one(self, e, device, dtype):
+        """A layer seen for the first time while the others are current (the very first forward registers the layers
+        one by one): prepare just that one instead of re-running the whole batch per registration."""
+        from . import _hip
+
+        items = (_hip.PrepItem * 1)()
+        nblk = self._fill(items[0], e, 0)
+        tab = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
+        _hip.check(_hip.lib().td_weight_prep_batch(tab.data_ptr(), 1, nblk, _hip.dtype_code(dtype), _hip.stream_ptr()), "td_weight_prep_batch")
+        e.ver = self._signature(e)
+        self._keep = getattr(self, "_keep", [])
+        self._keep.append(tab)  # the launch reads the table asynchronously
+        if len(self._keep) > 1024:
+            del self._keep[:512]
 
     def refresh_all(self, device, dtype):
         from . import _hip
@@ -121,8 +138,11 @@ def prepared(W: Tensor, dtype: torch.dtype, *, bn=None, need_dgrad: bool = True,
         sc = torch.empty(e.co_alloc, dtype=torch.float32, device=dev) if bn is not None else None
         e.res, e.ver = (wf, wd, b_out, sc), None
         cache[key] = e
+        others_current = all(o.ver is not None and o.ver == reg._signature(o) for o in reg.entries[-4:])
         reg.entries.append(e)
         reg.table_dev = None  # table must be rebuilt
+        if others_current and not torch.cuda.is_current_stream_capturing():
+            reg.refresh_one(e, W.device, dtype)
     if e.ver != reg._signature(e):
         reg.refresh_all(W.device, dtype)
     return e.res
