@@ -193,6 +193,36 @@ def test_linear_fwd_bwd(shape, dt):
     assert rel_err(db, (gy * (y_ref > 0)).sum(0)) < TOL[dt]
 
 
+@pytest.mark.parametrize("cfg", [(20001, 256, 1024, True, False, True), (70000, 64, 256, True, False, True), (40010, 128, 512, True, True, False),
+                                 (33000, 192, 512, False, True, False), (140000, 256, 128, False, False, True)])
+def test_pointwise_persistent_instance_matches_tiled_math(cfg):
+    """Shapes large enough to take the persistent weight-stationary instance (bf16, K <= 256, many rows): bias, residual,
+    ReLU and ReLU-mask epilogues, ragged last M tile, against an fp32 matmul of the same bf16 inputs."""
+    from tubedetr_amd import ops
+
+    M, K, Nn, use_res, use_mask, relu = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(M, K, generator=g)).to(dev(), dt)
+    w = (torch.randn(Nn, K, generator=g) / math.sqrt(K)).to(dev(), dt)
+    b = torch.randn(Nn, generator=g).to(dev())
+    res = torch.randn(M, Nn, generator=g).to(dev(), dt) if use_res else None
+    msk = torch.randn(M, Nn, generator=g).to(dev(), dt) if use_mask else None
+    ref = x.float() @ w.float().t() + b
+    if use_res:
+        ref = ref + res.float()
+    if relu:
+        ref = F.relu(ref)
+    if use_mask:
+        ref = ref * (msk.float() > 0)
+    y = ops.linear_fwd(x, w, b, residual=res, relu=relu, mask_src=msk)
+    assert rel_err(y, ref) < TOL[dt]
+    # in place on the residual (the dgrad chain accumulates into dx this way)
+    if use_res:
+        y2 = ops.linear_fwd(x, w, b, residual=res, relu=relu, mask_src=msk, out=res)
+        assert torch.equal(y2, y)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_linear_sigmoid_alpha_dropout(dt):
     from tubedetr_amd import ops

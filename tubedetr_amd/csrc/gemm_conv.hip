@@ -465,6 +465,166 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent, weight-stationary instance for the HBM-bound pointwise layers with K <= 256 (bottleneck conv3 forward,
+// conv1 dgrad: [M][K] x [Nc][K]^T with M in the 10^4..10^6 range).  In the tiled kernel above two thirds of such a
+// workgroup's HBM->LDS traffic is the weight tile it re-reads for every 64 rows, and with one K tile in flight per
+// workgroup the chip holds too few bytes in flight to cover the HBM latency (2.9 TB/s measured).  Here one workgroup per
+// CU keeps its 128 x K weight tile in LDS for the whole launch and walks the M tiles of its group: the activation tile
+// of the NEXT M tile is DMA'd while the current one is multiplied and stored, and the residual / mask rows are
+// requested at the top of the step.  The 128-row-of-N tiles of one M tile run on CUs of the same XCD at the same
+// time, so the activation tile comes from HBM once per XCD.  bf16, fused bias + residual + ReLU + mask epilogue.
+template <int NKT, bool RES, bool MSK>
+__global__ __launch_bounds__(256, 2) void pw_resident_kernel(GemmParams p, int MT, int P) {
+  using T = u16;
+  constexpr int ES = 2;
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  constexpr int WM = 32, WN = 64, TM = 2, TN = 4;
+  constexpr int CPRW = WN / 4, EPL = 8, LPR = WN / EPL, RPI = 64 / LPR, NIT = WM / RPI;
+  constexpr int NOPS = NIT * ((RES ? 1 : 0) + (MSK ? 1 : 0));  // operand loads per lane per step
+  __shared__ __attribute__((aligned(16))) char sA0[32768];
+  __shared__ __attribute__((aligned(16))) char sA1[32768];
+  const td_conv_desc& d = p.d;
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int NT = d.Nc >> 7;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int GPX = P / NT;                      // M-tile groups per XCD
+  const int nt = local % NT, gl = local / NT;
+  if (gl >= GPX) return;
+  const int gid = xcd * GPX + gl, G = 8 * GPX;
+  const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const int n0 = nt * 128;
+  auto issue_A = [&](char* buf, int mt) {
+    const int m0 = mt * 64;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (i * 4 + wave) * 8 + lrow;
+        const uint32_t off = (mt < MT && m < p.M) ? ((uint32_t)m * (uint32_t)p.K + (uint32_t)(kt * 64 + chunk * 8)) * ES : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(buf + kt * 8192 + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+      }
+  };
+  const int wy = wave >> 1, wx = wave & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int cc = lane % LPR, rsub = lane / LPR;
+  const int n = n0 + wx * WN + cc * EPL;
+  float bias[EPL];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) bias[r] = p.bias ? p.bias[n + r] : 0.f;
+  // the weight tile of this workgroup never changes: its MFMA fragments (row n = lane%16 of each 16-row block, 8
+  // consecutive k per lane group) live in registers for the whole launch - 16-byte loads straight from global, no LDS
+  uint4 wfr[NKT][2][TN];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        wfr[kt][ks][i] = *(const uint4*)(p.w + ((size_t)(n0 + wx * WN + i * 16 + lr) * p.K + kt * 64 + ks * 32 + lg * 8) * ES);
+  int mt = gid;
+  issue_A(sA0, mt);
+
+  auto step = [&](char* cur, char* nxt, int mt) {
+    // (1) epilogue operands of this tile (rows clamped: every lane always issues, the wait counts below are constants)
+    size_t offs[NIT];
+    bool live[NIT];
+    uint4 res[NIT], msk[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = mt * 64 + wy * WM + it * RPI + rsub;
+      live[it] = m < p.M;
+      offs[it] = (size_t)min(m, p.M - 1) * d.ldc + n;
+      if constexpr (RES) res[it] = *(const uint4*)(p.residual + offs[it] * ES);
+      if constexpr (MSK) msk[it] = *(const uint4*)(p.mask_src + offs[it] * ES);
+    }
+    // (2) next activation tile, then wait for the current one: only the loads issued in (1) and (2) may still be in
+    //     flight (loads complete in order; stores of the previous tile can only make this wait stricter)
+    issue_A(nxt, mt + G);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NKT + NOPS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int cidx = ks * 4 + lg;
+        uint4 af[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int row = wy * WM + j * 16 + lr;
+          af[j] = *(const uint4*)(cur + kt * 8192 + row * 128 + ((cidx ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) Mfma<T>::run(wfr[kt][ks][i], af[j], acc[i][j]);
+      }
+    // (3) every wave is done with the activation tile: its buffer becomes the transposition staging area
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* stg = (float*)(cur + wave * (WM * WN * 4));
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int row = j * 16 + lr;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int c = (i * 4 + lg) ^ (row & (CPRW - 1));
+        const f32x4 a = acc[i][j];
+        *(float4*)(stg + row * WN + c * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + rsub;
+      const int sw = row & (CPRW - 1);
+      float v[EPL];
+#pragma unroll
+      for (int q = 0; q < EPL / 4; ++q) {
+        const float4 f = *(const float4*)(stg + row * WN + (((cc * (EPL / 4) + q) ^ sw) * 4));
+        v[4 * q + 0] = f.x + bias[4 * q + 0]; v[4 * q + 1] = f.y + bias[4 * q + 1];
+        v[4 * q + 2] = f.z + bias[4 * q + 2]; v[4 * q + 3] = f.w + bias[4 * q + 3];
+      }
+      if constexpr (RES) {
+        float r8[EPL];
+        unpack16<T>(res[it], r8);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] += r8[r];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if constexpr (MSK) {
+        float m8[EPL];
+        unpack16<T>(msk[it], m8);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
+      }
+      if (live[it]) *(uint4*)(p.out + offs[it] * ES) = pack16<T>(v);
+    }
+    // (4) staging reads done before the next step's DMA lands in this buffer
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  while (mt < MT) {
+    step(sA0, sA1, mt);
+    mt += G;
+    if (mt >= MT) break;
+    step(sA1, sA0, mt);
+    mt += G;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-OOB) prefetch must not outlive the workgroup's LDS
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: dW[co][kk] += sum_{m in split} g[m][co] * gather(src)[m][kk]
 // Both operands are reduction-major in memory ([m][channel]); LDS keeps them that way and the bf16
 // fragments are produced by the gfx950 transposing LDS read (ds_read_b64_tr_b16).
@@ -785,6 +945,10 @@ static int validate(const td_conv_desc* d, int dtype, const char* who) {
 using namespace td;
 
 static unsigned long long* g_dbg = nullptr;
+static int persist_min_tiles() {
+  static const int v = [] { const char* e = getenv("TD_PW_PERSIST_MIN"); return e ? atoi(e) : 4; }();
+  return v;
+}
 extern "C" int td_debug_set_stamp_buffer(unsigned long long* buf) { g_dbg = buf; return TD_OK; }
 
 extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const td_conv_desc* d, const td_epilogue* e,
@@ -828,6 +992,50 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   }
   TD_REQUIRE(d->ldc >= d->Nc, "td_conv_gemm: ldc < Nc");
   hipStream_t st = (hipStream_t)stream;
+  {
+    // persistent weight-stationary instance (see pw_resident_kernel): bf16 pointwise layers with short K and many rows
+    static const int persist = [] { const char* e_ = getenv("TD_PW_PERSIST"); return e_ ? atoi(e_) : 1; }();
+    static const int n_cu = [] {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      return cus;
+    }();
+    const bool pw0 = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && p.d.out_sp == 1 && d->Hs == d->Ho && d->Ws == d->Wo;
+    const int NTp = d->Nc / 128, Pp = 2 * n_cu / 8;
+    const bool shape_ok = pw0 && dtype == TD_BF16 && p.K % 64 == 0 && p.K <= 256 && d->Nc % 128 == 0 &&
+                          (NTp == 1 || NTp == 2 || NTp == 4 || NTp == 8) && Pp >= NTp && d->ldc % 8 == 0 && !p.sigmoid &&
+                          !p.drop_thresh && p.alpha == 1.f && n_cu % 8 == 0;
+    const int MTp = cdiv(p.M, 64);
+    const int groups = shape_ok ? 8 * (Pp / NTp) : 1;
+    if (persist && shape_ok && MTp >= persist_min_tiles() * groups) {
+      const bool prof_ = prof_on();
+      if (prof_) {
+        prof_begin(TD_PROF_GEMM_64x128, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, 100 + d->mode);
+        const double es_ = 2.0;
+        double by = ((double)p.M * p.K + (double)d->Nc * p.K + (double)p.M * d->Nc) * es_;
+        if (p.residual) by += (double)p.M * d->Nc * es_;
+        if (p.mask_src) by += (double)p.M * d->Nc * es_;
+        prof_set_bytes(by);
+      }
+      const int nkt = p.K / 64;
+      const bool hr = p.residual != nullptr, hm = p.mask_src != nullptr;
+      dim3 g2(2 * n_cu);  // two resident workgroups per CU (64 KiB of LDS each)
+#define TD_PWR(NK)                                                                                      \
+  do {                                                                                                  \
+    if (hr && hm) pw_resident_kernel<NK, true, true><<<g2, 256, 0, st>>>(p, MTp, Pp);                  \
+    else if (hr) pw_resident_kernel<NK, true, false><<<g2, 256, 0, st>>>(p, MTp, Pp);                  \
+    else if (hm) pw_resident_kernel<NK, false, true><<<g2, 256, 0, st>>>(p, MTp, Pp);                  \
+    else pw_resident_kernel<NK, false, false><<<g2, 256, 0, st>>>(p, MTp, Pp);                         \
+  } while (0)
+      if (nkt == 1) TD_PWR(1);
+      else if (nkt == 2) TD_PWR(2);
+      else if (nkt == 3) TD_PWR(3);
+      else TD_PWR(4);
+#undef TD_PWR
+      if (prof_) prof_end(st);
+      return check_launch("td_conv_gemm(pw_resident)");
+    }
+  }
   // tile choice: 128x64 for <=64 output channels; 64x128 when 128x128 would leave the 256 CUs under-filled
   const bool narrow = d->Nc <= 64;
   const int tiles128 = cdiv(p.M, 128) * cdiv(d->Nc, 128);
