@@ -45,7 +45,8 @@ int td_set_dropout_step_counter(const uint32_t* dev_counter);
 #define TD_PROF_GEMM_128x64 1
 #define TD_PROF_WGRAD 2
 #define TD_PROF_GEMM_64x128 3
-#define TD_PROF_FAMILIES 4
+#define TD_PROF_PW_RESIDENT 4 /* persistent weight-stationary pointwise instance */
+#define TD_PROF_FAMILIES 5
 int td_prof_enable(int on);
 int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
 /* Sum of the ALGORITHMIC HBM bytes of the same launches (each operand / result tensor counted once per launch). */

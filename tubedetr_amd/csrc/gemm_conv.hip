@@ -1007,10 +1007,10 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
                           !p.drop_thresh && p.alpha == 1.f && n_cu % 8 == 0;
     const int MTp = cdiv(p.M, 64);
     const int groups = shape_ok ? 8 * (Pp / NTp) : 1;
-    if (persist && shape_ok && MTp >= persist_min_tiles() * groups) {
+    if (persist && shape_ok && MTp >= persist_min_tiles() * groups && !(persist == 2 && p.mask_src) && !(persist == 3 && d->mode != 0)) {
       const bool prof_ = prof_on();
       if (prof_) {
-        prof_begin(TD_PROF_GEMM_64x128, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, 100 + d->mode);
+        prof_begin(TD_PROF_PW_RESIDENT, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
         const double es_ = 2.0;
         double by = ((double)p.M * p.K + (double)d->Nc * p.K + (double)p.M * d->Nc) * es_;
         if (p.residual) by += (double)p.M * d->Nc * es_;
