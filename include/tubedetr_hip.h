@@ -96,6 +96,10 @@ int td_conv_gemm(const void* src, const void* wmat, void* out, const td_conv_des
  * Replaces: autograd weight gradients of Conv2d / Linear on the same call sites. */
 int td_conv_wgrad(const void* g, const void* src, float* dw, const td_conv_desc* d, int ldg, int dtype, int splits,
                   td_stream_t stream);
+/* Same, and dbias[n] += sum_m g[m][n] (the bias gradient of a Linear / Conv2d with bias, models/transformer.py:643,748,769)
+ * from the gradient fragments the kernel already holds; dbias (fp32, zero-initialised by the caller) may be NULL. */
+int td_conv_wgrad_bias(const void* g, const void* src, float* dw, float* dbias, const td_conv_desc* d, int ldg, int dtype,
+                       int splits, td_stream_t stream);
 
 /* Batched weight gradients: ONE launch (two when 1x1 and 3x3 jobs are mixed) computes the weight gradients of many
  * conv layers.  dW of every job is written in the parameter's own [Nc][ci_real][R][S] fp32 layout with `scale[co]`

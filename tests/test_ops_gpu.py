@@ -191,6 +191,11 @@ def test_linear_fwd_bwd(shape, dt):
     assert rel_err(dW, wr.grad) < TOL[dt]
     db = ops.colsum(gpre)
     assert rel_err(db, (gy * (y_ref > 0)).sum(0)) < TOL[dt]
+    # bias gradient fused into the weight-gradient launch (accumulates: starts from a non-zero buffer here)
+    db2 = torch.full((Nn,), 0.5, device=dev())
+    dW2 = ops.linear_wgrad(gpre, xd, dbias=db2)
+    assert rel_err(dW2, wr.grad) < TOL[dt]
+    assert rel_err(db2 - 0.5, (gy * (y_ref > 0)).sum(0)) < TOL[dt]
 
 
 @pytest.mark.parametrize("cfg", [(20001, 256, 1024, True, False, True), (70000, 64, 256, True, False, True), (40010, 128, 512, True, True, False),

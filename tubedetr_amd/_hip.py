@@ -52,6 +52,7 @@ _SIGS = {
     "td_prof_collect_bytes": [_I, _I, C.POINTER(C.c_double)],
     "td_conv_gemm": [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P],
     "td_conv_wgrad": [_P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
+    "td_conv_wgrad_bias": [_P, _P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
     "td_conv_wgrad_batch": [C.POINTER(WgradJob), _I, _I, _P],
     "td_resnet_num_convs": [C.POINTER(C.c_int)],
     "td_resnet_fwd": [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ, C.POINTER(_P), C.POINTER(C.c_int), _I, _P],

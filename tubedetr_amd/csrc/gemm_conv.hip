@@ -361,28 +361,26 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
     TD_STAMP(2);
     fetch_epilogue_operands();
   } else {
-    fetch_epilogue_operands();
-    issue_tile(smem0);
-    if (nk > 1) issue_tile(smem1);
-    // wait until at most the DMA of ONE younger tile (AI + BI instructions of this wave) is still in flight
-    auto wait_oldest = [&](bool younger_in_flight) {
-      if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    };
-    for (int kt = 0; kt < nk; kt += 3) {
-      wait_oldest(kt + 1 < nk);
-      if (kt + 2 < nk) issue_tile(smem2);
-      compute_tile(smem0);
-      if (kt + 1 >= nk) break;
-      wait_oldest(kt + 2 < nk);
-      if (kt + 3 < nk) issue_tile(smem0);
-      compute_tile(smem1);
-      if (kt + 2 >= nk) break;
-      wait_oldest(kt + 3 < nk);
-      if (kt + 4 < nk) issue_tile(smem1);
-      compute_tile(smem2);
+    // three stages, two tiles in flight.  Every step issues exactly one tile (k tiles past the end are all-OOB = zero
+    // fill, no traffic) so "tile j has landed" is always "at most AI+BI DMA instructions of this wave outstanding"; the
+    // pipeline warm-up is folded into the loop (steps -2, -1 only issue) so that each stage buffer has a single static
+    // DMA site and the compiler's own LDS-DMA wait counts stay exact.
+#define TD_CG_STEP(cur, nxt, j)                                                     \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");                    \
+  __builtin_amdgcn_s_barrier();                                                     \
+  issue_tile(nxt);                                                                  \
+  if ((j) >= 0) compute_tile(cur);
+    for (int it = -2; it < nk; it += 3) {
+      TD_CG_STEP(smem1, smem0, it)
+      if (it + 1 >= nk) break;
+      TD_CG_STEP(smem2, smem1, it + 1)
+      if (it + 2 >= nk) break;
+      TD_CG_STEP(smem0, smem2, it + 2)
     }
+#undef TD_CG_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing zero-fill DMAs must not land in the epilogue staging area
+    TD_STAMP(2);
+    fetch_epilogue_operands();
   }
 
   // (2) transpose the accumulators through LDS.  Raw barrier: the operand loads above stay in flight (a
@@ -634,6 +632,7 @@ struct WgradParams {
   const char* src;
   float* dw;
   const float* scale;  // out_mode 1/2: per-output-channel factor folded into the result (FrozenBN scale), may be null
+  float* dbias;        // optional: dbias[co] += sum_m g[m][co] (column sums of the gradient), by the k-tile-0 workgroups
   td_conv_desc d;
   int M, K, ldg, mper;
   uint32_t g_bytes, src_bytes;
@@ -760,6 +759,12 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient = column sums of g: one more MFMA per G fragment against an all-ones operand, only in the
+  // workgroups of the first k tile (every column of the product holds the same sums)
+  const bool do_bias = p.dbias != nullptr && by == 0;
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto compute_stage = [&](const char* st) {
     const char* sG = st;
     const char* sX = st + TILEB;
@@ -797,6 +802,14 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&gf[ks][i], *(const bf16x8*)&xf[ks][j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // 8 x bf16(1.0)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&gf[ks][i], *(const bf16x8*)&ones, accb[i], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int s4 = 0; s4 < MK / 4; ++s4) {
@@ -811,6 +824,10 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[i], xf[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[i], 1.0f, accb[i], 0, 0, 0);
+        }
       }
     }
   };
@@ -856,6 +873,15 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
   // D[i=co][j=kk]: lane holds co = base + 4*lg + r, kk = base + lr
   TD_WSTAMP(2);
   if (p.dbg == 1 && acc[0][0][0] != 12345.f) return;
+  if (do_bias && wx == 0 && lr == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int coo = co0 + wy * 64 + i * 16 + 4 * lg + rr;
+        if (coo < d.Nc) atomicAdd(p.dbias + coo, accb[i][rr]);
+      }
+  }
   if (p.out_mode == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1061,8 +1087,14 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
     if (pw) conv_gemm_kernel<TT, BMv, BNv, 2, true><<<grid, 256, 0, st>>>(p);                    \
     else conv_gemm_kernel<TT, BMv, BNv, 2, false><<<grid, 256, 0, st>>>(p);                      \
   } while (0)
+  static const int deep = [] { const char* e_ = getenv("TD_CONV_DEEP"); return e_ ? atoi(e_) : 1; }();
+  // under-filled launch (at most two 64x128 workgroups per CU anyway) with a long K loop: the third stage costs nothing
+  // in occupancy and halves the exposed DMA round trips
+  const bool deep_ok = deep && small_m && (int)grid.x <= 2 * 256 && p.K >= 1024;  // measured: +6 % at K >= 1024, neutral-to-negative at K = 256
   if (dtype == TD_BF16) {
     if (narrow) TD_LAUNCH(u16, 128, 64);
+    else if (deep_ok && pw) conv_gemm_kernel<u16, 64, 128, 3, true><<<grid, 256, 0, st>>>(p);
+    else if (deep_ok) conv_gemm_kernel<u16, 64, 128, 3, false><<<grid, 256, 0, st>>>(p);
     else if (small_m) TD_LAUNCH(u16, 64, 128);
     else TD_LAUNCH(u16, 128, 128);
   } else {
@@ -1133,11 +1165,17 @@ static int wgrad_fill(WgradParams& p, const void* g, const void* src, const td_c
 
 extern "C" int td_conv_wgrad(const void* g, const void* src, float* dw, const td_conv_desc* d, int ldg, int dtype,
                              int splits, td_stream_t stream) {
+  return td_conv_wgrad_bias(g, src, dw, nullptr, d, ldg, dtype, splits, stream);
+}
+
+extern "C" int td_conv_wgrad_bias(const void* g, const void* src, float* dw, float* dbias, const td_conv_desc* d, int ldg,
+                                  int dtype, int splits, td_stream_t stream) {
   TD_REQUIRE(g && src && dw && d, "td_conv_wgrad: null pointer");
   WgradParams p;
   int rc = wgrad_fill(p, g, src, d, ldg, dtype, &splits, 0, "td_conv_wgrad");
   if (rc) return rc;
   p.dw = dw;
+  p.dbias = dbias;
   p.out_mode = 0;
   p.stamps = g_dbg;
   dim3 grid(p.tn, p.tk, splits);

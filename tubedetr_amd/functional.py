@@ -196,8 +196,14 @@ class LinearFn(Function):
         else:
             g = dy
         dx = ops.linear_fwd(g, wd) if ctx.needs_input_grad[0] else None
-        dW = ops.linear_wgrad(g, x)[:N] if ctx.needs_input_grad[1] else None
-        db = ops.colsum(g)[:N] if (has_b and ctx.needs_input_grad[2]) else None
+        want_w, want_b = ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]
+        dW = db = None
+        if want_w:  # the bias gradient (column sums of g) rides along in the weight-gradient launch
+            db_full = ops.zeros_f32(g.shape[1], g.device) if want_b else None
+            dW = ops.linear_wgrad(g, x, dbias=db_full)[:N]
+            db = db_full[:N] if want_b else None
+        elif want_b:
+            db = ops.colsum(g)[:N]
         return dx, dW, db, None, None, None
 
 
@@ -224,12 +230,12 @@ class FFNFn(Function):
         x, h, w1d, w2d = ctx.saved_tensors
         p, seed1, seed2 = ctx.cfg
         g2 = ops.dropout(dy.contiguous(), p, seed2) if p > 0 else dy.contiguous()
-        dW2 = ops.linear_wgrad(g2, h)
-        db2 = ops.colsum(g2)
+        db2 = ops.zeros_f32(g2.shape[1], g2.device)
+        dW2 = ops.linear_wgrad(g2, h, dbias=db2)
         # dh = (g2 @ W2) * (h > 0) / (1-p): mask + scale fused in the GEMM epilogue
         dh = ops.linear_fwd(g2, w2d, mask_src=h, alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
-        dW1 = ops.linear_wgrad(dh, x)
-        db1 = ops.colsum(dh)
+        db1 = ops.zeros_f32(dh.shape[1], dh.device)
+        dW1 = ops.linear_wgrad(dh, x, dbias=db1)
         dx = ops.linear_fwd(dh, w1d) if ctx.needs_input_grad[0] else None
         return dx, dW1, db1, dW2, db2, None, None, None
 
@@ -316,8 +322,8 @@ class MHAFn(Function):
         g = ops.dropout(dout.contiguous(), p_out, seed_out) if p_out > 0 else dout.contiguous()
         dW_in = ops.zeros_f32((3 * E, E), dev)
         db_in = ops.zeros_f32(3 * E, dev)
-        dW_out = ops.linear_wgrad(g, ctxv.view(B * Lq, E))
-        db_out = ops.colsum(g)
+        db_out = ops.zeros_f32(E, dev)
+        dW_out = ops.linear_wgrad(g, ctxv.view(B * Lq, E), dbias=db_out)
         dctx = ops.linear_fwd(g, wo_d).view(B, Lq, E)
         if same_qk:
             dqk = torch.empty((B, Lq, 2 * E), dtype=dt, device=dev)
@@ -329,22 +335,18 @@ class MHAFn(Function):
         dwa = dwavg.contiguous().float() if dwavg is not None else None
         ops.mha_bwd(q, k, v, dctx, probs, dwa, H, scale, dq, dk, dv, dropout_p=p_attn, seed=seed_attn)
         dv2 = dv.view(B * Lk, E)
-        ops.linear_wgrad(dv2, v_in, out=dW_in[2 * E :])
-        ops.colsum(dv2, out=db_in[2 * E :])
+        ops.linear_wgrad(dv2, v_in, out=dW_in[2 * E :], dbias=db_in[2 * E :])
         d_v_in = ops.linear_fwd(dv2, wv_d) if ctx.needs_input_grad[2] else None
         d_q_in = d_k_in = None
         if same_qk:
             dqk2 = dqk.view(B * Lq, 2 * E)
-            ops.linear_wgrad(dqk2, q_in, out=dW_in[: 2 * E])
-            ops.colsum(dqk2, out=db_in[: 2 * E])
+            ops.linear_wgrad(dqk2, q_in, out=dW_in[: 2 * E], dbias=db_in[: 2 * E])
             if ctx.needs_input_grad[0]:
                 d_q_in = ops.linear_fwd(dqk2, wd_list[0])
         else:
             dq2, dk2 = dq.view(B * Lq, E), dk.view(B * Lk, E)
-            ops.linear_wgrad(dq2, q_in, out=dW_in[:E])
-            ops.colsum(dq2, out=db_in[:E])
-            ops.linear_wgrad(dk2, k_in, out=dW_in[E : 2 * E])
-            ops.colsum(dk2, out=db_in[E : 2 * E])
+            ops.linear_wgrad(dq2, q_in, out=dW_in[:E], dbias=db_in[:E])
+            ops.linear_wgrad(dk2, k_in, out=dW_in[E : 2 * E], dbias=db_in[E : 2 * E])
             if ctx.needs_input_grad[0]:
                 d_q_in = ops.linear_fwd(dq2, wd_list[0])
             if ctx.needs_input_grad[1]:

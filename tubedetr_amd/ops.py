@@ -158,13 +158,16 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, residual=
     return y
 
 
-def linear_wgrad(g: Tensor, x: Tensor, *, out: Optional[Tensor] = None, splits: int = 0) -> Tensor:
-    """dW [N,K] fp32 (+)= g^T @ x   with g [M,N], x [M,K]."""
+def linear_wgrad(g: Tensor, x: Tensor, *, out: Optional[Tensor] = None, splits: int = 0, dbias: Optional[Tensor] = None) -> Tensor:
+    """dW [N,K] fp32 (+)= g^T @ x   with g [M,N], x [M,K]; optionally dbias [N] fp32 += column sums of g (same launch)."""
     M, K = x.shape
     Nn = g.shape[1]
     dw = out if out is not None else zeros_f32((Nn, K), x.device)
     d = _desc(1, M, 1, K, M, 1, 1, 1, 1, 0, 0, Nn, Nn)
-    check(_hip.lib().td_conv_wgrad(ptr(g), ptr(x), ptr(dw), C.byref(d), g.shape[1], dtype_code(x.dtype), splits, stream_ptr()), "td_conv_wgrad")
+    if dbias is not None:
+        assert dbias.dtype == torch.float32 and dbias.numel() == Nn and dbias.is_contiguous()
+    check(_hip.lib().td_conv_wgrad_bias(ptr(g), ptr(x), ptr(dw), ptr(dbias), C.byref(d), g.shape[1], dtype_code(x.dtype), splits, stream_ptr()),
+          "td_conv_wgrad")
     return dw
 
 
