@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--roofline-steps", type=int, default=2)
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample clip (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-baseline sample clip (0 = skip)")
     ap.add_argument("--keep-prepared-weights", action="store_true", help="diagnostic: reuse prepared bf16 weights across steps")
     ap.add_argument("--dedupe", action="store_true",
                     help="do not recompute the slow frames inside the fast pass (exact, slow = video[::k]); off by default so the timed step "
