@@ -321,8 +321,8 @@ def main():
             code = _hip.TD_BF16 if cdt == torch.bfloat16 else _hip.TD_F32
             tname = "unsigned short" if cdt == torch.bfloat16 else "float"
             peak = PEAK_BF16_TFLOPS if cdt == torch.bfloat16 else 157.3
-            fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128, 2, *>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128, 2, *>",
-                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, 2, *>", 2: f"td::conv_wgrad_kernel|conv_wgrad_batch_kernel<{tname}>", 4: "td::pw_resident_kernel<*>"}  # * = both pointwise / generic instances
+            fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128, *, *>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128, *, *>",
+                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, *, *>", 2: f"td::conv_wgrad_kernel|conv_wgrad_batch_kernel<{tname}>", 4: "td::pw_resident_kernel<*>"}  # * = all pipeline depths, pointwise and generic instances
             # PMC-measured HBM traffic per launch of the same command (tools/pmc_traffic.py, committed under profiles/):
             # counters cannot be read from inside the process being timed
             pmc = {}

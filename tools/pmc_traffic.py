@@ -10,7 +10,7 @@ import csv, json, re, sys
 def family(name):
     m = re.search(r"td::conv_gemm_kernel<([^,]+), (\d+), (\d+), (\d+), (true|false)>", name)
     if m:
-        return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, *>"
+        return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, *, *>"  # stages and pointwise flag merged
     if "td::pw_resident_kernel" in name:
         return "td::pw_resident_kernel<*>"
     m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)
