@@ -227,7 +227,7 @@ def main():
         loss, _, _, _ = forward_step(net, criterion, weight_dict, b)
         loss.backward()
         if reducer is not None:
-            reducer.reduce()
+            reducer.reduce(attach=True)  # gather, ONE all-reduce, .grad re-pointed at the flat buffer (no copy back)
         return loss
 
     def fence():
@@ -251,6 +251,8 @@ def main():
                 invalidate_prepared()
                 l_, _, _, _ = forward_step(net, criterion, weight_dict, static)
                 l_.backward()
+                if reducer is not None:
+                    reducer.gather()  # no collective: part of the captured step
                 return l_
 
             side = torch.cuda.Stream()
@@ -270,6 +272,8 @@ def main():
                 static_loss = body()
             torch.cuda.synchronize()
             _trace("capture done")
+            if reducer is not None:
+                reducer.attach()  # from now on .grad of every parameter is its (averaged) slice of the flat buffer
 
             def step(i):  # noqa: F811
                 b_ = batches[i % len(batches)]
@@ -279,9 +283,9 @@ def main():
                 counter.add_(1)
                 if reducer is not None:
                     sync_num_boxes(b_["target_boxes"].shape[0], criterion.external_num_boxes)
-                graph.replay()
+                graph.replay()  # ends with the gather of the gradients into the flat exchange buffer
                 if reducer is not None:
-                    reducer.reduce()  # the only collective of the step, outside the graph
+                    reducer.all_reduce()  # the only collective of the step, outside the graph
                 return static_loss
 
             execution = "hip_graph"

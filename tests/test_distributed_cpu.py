@@ -119,6 +119,17 @@ def _flat_grad_allreduce(rank, world):
         for got, w in zip((model.enc.weight.grad, model.dec.bias.grad), want):
             assert torch.allclose(got, w / world, atol=tol * max(1.0, w.abs().max().item())), wire
         assert model.pooler.weight.grad is None
+        # zero-copy hand-over: same values, .grad re-pointed at the flat exchange buffer, grad-less parameters stay None
+        model2 = TwoPhase()
+        model2(x, False, model2(x))["pred"].pow(2).sum().backward()
+        red2 = FlatGradAllReducer(model2.parameters(), wire)
+        red2.gather()
+        red2.all_reduce()
+        red2.attach()
+        assert torch.equal(model2.enc.weight.grad, model.enc.weight.grad) and model2.pooler.weight.grad is None
+        assert model2.enc.weight.grad.data_ptr() == red2.views[[id(p) for p in red2.params].index(id(model2.enc.weight))].data_ptr()
+        red2.gather()  # gradients already living in the flat buffer are left alone
+        assert torch.equal(model2.enc.weight.grad, model.enc.weight.grad)
     nb = sync_num_boxes(4 + 2 * rank, torch.zeros(1))
     assert nb.item() == (4 + 6) / world
     assert sync_num_boxes(0, torch.zeros(1)).item() == 1.0

@@ -8,7 +8,8 @@ into 25 MB buckets.  The exchange itself is only "average 185 M fp32 gradients",
   * gradients are gathered into ONE persistent flat buffer with a fused multi-tensor copy, optionally narrowed to bf16
     for the wire (halves the bytes each xGMI link carries; RCCL ring all-reduce is per-link bound on this fabric),
   * a single ``all_reduce`` (no bucketing: 288 GB of HBM makes one 0.74 GB collective cheaper than 30 small ones),
-  * the averaged values are scattered back into the ``.grad`` tensors with one more fused copy.
+  * the averaged values are scattered back into the ``.grad`` tensors with one more fused copy - or, zero-copy, ``.grad``
+    is re-pointed at the flat buffer (``attach``); the gather has no collective and can live inside the step's HIP graph.
 
 Parameters that received no gradient (RoBERTa's pooler - the reason the reference needs find_unused_parameters) are
 simply exchanged as zeros.  The forward / backward of the step itself contains no collective, so it can be replayed
@@ -39,24 +40,57 @@ class FlatGradAllReducer:
         self.numel = n
         self.always_communicate = False  # diagnostic: issue the collective even in a 1-rank group
 
-    def reduce(self) -> None:
-        """Average the current ``.grad`` of every parameter over the ranks, in place."""
-        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
-        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
+    # ---- three phases; `reduce()` runs them back to back ----
+    def gather(self, grads: Optional[List[Optional[torch.Tensor]]] = None) -> None:
+        """Copy the gradients (default: the parameters' current ``.grad``) into the flat buffer with fused multi-tensor
+        copies; missing ones become zeros.  Contains no collective: it can be captured in the step's HIP graph."""
+        grads = [p.grad for p in self.params] if grads is None else grads
+        have = [(v, g) for v, g in zip(self.views, grads) if g is not None and g.data_ptr() != v.data_ptr()]
+        missing = [v for v, g in zip(self.views, grads) if g is None]
         if missing:
             torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        if self.world > 1 or self.always_communicate:
-            if self.wire is not self.flat:
-                self.wire.copy_(self.flat)
-                dist.all_reduce(self.wire, group=self.group)
-                self.flat.copy_(self.wire)
-            else:
-                dist.all_reduce(self.flat, group=self.group)
+        self._had_grad = [g is not None for g in grads]
+
+    def all_reduce(self) -> None:
+        """The one collective of a training step: average the flat buffer over the ranks (in place)."""
+        if not (self.world > 1 or self.always_communicate):
+            return
+        avg = dist.is_initialized() and dist.get_backend(self.group) == "nccl"  # RCCL averages in the reduction itself
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        if self.wire is not self.flat:
+            self.wire.copy_(self.flat)
+            dist.all_reduce(self.wire, op=op, group=self.group)
+            self.flat.copy_(self.wire)
+        else:
+            dist.all_reduce(self.flat, op=op, group=self.group)
+        if not avg:
             self.flat.div_(self.world)
+
+    def attach(self) -> None:
+        """Zero-copy hand-over: ``.grad`` of every parameter that had a gradient becomes its view of the flat buffer
+        (what a fused optimizer wants anyway)."""
+        had = getattr(self, "_had_grad", [True] * len(self.params))
+        for p, v, h in zip(self.params, self.views, had):
+            if h:
+                p.grad = v
+
+    def scatter(self) -> None:
+        """Copy the averaged values back into the existing ``.grad`` tensors (keeps their storage)."""
+        have = [(p.grad, v) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:
-            torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
+            torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
+
+    def reduce(self, attach: bool = False) -> None:
+        """Average the current ``.grad`` of every parameter over the ranks, in place (``attach=True``: ``.grad`` is
+        re-pointed at the flat buffer instead of being copied back)."""
+        self.gather()
+        self.all_reduce()
+        if attach:
+            self.attach()
+        else:
+            self.scatter()
 
 
 def sync_num_boxes(n_local: int, out: torch.Tensor, group=None) -> torch.Tensor:
