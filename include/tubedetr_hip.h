@@ -105,7 +105,13 @@ int td_conv_wgrad_bias(const void* g, const void* src, float* dw, float* dbias, 
  * conv layers.  dW of every job is written in the parameter's own [Nc][ci_real][R][S] fp32 layout with `scale[co]`
  * (the FrozenBN factor, may be NULL) folded in - overwritten, not accumulated.  With thousands of output tiles in flight
  * a job needs no reduction splits (no atomics, no accumulator memset, no finalize pass) unless its M is very long.
- * `jobs` is a host array, consumed before the call returns.  Replaces the same autograd call sites as td_conv_wgrad,
+ * `jobs` is a host array, consumed before the call returns.
+ * Deviation from the "caller allocates everything" rule of this ABI: the per-launch job table (<= 64 KiB) is staged
+ * through a small library-owned pool of pinned-host / device buffers (allocated lazily by eager calls, never inside a
+ * stream capture, where pre-allocated spares are used and an error is returned if none exists; an eager call may wait on
+ * the event of the table it recycles, eight batches back).  The pool makes this entry point single-threaded per
+ * process (it is called from autograd's backward thread only).  Planned: caller-provided table workspace.
+ * Replaces the same autograd call sites as td_conv_wgrad,
  * for all convs of the trunk at once (torchvision resnet Bottleneck backward, models/backbone.py:94-98). */
 typedef struct td_wgrad_job {
   const void* g;      /* [M][ldg] output gradient rows */

@@ -640,7 +640,6 @@ struct WgradParams {
                  // 2: as 1 with plain stores (the job has a single split: nobody else touches the tile)
   int ci_real;   // input channels of the parameter (C may be padded)
   int tn, tk, first;  // batched launch: tile grid of this job and its first workgroup index
-  int dbg;
   unsigned long long* stamps;  // debug: 40 cycle stamps per workgroup (tools/stamp_wgrad.py)
 };
 
@@ -872,7 +871,6 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
   }
   // D[i=co][j=kk]: lane holds co = base + 4*lg + r, kk = base + lr
   TD_WSTAMP(2);
-  if (p.dbg == 1 && acc[0][0][0] != 12345.f) return;
   if (do_bias && wx == 0 && lr == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1128,10 +1126,6 @@ static int wgrad_fill(WgradParams& p, const void* g, const void* src, const td_c
   p.K = d->R * d->S * d->C;
   p.ldg = ldg;
   p.ci_real = d->C;
-  {
-    static const int dbg = [] { const char* e = getenv("TD_WGRAD_DBG"); return e ? atoi(e) : 0; }();
-    p.dbg = dbg;
-  }
   {
     const double es = dtype == TD_BF16 ? 2.0 : 4.0;
     const double gb = (double)p.M * ldg * es, sb = (double)d->N * d->Hs * d->Ws * d->C * es;
