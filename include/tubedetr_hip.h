@@ -105,12 +105,11 @@ int td_conv_wgrad_bias(const void* g, const void* src, float* dw, float* dbias, 
  * conv layers.  dW of every job is written in the parameter's own [Nc][ci_real][R][S] fp32 layout with `scale[co]`
  * (the FrozenBN factor, may be NULL) folded in - overwritten, not accumulated.  With thousands of output tiles in flight
  * a job needs no reduction splits (no atomics, no accumulator memset, no finalize pass) unless its M is very long.
- * `jobs` is a host array, consumed before the call returns.
- * Deviation from the "caller allocates everything" rule of this ABI: the per-launch job table (<= 64 KiB) is staged
- * through a small library-owned pool of pinned-host / device buffers (allocated lazily by eager calls, never inside a
- * stream capture, where pre-allocated spares are used and an error is returned if none exists; an eager call may wait on
- * the event of the table it recycles, eight batches back).  The pool makes this entry point single-threaded per
- * process (it is called from autograd's backward thread only).  Planned: caller-provided table workspace.
+ * `jobs` is a host array, consumed before the call returns.  The per-launch job table lives in caller-provided
+ * memory of td_conv_wgrad_batch_table_bytes(n_jobs) bytes each: `table_host` (page-locked host memory, written by this
+ * call) and `table_dev` (device memory, filled by ONE hipMemcpyAsync on `stream`).  Both must stay untouched until the
+ * stream has passed this call - for a captured stream, for the lifetime of the graph (the copy node re-reads
+ * table_host at every replay).  No allocation, no synchronisation inside.
  * Replaces the same autograd call sites as td_conv_wgrad,
  * for all convs of the trunk at once (torchvision resnet Bottleneck backward, models/backbone.py:94-98). */
 typedef struct td_wgrad_job {
@@ -122,7 +121,9 @@ typedef struct td_wgrad_job {
   int ldg;
   int ci_real;        /* input channels of the parameter (d.C may be padded) */
 } td_wgrad_job;
-int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, td_stream_t stream);
+size_t td_conv_wgrad_batch_table_bytes(int n_jobs);
+int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev, size_t table_bytes,
+                        td_stream_t stream);
 
 /* Native executor of the bottleneck-ResNet trunk (replaces the module-graph execution of torchvision resnet101 through
  * IntermediateLayerGetter, models/backbone.py:94-98, and its autograd backward).  Conv order in every array: stem,
@@ -141,9 +142,12 @@ int td_resnet_fwd(const float* x_nchw, int N, int H, int W, const int* nblocks, 
  * The forward may have run over N_fwd >= N frames (slow frames first, then the no_grad "fast" frames in the same
  * launch sequence); only the first N frames are back-propagated. */
 size_t td_resnet_bwd_ws_bytes(int N, int H, int W, const int* nblocks, int first_train_stage, int dtype);
+/* bytes of the weight-gradient job table (see td_conv_wgrad_batch): table_host = page-locked host memory, table_dev =
+ * device memory, both caller-allocated and left untouched until the stream has passed the call. */
+size_t td_resnet_bwd_table_bytes(const int* nblocks, int first_train_stage);
 int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, const int* nblocks, int first_train_stage,
                   const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws, void* ws,
-                  size_t ws_bytes, int dtype, td_stream_t stream);
+                  size_t ws_bytes, void* table_host, void* table_dev, size_t table_bytes, int dtype, td_stream_t stream);
 
 /* Fold FrozenBatchNorm2d (models/backbone.py:60-70) into a conv: w_fwd[co][r][s][ci] = W[co][ci][r][s]*scale[co]
  * (ci zero-padded to Cpad), w_dgrad[ci][r][s][co] likewise (may be NULL), bias_out[co] = b - rm*scale,

@@ -53,10 +53,10 @@ _SIGS = {
     "td_conv_gemm": [_P, _P, _P, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P],
     "td_conv_wgrad": [_P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
     "td_conv_wgrad_bias": [_P, _P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
-    "td_conv_wgrad_batch": [C.POINTER(WgradJob), _I, _I, _P],
+    "td_conv_wgrad_batch": [C.POINTER(WgradJob), _I, _I, _P, _P, _SZ, _P],
     "td_resnet_num_convs": [C.POINTER(C.c_int)],
     "td_resnet_fwd": [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ, C.POINTER(_P), C.POINTER(C.c_int), _I, _P],
-    "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _I, _P],
+    "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _P, _P, _SZ, _I, _P],
     "td_weight_prep_batch": [_P, _I, _I, _I, _P],
     "td_weight_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "td_wgrad_finalize": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -75,6 +75,8 @@ _SIGS = {
     "td_mha_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _I, _P],
 }
 _SIZE_SIGS = {
+    "td_conv_wgrad_batch_table_bytes": [_I],
+    "td_resnet_bwd_table_bytes": [C.POINTER(C.c_int), _I],
     "td_resnet_fwd_ws_bytes": [_I, _I, _I, C.POINTER(C.c_int), _I, _I],
     "td_resnet_bwd_ws_bytes": [_I, _I, _I, C.POINTER(C.c_int), _I, _I],
 }

@@ -1197,83 +1197,17 @@ extern "C" int td_conv_wgrad_bias(const void* g, const void* src, float* dw, flo
 }
 
 // ---- batched weight gradients ----
-namespace {
-struct JobUpload {  // pinned staging + device copy of one batch's job table
-  WgradParams* host = nullptr;
-  WgradParams* dev = nullptr;
-  size_t cap = 0;
-  hipEvent_t done = nullptr;
-  bool busy = false;
-};
-constexpr int kUploadRing = 8;
-JobUpload g_ring[kUploadRing];
-int g_ring_next = 0;
+// The job table of a launch lives in caller-provided memory: the library writes it into `table_host` (page-locked),
+// enqueues ONE hipMemcpyAsync into `table_dev` on the caller's stream and launches; no allocation, no synchronisation.
+static size_t wg_table_half(int n_jobs) { return (((size_t)n_jobs * sizeof(WgradParams)) + 255) & ~(size_t)255; }
+extern "C" size_t td_conv_wgrad_batch_table_bytes(int n_jobs) { return n_jobs > 0 ? 2 * wg_table_half(n_jobs) : 0; }
 
-// Buffers for job tables uploaded inside a stream capture: the captured copy node re-reads its pinned source on every
-// replay, so such a table gets a buffer pair nobody ever reuses.  Allocation is illegal while capturing, hence the
-// spares are created by the eager calls that precede any capture (a framework warms up before it captures).
-std::vector<JobUpload> g_spares;
-
-bool alloc_upload(JobUpload& u, size_t n) {
-  u.cap = std::max<size_t>(n, 256);
-  return hipHostMalloc((void**)&u.host, u.cap * sizeof(WgradParams), hipHostMallocDefault) == hipSuccess &&
-         hipMalloc((void**)&u.dev, u.cap * sizeof(WgradParams)) == hipSuccess;
-}
-
-int upload_jobs(const std::vector<WgradParams>& jobs, hipStream_t st, const WgradParams** dev_out) {
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cap);
-  const bool capturing = cap != hipStreamCaptureStatusNone;
-  JobUpload local;
-  JobUpload* u;
-  if (capturing) {
-    size_t k = 0;
-    while (k < g_spares.size() && g_spares[k].cap < jobs.size()) ++k;
-    if (k == g_spares.size()) {
-      set_error("td_conv_wgrad_batch: no pre-allocated job table for a stream capture (run one step eagerly before capturing)");
-      return TD_ERR_INVALID;
-    }
-    local = g_spares[k];
-    g_spares.erase(g_spares.begin() + k);
-    u = &local;
-  } else {
-    u = &g_ring[g_ring_next];
-    g_ring_next = (g_ring_next + 1) % kUploadRing;
-    if (u->busy) {
-      (void)hipEventSynchronize(u->done);  // eight batches ago: long finished unless the host runs far ahead
-      u->busy = false;
-    }
-    if (u->cap < jobs.size()) {
-      if (u->host) (void)hipHostFree(u->host);
-      if (u->dev) (void)hipFree(u->dev);
-      if (!alloc_upload(*u, jobs.size())) {
-        set_error("td_conv_wgrad_batch: job table allocation failed");
-        return TD_ERR_LAUNCH;
-      }
-    }
-    while (g_spares.size() < 8) {
-      JobUpload sp;
-      if (!alloc_upload(sp, jobs.size())) break;
-      g_spares.push_back(sp);
-    }
-  }
-  memcpy(u->host, jobs.data(), jobs.size() * sizeof(WgradParams));
-  if (hipMemcpyAsync(u->dev, u->host, jobs.size() * sizeof(WgradParams), hipMemcpyHostToDevice, st) != hipSuccess) {
-    set_error("td_conv_wgrad_batch: job table upload failed");
-    return TD_ERR_LAUNCH;
-  }
-  if (!capturing) {
-    if (!u->done) (void)hipEventCreateWithFlags(&u->done, hipEventDisableTiming);
-    (void)hipEventRecord(u->done, st);
-    u->busy = true;
-  }
-  *dev_out = u->dev;
-  return TD_OK;
-}
-}  // namespace
-
-extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, td_stream_t stream) {
+extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev,
+                                   size_t table_bytes, td_stream_t stream) {
   TD_REQUIRE(jobs && n_jobs >= 1, "td_conv_wgrad_batch: no jobs");
+  TD_REQUIRE(table_host && table_dev && table_bytes >= td_conv_wgrad_batch_table_bytes(n_jobs),
+             "td_conv_wgrad_batch: job-table workspace missing or smaller than td_conv_wgrad_batch_table_bytes(%d)", n_jobs);
+  const size_t half = wg_table_half(n_jobs);
   hipStream_t st = (hipStream_t)stream;
   std::vector<WgradParams> tab[2];  // [0] general geometry, [1] pointwise
   double flops = 0, abytes = 0;
@@ -1353,9 +1287,16 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
       max_slots = std::max(max_slots, slots);
     }
     xi.start[8] = (int)sorted.size();
-    const WgradParams* dev = nullptr;
-    int rc = upload_jobs(sorted, st, &dev);
-    if (rc) return rc;
+    // instance `pw` owns half `pw` of the caller's table; the async copy reads table_host when the stream gets there
+    // (or, inside a captured graph, at every replay): the caller keeps both buffers untouched until then
+    WgradParams* host = (WgradParams*)((char*)table_host + pw * half);
+    const WgradParams* dev = (const WgradParams*)((char*)table_dev + pw * half);
+    memcpy(host, sorted.data(), sorted.size() * sizeof(WgradParams));
+    if (hipMemcpyAsync((void*)dev, host, sorted.size() * sizeof(WgradParams), hipMemcpyHostToDevice, st) != hipSuccess) {
+      set_error("td_conv_wgrad_batch: job table upload failed");
+      return TD_ERR_LAUNCH;
+    }
+    int rc;
     const unsigned grid = (unsigned)(8 * max_slots);
 #define TD_WGB_LAUNCH(TT, NS)                                                                \
   do {                                                                                       \

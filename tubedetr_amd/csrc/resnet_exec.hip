@@ -222,9 +222,17 @@ extern "C" size_t td_resnet_bwd_ws_bytes(int N, int H, int W, const int* nblocks
   return dwk_bytes(P, first_train_stage, nullptr) + 6 * grad_slot_bytes(P, N, first_train_stage);
 }
 
+extern "C" size_t td_resnet_bwd_table_bytes(const int* nblocks, int first_train_stage) {
+  int n = 0;
+  for (int st = 0; st < 4; ++st)
+    if (st >= first_train_stage) n += 3 * nblocks[st] + 1;  // three convs per bottleneck + the stage's downsample
+  return td_conv_wgrad_batch_table_bytes(n);
+}
+
 extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, const int* nblocks, int first_train_stage,
                              const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws,
-                             void* ws, size_t ws_bytes, int dtype, td_stream_t stream) {
+                             void* ws, size_t ws_bytes, void* table_host, void* table_dev, size_t table_bytes, int dtype,
+                             td_stream_t stream) {
   TD_REQUIRE(dfeat && nblocks && w_dgrad && scale && dW && fwd_ws && ws, "td_resnet_bwd: null pointer");
   TD_REQUIRE(N >= 1 && N <= N_fwd, "td_resnet_bwd: N=%d must be in 1..N_fwd=%d", N, N_fwd);
   // activation offsets are those of the forward pass over N_fwd frames; the first N frames of every tensor (a
@@ -372,6 +380,7 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     g_out = dx;
   }
   join();
-  if (batched && !jobs.empty()) return td_conv_wgrad_batch(jobs.data(), (int)jobs.size(), dtype, stream);
+  if (batched && !jobs.empty())
+    return td_conv_wgrad_batch(jobs.data(), (int)jobs.size(), dtype, table_host, table_dev, table_bytes, stream);
   return TD_OK;
 }

@@ -183,9 +183,14 @@ class ResNetTrunkFn(Function):
         dWs = [torch.empty_like(c.weight) if c.weight.requires_grad else None for c, _ in convs]
         nbytes = L.td_resnet_bwd_ws_bytes(N, H, W, nb, first_stage, code)
         bws = torch.empty(nbytes, dtype=torch.uint8, device=dfeat.device)
+        from .. import ops
+
+        tbytes = L.td_resnet_bwd_table_bytes(nb, first_stage)
+        th, td_, done = ops.job_tables.take(tbytes, dfeat.device)  # weight-gradient job table: caller-owned staging
         _hip.check(L.td_resnet_bwd(dfeat.contiguous().data_ptr(), N, N_fwd, H, W, nb, first_stage, _ptr_array([p[1] for p in preps]),
-                                   _ptr_array([p[3] for p in preps]), _ptr_array(dWs), ws.data_ptr(), bws.data_ptr(), nbytes, code,
-                                   _hip.stream_ptr()), "td_resnet_bwd")
+                                   _ptr_array([p[3] for p in preps]), _ptr_array(dWs), ws.data_ptr(), bws.data_ptr(), nbytes,
+                                   th.data_ptr(), td_.data_ptr(), tbytes, code, _hip.stream_ptr()), "td_resnet_bwd")
+        done()
         ctx.ws = ctx.preps = None
         by_id = {id(c.weight): g for (c, _), g in zip(convs, dWs)}
         return (None, None, None, None) + tuple(by_id.get(id(p)) for p in body.trainable_weights())

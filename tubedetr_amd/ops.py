@@ -127,6 +127,54 @@ def conv_wgrad(g: Tensor, x: Tensor, R: int, S: int, stride: int, pad: int, *, o
     return dw
 
 
+class _JobTables:
+    """Caller-side staging of the job tables of td_conv_wgrad_batch / td_resnet_bwd (the C ABI allocates nothing): a
+    ring of (page-locked host, device) buffer pairs.  An eager call recycles the pair used eight calls ago after its
+    event has passed; a call made inside a stream capture takes a pair out of the ring for good (the captured copy node
+    re-reads the host buffer at every replay), so the pairs must exist before the capture starts - any eager step
+    creates them."""
+
+    RING = 12
+
+    def __init__(self):
+        self.slots, self.retired, self.cap, self.next = [], [], 0, 0
+
+    def _grow(self, nbytes, device):
+        self.cap = max(self.cap, (nbytes + 4095) // 4096 * 4096, 65536)
+        self.slots = [s for s in self.slots if s[0].numel() >= self.cap]
+        while len(self.slots) < self.RING:
+            self.slots.append([torch.empty(self.cap, dtype=torch.uint8, pin_memory=True),
+                               torch.empty(self.cap, dtype=torch.uint8, device=device), None])
+
+    def take(self, nbytes: int, device):
+        """-> (host tensor, device tensor, done) ; call done() after the launch has been enqueued."""
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            ok = [s for s in self.slots if s[0].numel() >= nbytes and s[1].device == device]
+            if not ok:
+                raise RuntimeError("td job tables must exist before a stream capture: run one training step eagerly first")
+            slot = ok[0]
+            self.slots.remove(slot)
+            self.retired.append(slot)  # alive (and untouched) for as long as the graph may replay
+            return slot[0], slot[1], (lambda: None)
+        if len(self.slots) < self.RING or self.cap < nbytes:
+            self._grow(nbytes, device)
+        slot = self.slots[self.next % len(self.slots)]
+        self.next += 1
+        if slot[2] is not None:
+            slot[2].synchronize()  # the launch that last used this pair (RING calls ago) must have consumed it
+
+        def done():
+            ev = torch.cuda.Event()
+            ev.record()
+            slot[2] = ev
+
+        return slot[0], slot[1], done
+
+
+job_tables = _JobTables()
+
+
 def conv_wgrad_batch(jobs) -> list:
     """jobs: iterable of (g NHWC [N,Ho,Wo,Co], x NHWC [N,H,W,C], R, S, stride, pad, scale [Co] fp32 | None, ci_real).
     One launch (two when pointwise and spatial kernels are mixed); returns dW per job in the parameter layout
@@ -143,7 +191,11 @@ def conv_wgrad_batch(jobs) -> list:
         a.g, a.src, a.dW, a.scale = g.data_ptr(), x.data_ptr(), dw.data_ptr(), (scale.data_ptr() if scale is not None else None)
         a.d = _desc(N, H, W, Cs, Ho, Wo, R, S, stride, pad, 0, Co, Co)
         a.ldg, a.ci_real = Co, ci_real
-    check(_hip.lib().td_conv_wgrad_batch(arr, len(jobs), dtype_code(jobs[0][0].dtype), stream_ptr()), "td_conv_wgrad_batch")
+    nbytes = _hip.lib().td_conv_wgrad_batch_table_bytes(len(jobs))
+    th, td_, done = job_tables.take(nbytes, jobs[0][0].device)
+    check(_hip.lib().td_conv_wgrad_batch(arr, len(jobs), dtype_code(jobs[0][0].dtype), th.data_ptr(), td_.data_ptr(), nbytes, stream_ptr()),
+          "td_conv_wgrad_batch")
+    done()
     return outs
 
 
