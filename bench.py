@@ -381,7 +381,7 @@ def main():
         value = clips / elapsed
         step_tflop = ALGO_TFLOP_PER_CLIP.get(a.workload)
         out = {
-            "metric": "training clips/sec (fwd+bwd)", "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
+            "metric": ("training clips/sec (fwd+bwd) at T=100 k=4 res=352, 1/2/4/8 MI355X" if a.workload == "cfg3" else "training clips/sec (fwd+bwd)"), "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "execution": execution, "gradient_exchange": (None if not distributed else ("torch DDP (find_unused_parameters)" if a.ddp else f"flat all-reduce, {a.grad_wire_dtype} on the wire")),
