@@ -90,3 +90,21 @@ def test_criterion_matches_oracle(built):
     assert set(got) == set(ref) and len(got) == 24
     for k in ref:
         assert torch.allclose(got[k], ref[k], rtol=1e-5, atol=1e-6), k
+
+
+def test_pmc_traffic_json_is_reproducible_from_the_committed_counter_sums(tmp_path):
+    """profiles/r01_pmc_traffic.json (read by bench.py for roofline.traffic) is exactly tools/pmc_traffic.py over the
+    committed per-kernel FETCH_SIZE / WRITE_SIZE sums."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "t.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), os.path.join(root, "profiles", "r01_pmc_FETCH_SIZE_per_kernel.csv"),
+                    os.path.join(root, "profiles", "r01_pmc_WRITE_SIZE_per_kernel.csv"), str(out)], check=True, stdout=subprocess.DEVNULL)
+    got, want = json.load(open(out)), json.load(open(os.path.join(root, "profiles", "r01_pmc_traffic.json")))
+    assert got == want
+    fam = want["td::pw_resident_kernel<*>"]
+    assert fam["fetch_bytes_per_launch"] > 0 and fam["write_bytes_per_launch"] > 0
