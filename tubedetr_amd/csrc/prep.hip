@@ -42,10 +42,72 @@ __global__ void weight_prep_kernel(const float* W, const float* bn_w, const floa
 
 // One launch for all layers: workgroup -> (item, 16-channel co tile, 32-channel ci tile); the W slab of the tile
 // (16 x [32 ci x RS] contiguous floats) goes through LDS so reads and both writes run over contiguous segments.
+// NRS = taps per group as a compile-time constant (1: linears / 1x1 convs, 9: 3x3; 0: generic, e.g. the 7x7 stem) so
+// the index arithmetic folds to shifts and constant divisions; bf16 results leave as packed pairs (4-byte stores).
+template <typename T, int NRS>
+__device__ __forceinline__ void prep_group(const td_prep_item& I, float (&tile)[16][32 * 9 + 1], const float* sc16, int co0, int ci0,
+                                           int rs0, int nrs_rt, int t) {
+  const int nrs = NRS ? NRS : nrs_rt;
+  const int RS = I.RS;
+  T* wf = (T*)I.w_fwd;
+  T* wd = (T*)I.w_dgrad;
+  // load: 16 co x (32 ci x nrs taps); for a full-width tile the 32*nrs floats of one co are contiguous in W
+  for (int idx = t; idx < 16 * 32 * nrs; idx += 256) {
+    const int c = idx / (32 * nrs), k = idx - c * (32 * nrs);
+    const int cil = k / nrs, r = k - cil * nrs;
+    const int ci = ci0 + cil, co = co0 + c;
+    float v = 0.f;
+    if (co < I.Co && ci < I.Ci) v = I.W[((size_t)co * I.Ci + ci) * RS + rs0 + r] * sc16[c];
+    tile[c][cil * 9 + r] = v;
+  }
+  __syncthreads();
+  if constexpr (sizeof(T) == 2) {
+    // forward layout [Co_alloc][RS][Cpad]: pairs of consecutive ci
+    for (int idx = t; idx < 16 * nrs * 16; idx += 256) {
+      const int cp = idx & 15, r = (idx >> 4) % nrs, c = idx / (16 * nrs);
+      const int co = co0 + c, ci = ci0 + 2 * cp;
+      if (co < I.Co_alloc && ci + 1 < I.Cpad) {
+        const uint32_t v = (uint32_t)f32_to_bf16(tile[c][(2 * cp) * 9 + r]) | ((uint32_t)f32_to_bf16(tile[c][(2 * cp + 1) * 9 + r]) << 16);
+        *(uint32_t*)((u16*)wf + ((size_t)co * RS + rs0 + r) * I.Cpad + ci) = v;
+      } else if (co < I.Co_alloc && ci < I.Cpad) {
+        Elem<T>::store(wf, ((size_t)co * RS + rs0 + r) * I.Cpad + ci, tile[c][(2 * cp) * 9 + r]);
+      }
+    }
+    // dgrad layout [Ci][RS][Co_alloc]: pairs of consecutive co
+    if (wd) {
+      for (int idx = t; idx < 32 * nrs * 8; idx += 256) {
+        const int cp = idx & 7, r = (idx >> 3) % nrs, cil = idx / (8 * nrs);
+        const int co = co0 + 2 * cp, ci = ci0 + cil;
+        if (ci < I.Ci && co + 1 < I.Co_alloc) {
+          const uint32_t v = (uint32_t)f32_to_bf16(tile[2 * cp][cil * 9 + r]) | ((uint32_t)f32_to_bf16(tile[2 * cp + 1][cil * 9 + r]) << 16);
+          *(uint32_t*)((u16*)wd + ((size_t)ci * RS + rs0 + r) * I.Co_alloc + co) = v;
+        } else if (ci < I.Ci && co < I.Co_alloc) {
+          Elem<T>::store(wd, ((size_t)ci * RS + rs0 + r) * I.Co_alloc + co, tile[2 * cp][cil * 9 + r]);
+        }
+      }
+    }
+  } else {
+    for (int idx = t; idx < 16 * nrs * 32; idx += 256) {
+      const int cil = idx & 31, r = (idx >> 5) % nrs, c = idx / (32 * nrs);
+      const int co = co0 + c, ci = ci0 + cil;
+      if (co < I.Co_alloc && ci < I.Cpad) Elem<T>::store(wf, ((size_t)co * RS + rs0 + r) * I.Cpad + ci, tile[c][cil * 9 + r]);
+    }
+    if (wd) {
+      for (int idx = t; idx < 32 * nrs * 16; idx += 256) {
+        const int c = idx & 15, r = (idx >> 4) % nrs, cil = idx / (16 * nrs);
+        const int co = co0 + c, ci = ci0 + cil;
+        if (co < I.Co_alloc && ci < I.Ci) Elem<T>::store(wd, ((size_t)ci * RS + rs0 + r) * I.Co_alloc + co, tile[c][cil * 9 + r]);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void prep_batch_kernel(const td_prep_item* items, int n_items) {
   __shared__ float tile[16][32 * 9 + 1];
-  // locate the item of this workgroup (items are few: linear scan over the prefix sums)
+  __shared__ float sc16[16];
+  // locate the item of this workgroup (binary search over the items' first workgroup index)
   int it = 0;
   {
     int lo = 0, hi = n_items - 1;
@@ -62,38 +124,18 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(const td_prep_item* ite
   const int co0 = cot * 16, ci0 = cit * 32;
   const int RS = I.RS;
   const int t = threadIdx.x;
-  T* wf = (T*)I.w_fwd;
-  T* wd = (T*)I.w_dgrad;
-  for (int rs0 = 0; rs0 < RS; rs0 += 9) {  // taps in groups of <= 9 (7x7 stem: 6 groups)
-    const int nrs = min(9, RS - rs0);
-    // load: 16 co x (32 ci x nrs taps)
-    for (int idx = t; idx < 16 * 32 * nrs; idx += 256) {
-      const int c = idx / (32 * nrs), k = idx - c * (32 * nrs);
-      const int ci = ci0 + k / nrs, rs = rs0 + k % nrs;
-      const int co = co0 + c;
-      float v = 0.f;
-      if (co < I.Co && ci < I.Ci) {
-        const float sc = I.bn_w ? I.bn_w[co] * rsqrtf(I.bn_rv[co] + 1e-5f) : 1.f;
-        v = I.W[((size_t)co * I.Ci + ci) * RS + rs] * sc;
-      }
-      tile[c][(k / nrs) * 9 + (k % nrs)] = v;
-    }
-    __syncthreads();
-    // forward layout [Co_alloc][RS][Cpad]: runs of 32 ci
-    for (int idx = t; idx < 16 * nrs * 32; idx += 256) {
-      const int cil = idx & 31, r = (idx >> 5) % nrs, c = idx / (32 * nrs);
-      const int co = co0 + c, ci = ci0 + cil;
-      if (co < I.Co_alloc && ci < I.Cpad) Elem<T>::store(wf, ((size_t)co * RS + rs0 + r) * I.Cpad + ci, tile[c][cil * 9 + r]);
-    }
-    // dgrad layout [Ci][RS][Co_alloc]: runs of 16 co
-    if (wd) {
-      for (int idx = t; idx < 32 * nrs * 16; idx += 256) {
-        const int c = idx & 15, r = (idx >> 4) % nrs, cil = idx / (16 * nrs);
-        const int co = co0 + c, ci = ci0 + cil;
-        if (co < I.Co_alloc && ci < I.Ci) Elem<T>::store(wd, ((size_t)ci * RS + rs0 + r) * I.Co_alloc + co, tile[c][cil * 9 + r]);
-      }
-    }
-    __syncthreads();
+  if (t < 16) {
+    const int co = co0 + t;
+    sc16[t] = (co < I.Co && I.bn_w) ? I.bn_w[co] * rsqrtf(I.bn_rv[co] + 1e-5f) : 1.f;
+  }
+  __syncthreads();
+  if (RS == 1) {
+    prep_group<T, 1>(I, tile, sc16, co0, ci0, 0, 1, t);
+  } else if (RS == 9) {
+    prep_group<T, 9>(I, tile, sc16, co0, ci0, 0, 9, t);
+  } else {
+    for (int rs0 = 0; rs0 < RS; rs0 += 9)  // taps in groups of <= 9 (7x7 stem: 6 groups)
+      prep_group<T, 0>(I, tile, sc16, co0, ci0, rs0, min(9, RS - rs0), t);
   }
   if (cit == 0 && t < 16) {
     const int co = co0 + t;
