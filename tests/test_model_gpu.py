@@ -170,3 +170,69 @@ def test_dedupe_slow_frames_is_exact():
                      model.backbone[0].body.layer3[5].conv2.weight.grad.clone(), model.input_proj.weight.grad.clone())
     for a, b in zip(res[False], res[True]):
         assert (a - b).abs().max() <= 1e-5 * max(1.0, b.abs().max().item())
+
+
+def test_hip_graph_replay_matches_eager_step():
+    """bench.py measures the step replayed from a HIP graph: the replay (static inputs, device-side dropout step
+    counter, batched weight-gradient job table re-uploaded by a captured copy node, in-place weight re-preparation) must
+    produce the loss and the gradients of the same step launched eagerly.  Train mode, bf16; the dropout masks of
+    replay i are those of eager step i because both derive them from (seed drawn at capture/launch, step counter)."""
+    import tubedetr_amd
+    from oracle.weights import synthetic_batch
+    from tubedetr_amd import _hip
+    from tubedetr_amd.functional import invalidate_prepared
+    from tubedetr_amd.harness import FixedTokenizer, batch_to, forward_step
+    from tubedetr_amd.models import build_model
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model, criterion, weight_dict = build_model(tubedetr_amd.default_args(stride=2, compute_dtype=torch.bfloat16))
+    model.to(dev).eval()  # dropout off: the eager and the captured run must then agree up to fp32-atomic ordering
+    batch = batch_to(synthetic_batch(T=6, res=64, k=2, L=5, seed=4), dev)
+    model.transformer.tokenizer = FixedTokenizer(batch["input_ids"], batch["attention_mask"])
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def run():
+        invalidate_prepared()
+        loss, _, _, _ = forward_step(model, criterion, weight_dict, batch)
+        loss.backward()
+        return loss
+
+    os.environ["TD_TEXT_STREAM"] = "0"  # single-stream capture, as bench.py does
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for p in params:
+                    p.grad = None
+                eager_loss = run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        eager = {i: p.grad.detach().float().clone() for i, p in enumerate(params) if p.grad is not None}
+        for p in params:
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_loss = run()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("TD_TEXT_STREAM", None)
+        _hip.lib().td_set_dropout_step_counter(None)
+    assert abs(g_loss.item() - eager_loss.item()) <= 2e-3 * abs(eager_loss.item())
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    checked, bad = 0, []
+    for i, p in enumerate(params):
+        if p.grad is None:
+            assert i not in eager, names[i]
+            continue
+        a, b = p.grad.detach().float(), eager[i]
+        scale = b.abs().max().clamp_min(1e-4)  # (RoBERTa's key biases have a mathematically zero gradient: ~1e-8 noise)
+        err = ((a - b).abs().max() / scale).item()
+        if not err < 2e-2:
+            bad.append((names[i], err, scale.item()))
+        checked += 1
+    assert not bad, bad[:12]
+    assert checked > 300
