@@ -4,16 +4,26 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
 torch.distributed.run with one rank per GPU (RCCL).  A "step" = one pass of the hot path over one synthetic clip
 per GPU: the two model calls of engine.py:67-80 (video-text encoder, then space-time decoder), the criterion, and
-the backward pass (DDP gradient all-reduce overlapped when N>1).  Rank 0 prints ONE JSON line.
+the backward pass; at N>1 followed by ONE flat all-reduce of the gradients (tubedetr_amd/distributed.py; `--ddp`
+uses torch DistributedDataParallel like main.py:372-376 instead).  Rank 0 prints ONE JSON line.
 
 Workload at N=1: BASELINE.json configs[2] (the config the metric is quoted on): T=100 frames, stride k=4,
 res=352, L=30 text tokens, 1 clip per GPU, bf16 MFMA kernels with fp32 accumulation, random-init weights,
-train mode (dropout active).  Inputs are generated on the device before the timed region.
+train mode (dropout active), weights re-prepared every step (as after an optimizer step), all 125 trunk-forward
+frames executed (`--dedupe` skips the 25 slow frames inside the fast pass).  Inputs are generated on the device before
+the timed region.
+
+Execution: the whole step is captured once in a single-stream HIP graph and replayed (`--no-graph`: eager launches,
+host-bound).  At N=1 the measurement runs in a child process; if that process dies (a GPU memory fault was seen
+intermittently with the forked two-stream graph, `--text-stream`), the parent re-measures with eager launches, so a
+bench line is always produced; `attempts` in the JSON records what happened.
 
 Extra legs (rank 0, after the timed region, not part of `value`):
-  roofline     : `--roofline-steps` more identical steps with HIP events recorded on the launch stream around every
-                 launch of the dominant kernel (the implicit-GEMM conv/linear MFMA kernel); achieved = algorithmic
-                 FLOPs of those launches / their summed duration.
+  roofline     : `--roofline-steps` more identical steps, launched eagerly, with HIP events recorded on the launch
+                 stream around every launch of the MFMA kernel families; per family achieved = algorithmic FLOPs or
+                 algorithmic HBM bytes / summed duration, bound = the roof it sits closer to, traffic = PMC-measured
+                 HBM bytes per launch (profiles/r01_pmc_traffic.json).  `roofline` is the family with the largest
+                 share of the step, the others follow in `other_mfma_kernels`.
   cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on the host cores on a bounded
                  sample (a T=`--cpu-frames` clip of the same resolution, fwd+bwd) and scaled to T=100.
 """
