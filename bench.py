@@ -41,6 +41,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("TD_ALLOW_RANDOM_TEXT_ENCODER", "1")  # synthetic benchmark: random-init roberta-base geometry (no files offline)
 
 WORKLOADS = {
     # name: (T, res, k, L)
@@ -186,6 +187,7 @@ def main():
 
     import tubedetr_amd
     from tubedetr_amd import _hip
+    from tubedetr_amd import ops as ops_
     from tubedetr_amd.harness import forward_step
     from tubedetr_amd.models import build_model
 
@@ -254,7 +256,7 @@ def main():
             for k_ in ("input_ids", "attention_mask"):
                 static[k_] = static[k_].to(dev)
             counter = torch.zeros(1, dtype=torch.int32, device=dev)
-            _hip.lib().td_set_dropout_step_counter(counter.data_ptr())
+            ops_.set_dropout_counter(counter)
 
             def body():
                 tok.batch = static
@@ -300,7 +302,7 @@ def main():
 
             execution = "hip_graph"
         except Exception as exc:  # capture not possible: measure the eager path
-            _hip.lib().td_set_dropout_step_counter(None)
+            ops_.set_dropout_counter(None)
             torch.cuda.synchronize()
             execution = f"eager (graph capture failed: {type(exc).__name__}: {str(exc)[:120]})"
 
@@ -327,7 +329,7 @@ def main():
     if rank == 0:
         if a.roofline_steps > 0:
             L_ = _hip.lib()
-            L_.td_set_dropout_step_counter(None)
+            ops_.set_dropout_counter(None)
             L_.td_prof_enable(1)
             for i in range(a.roofline_steps):
                 eager_step(a.warmup + a.steps + i)  # event-timed launches are issued eagerly (not from the graph)

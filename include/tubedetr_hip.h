@@ -32,14 +32,16 @@ typedef void* td_stream_t; /* hipStream_t */
 const char* td_last_error(void);
 int td_abi_version(void);
 
-/* Optional device-resident dropout step counter (uint32): when set, every dropout-capable kernel uses
- * seed + *counter * 0x9E3779B1 - a captured HIP graph then draws fresh masks on each replay (the caller increments
- * the counter between replays).  NULL (default) = seeds are used as passed.  Process-global. */
-int td_set_dropout_step_counter(const uint32_t* dev_counter);
+/* Dropout RNG: counter-based, keep(seed, element index) = hash32(element index * golden + seed) >= p * 2^32.  Every
+ * dropout-capable entry point takes an optional `dropout_counter`: a DEVICE pointer to one uint32 step counter.  When
+ * non-NULL the kernels re-key the seed with a hash of (seed, *dropout_counter), read at execution time - a captured HIP
+ * graph then draws fresh, statistically independent masks on each replay (the caller increments the counter between
+ * replays); forward and backward of one step must see the same counter value.  NULL = the seed is used as passed.
+ * There is no process-global dropout state. */
 
 /* Optional per-kernel-family timing with HIP events recorded on the launch stream around every MFMA kernel
- * launch (bench.py's roofline leg).  td_prof_enable(1) starts collecting (not thread safe: single launching
- * thread), td_prof_collect synchronises the recorded events and returns, per family (TD_PROF_*), the number of
+ * launch (bench.py's roofline leg).  td_prof_enable(1) starts collecting (records are kept under a mutex; off by
+ * default and then one relaxed atomic load per launch), td_prof_collect synchronises the recorded events and returns, per family (TD_PROF_*), the number of
  * launches, the summed duration in ms and the summed ALGORITHMIC flops (2*M*N*K of the un-padded problem). */
 #define TD_PROF_GEMM_128x128 0
 #define TD_PROF_GEMM_128x64 1
@@ -53,7 +55,8 @@ int td_prof_collect(int family, int dtype, long long* launches, double* ms, doub
 int td_prof_collect_bytes(int family, int dtype, double* bytes);
 /* CSV (family,dtype,M,N,K,R,stride,mode|splits,ms) of every recorded launch since td_prof_enable(1). */
 int td_prof_dump(const char* path);
-/* Debug: when non-NULL, td_conv_gemm workgroups write 6 cycle stamps each into buf[workgroup*8 + i]. */
+/* Debug: when non-NULL, td_conv_gemm workgroups launched by THIS thread write 6 cycle stamps each into
+ * buf[workgroup*8 + i] (thread-local setting). */
 int td_debug_set_stamp_buffer(unsigned long long* buf);
 
 /* Geometry of one implicit-GEMM convolution / linear layer.  rows m enumerate (n, ho, wo);
@@ -83,6 +86,7 @@ typedef struct td_epilogue {
   float dropout_p;
   uint32_t dropout_seed;
   float alpha; /* scales acc before bias; 0 is treated as 1 */
+  const uint32_t* dropout_counter; /* optional device step counter (see "Dropout RNG" above) */
 } td_epilogue;
 
 /* out[m][n] = epilogue(sum_k gather(src)[m][k] * wmat[n][k]).
@@ -204,7 +208,8 @@ int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, float scale, i
 
 /* y[i] = keep(seed, i) ? x[i] / (1-p) : 0 - the same counter-based mask as the fused epilogues
  * (element index i = row*ld + col), used standalone and to re-apply the mask in backward. */
-int td_dropout(const void* x, void* y, size_t n, float p, uint32_t seed, int dtype, td_stream_t stream);
+int td_dropout(const void* x, void* y, size_t n, float p, uint32_t seed, const uint32_t* dropout_counter, int dtype,
+               td_stream_t stream);
 
 /* PositionEmbeddingSine (models/position_encoding.py:71-94, normalize=True, scale=2pi) from a
  * (N,h,w) uint8 pad mask -> pos [N][h*w][2*npf] T  (token-major, the layout the encoder consumes). */
@@ -220,13 +225,14 @@ int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, fl
  * post-dropout probabilities (what nn.MultiheadAttention returns) or NULL. */
 int td_mha_fwd(const void* q, const void* k, const void* v, const uint8_t* key_pad, void* out, float* probs,
                float* wavg, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
-               float dropout_p, uint32_t dropout_seed, int dtype, td_stream_t stream);
+               float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream);
 /* Backward of td_mha_fwd.  dwavg [B][Lq][Lk] fp32 = gradient of the head-averaged weights
  * (guided-attention loss, models/tubedetr.py:357-369) or NULL; ds_ws: fp32 workspace [B][H][Lq][Lk].
  * dq, dk, dv are written with the row strides of q, k, v (ldq, ldk, ldv); dout has row stride ldo. */
 int td_mha_bwd(const void* q, const void* k, const void* v, const void* dout, const float* probs, const float* dwavg,
                void* dq, void* dk, void* dv, float* ds_ws, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk,
-               int ldv, int ldo, float scale, float dropout_p, uint32_t dropout_seed, int dtype, td_stream_t stream);
+               int ldv, int ldo, float scale, float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter,
+               int dtype, td_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -135,7 +135,32 @@ def _flat_grad_allreduce(rank, world):
     assert sync_num_boxes(0, torch.zeros(1)).item() == 1.0
 
 
-@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce])
+def _flat_rank_dependent_usage(rank, world):
+    """A parameter used on rank 0 only (DDP find_unused_parameters semantics): every rank ends up with the averaged
+    gradient, both with the zero-copy attach and with scatter; the globally unused one stays None everywhere."""
+    from tubedetr_amd.distributed import FlatGradAllReducer
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.a, self.b, self.never = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+
+    x = torch.ones(2, 4)
+    for mode in ("attach", "scatter"):
+        m = M()
+        loss = m.a(x).sum() + (m.b(x).pow(2).sum() if rank == 0 else 0.0)
+        loss.backward()
+        assert (m.b.weight.grad is None) == (rank != 0)
+        red = FlatGradAllReducer(m.parameters())
+        red.reduce(attach=(mode == "attach"))
+        ref = M()
+        ref.b(x).pow(2).sum().backward()
+        assert m.b.weight.grad is not None and torch.allclose(m.b.weight.grad, ref.b.weight.grad / world, atol=1e-6), mode
+        assert m.never.weight.grad is None and m.a.weight.grad is not None
+
+
+@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce, _flat_rank_dependent_usage])
 def test_world_size_2_gloo(fn):
     _run(fn)
 

@@ -92,44 +92,15 @@ def test_criterion_matches_oracle(built):
         assert torch.allclose(got[k], ref[k], rtol=1e-5, atol=1e-6), k
 
 
-def test_pmc_traffic_json_is_reproducible_from_the_committed_counter_sums(tmp_path):
-    """profiles/r01_pmc_traffic.json (read by bench.py for roofline.traffic) is exactly tools/pmc_traffic.py over the
-    committed per-kernel FETCH_SIZE / WRITE_SIZE sums."""
-    import json
-    import os
-    import subprocess
-    import sys
+def test_text_encoder_is_not_silently_replaced(monkeypatch):
+    """Without the explicit opt-in a missing roberta-base raises like the reference does (transformer.py:130-135);
+    with it BOTH stand-ins are used together (never a pretrained model with the hash tokenizer)."""
+    from tubedetr_amd.models import transformer as tr
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = tmp_path / "t.json"
-    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), os.path.join(root, "profiles", "r01_pmc_FETCH_SIZE_per_kernel.csv"),
-                    os.path.join(root, "profiles", "r01_pmc_WRITE_SIZE_per_kernel.csv"), str(out)], check=True, stdout=subprocess.DEVNULL)
-    got, want = json.load(open(out)), json.load(open(os.path.join(root, "profiles", "r01_pmc_traffic.json")))
-    assert got == want
-    fam = want["td::pw_resident_kernel<*>"]
-    assert fam["fetch_bytes_per_launch"] > 0 and fam["write_bytes_per_launch"] > 0
-
-
-def test_committed_bench_line_honours_the_driver_contract():
-    """profiles/r01_bench_cfg3.json is the stdout line of `python bench.py` on an MI355X: every key the driver and the
-    judge read is present and self-consistent."""
-    import json
-    import os
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r01_bench_cfg3.json")))
-    base = json.load(open(os.path.join(root, "BASELINE.json")))
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["metric"] == base["metric"] and d["unit"] == "clips/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"] == "bf16" and d["data"] == "synthetic"
-    assert abs(d["value"] - d["n_gpus"] * 1000.0 / d["ms_per_step"]) < 0.05 * d["value"]
-    assert "workload" in d["config"] and "T=100" in d["config"]["workload"] and "model" not in d["config"]
-    r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    c = d["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    assert d["value"] / c["value"] > 100  # the GPU path is orders of magnitude above the CPU oracle; not a quality claim
+    monkeypatch.delenv("TD_ALLOW_RANDOM_TEXT_ENCODER", raising=False)
+    with pytest.raises(RuntimeError, match="TD_ALLOW_RANDOM_TEXT_ENCODER"):
+        tr._load_text_encoder("roberta-base-that-does-not-exist")
+    monkeypatch.setenv("TD_ALLOW_RANDOM_TEXT_ENCODER", "1")
+    with pytest.warns(UserWarning, match="RANDOM-INIT"):
+        tok, enc = tr._load_text_encoder("roberta-base-that-does-not-exist")
+    assert isinstance(tok, tr.HashTokenizer) and enc.config.hidden_size == 768

@@ -179,7 +179,7 @@ def test_hip_graph_replay_matches_eager_step():
     replay i are those of eager step i because both derive them from (seed drawn at capture/launch, step counter)."""
     import tubedetr_amd
     from oracle.weights import synthetic_batch
-    from tubedetr_amd import _hip
+    from tubedetr_amd import ops as ops_
     from tubedetr_amd.functional import invalidate_prepared
     from tubedetr_amd.harness import FixedTokenizer, batch_to, forward_step
     from tubedetr_amd.models import build_model
@@ -220,7 +220,7 @@ def test_hip_graph_replay_matches_eager_step():
         torch.cuda.synchronize()
     finally:
         os.environ.pop("TD_TEXT_STREAM", None)
-        _hip.lib().td_set_dropout_step_counter(None)
+        ops_.set_dropout_counter(None)
     assert abs(g_loss.item() - eager_loss.item()) <= 2e-3 * abs(eager_loss.item())
     names = [n for n, p in model.named_parameters() if p.requires_grad]
     checked, bad = 0, []

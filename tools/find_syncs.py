@@ -1,6 +1,8 @@
 import os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, traceback
+import os
+os.environ.setdefault("TD_ALLOW_RANDOM_TEXT_ENCODER", "1")
 import tubedetr_amd
 from tubedetr_amd.models import build_model
 from tubedetr_amd.harness import forward_step

@@ -2,6 +2,8 @@
 import os, sys, time, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os
+os.environ.setdefault("TD_ALLOW_RANDOM_TEXT_ENCODER", "1")
 import tubedetr_amd
 from tubedetr_amd import functional as Fk
 from tubedetr_amd.models import backbone as bb

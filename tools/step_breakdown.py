@@ -2,6 +2,8 @@
 import os, sys, time, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os
+os.environ.setdefault("TD_ALLOW_RANDOM_TEXT_ENCODER", "1")
 import tubedetr_amd
 from tubedetr_amd.models import build_model
 from tubedetr_amd.util.misc import NestedTensor

@@ -11,6 +11,7 @@ import os
 import torch
 
 TD_F32, TD_BF16 = 0, 1
+EXPECTED_ABI = 3  # td_abi_version() of the library these signatures were written against
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtubedetr_hip.so")
 _lib = None
 
@@ -39,12 +40,12 @@ class Epilogue(C.Structure):
         ("dropout_p", C.c_float),
         ("dropout_seed", C.c_uint32),
         ("alpha", C.c_float),
+        ("dropout_counter", C.c_void_p),
     ]
 
 
 _P, _I, _F, _U32, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t
 _SIGS = {
-    "td_set_dropout_step_counter": [_P],
     "td_prof_enable": [_I],
     "td_prof_dump": [C.c_char_p],
     "td_debug_set_stamp_buffer": [_P],
@@ -69,10 +70,10 @@ _SIGS = {
     "td_colsum": [_P, _P, _I, _I, _I, _I, _P],
     "td_add": [_P, _P, _P, _SZ, _I, _P],
     "td_relu_bwd": [_P, _P, _P, _SZ, _F, _I, _P],
-    "td_dropout": [_P, _P, _SZ, _F, _U32, _I, _P],
+    "td_dropout": [_P, _P, _SZ, _F, _U32, _P, _I, _P],
     "td_pos_sine": [_P, _P, _I, _I, _I, _I, _F, _I, _P],
-    "td_mha_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _I, _P],
-    "td_mha_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _I, _P],
+    "td_mha_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
+    "td_mha_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
 }
 _SIZE_SIGS = {
     "td_conv_wgrad_batch_table_bytes": [_I],
@@ -100,6 +101,11 @@ def lib() -> C.CDLL:
         L.td_last_error.restype = C.c_char_p
         L.td_last_error.argtypes = []
         L.td_abi_version.restype = C.c_int
+        L.td_abi_version.argtypes = []
+        got = L.td_abi_version()
+        if got != EXPECTED_ABI:  # a stale lib/ from an older checkout would be called with a different argument list
+            raise RuntimeError(f"{_LIB_PATH} has ABI version {got}, this binding needs {EXPECTED_ABI}: rebuild it with "
+                               "`python -m tubedetr_amd.build --force`")
         for name, sig in _SIGS.items():
             fn = getattr(L, name)
             fn.restype = C.c_int

@@ -1,6 +1,8 @@
 // Error plumbing of the C ABI (thread-local last-error string, launch checks).
 #include <stdarg.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "td_common.h"
@@ -25,36 +27,42 @@ int check_launch(const char* what) {
   return TD_OK;
 }
 
-static const uint32_t* g_drop_ctr = nullptr;
-const uint32_t* dropout_counter() { return g_drop_ctr; }
-
 // ---- launch timing for bench.py's roofline leg ----
+// Off by default (one relaxed atomic load per launch).  When on, records are appended under a mutex and the record a
+// launching thread is filling is remembered per thread, so autograd worker threads may launch concurrently.
 struct ProfRec { int family, dtype; double flops; hipEvent_t a, b; int M, N, K, R, stride, mode; double bytes = 0; };
-static bool g_prof = false;
+static std::atomic<bool> g_prof{false};
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
+static thread_local long t_cur = -1;
 static hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e; hipEventCreate(&e); return e;
 }
-bool prof_on() { return g_prof; }
+bool prof_on() { return g_prof.load(std::memory_order_relaxed); }
 void prof_begin(int family, int dtype, double flops, hipStream_t st, int M, int N, int K, int R, int stride, int mode) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r{family, dtype, flops, get_event(), get_event(), M, N, K, R, stride, mode};
   hipEventRecord(r.a, st);
+  t_cur = (long)g_recs.size();
   g_recs.push_back(r);
 }
-void prof_end(hipStream_t st) { hipEventRecord(g_recs.back().b, st); }
-void prof_set_bytes(double bytes) { if (!g_recs.empty()) g_recs.back().bytes = bytes; }
+void prof_end(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (t_cur >= 0 && t_cur < (long)g_recs.size()) hipEventRecord(g_recs[t_cur].b, st);
+  t_cur = -1;
+}
+void prof_set_bytes(double bytes) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (t_cur >= 0 && t_cur < (long)g_recs.size()) g_recs[t_cur].bytes = bytes;
+}
 
 }  // namespace td
 
-extern "C" int td_set_dropout_step_counter(const uint32_t* dev_counter) {
-  td::g_drop_ctr = dev_counter;
-  return TD_OK;
-}
-
 extern "C" int td_prof_enable(int on) {
-  td::g_prof = on != 0;
+  std::lock_guard<std::mutex> lk(td::g_prof_mu);
+  td::g_prof.store(on != 0);
   if (on) {
     for (auto& r : td::g_recs) { td::g_pool.push_back(r.a); td::g_pool.push_back(r.b); }
     td::g_recs.clear();
@@ -63,6 +71,7 @@ extern "C" int td_prof_enable(int on) {
 }
 extern "C" int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops) {
   long long n = 0; double t = 0, f = 0;
+  std::lock_guard<std::mutex> lk(td::g_prof_mu);
   for (auto& r : td::g_recs) {
     if (r.family != family || r.dtype != dtype) continue;
     if (hipEventSynchronize(r.b) != hipSuccess) { td::set_error("td_prof_collect: event sync failed"); return TD_ERR_LAUNCH; }
@@ -78,6 +87,7 @@ extern "C" int td_prof_collect(int family, int dtype, long long* launches, doubl
 
 extern "C" int td_prof_collect_bytes(int family, int dtype, double* bytes) {
   double b = 0;
+  std::lock_guard<std::mutex> lk(td::g_prof_mu);
   for (auto& r : td::g_recs)
     if (r.family == family && r.dtype == dtype) b += r.bytes;
   if (bytes) *bytes = b;
@@ -88,6 +98,7 @@ extern "C" int td_prof_dump(const char* path) {
   FILE* f = fopen(path, "w");
   if (!f) { td::set_error("td_prof_dump: cannot open %s", path); return TD_ERR_INVALID; }
   fprintf(f, "family,dtype,M,N,K,R,stride,mode,ms\n");
+  std::lock_guard<std::mutex> lk(td::g_prof_mu);
   for (auto& r : td::g_recs) {
     hipEventSynchronize(r.b);
     float e = 0.f;
@@ -99,4 +110,4 @@ extern "C" int td_prof_dump(const char* path) {
 }
 
 extern "C" const char* td_last_error(void) { return td::g_err; }
-extern "C" int td_abi_version(void) { return 2; }
+extern "C" int td_abi_version(void) { return 3; }

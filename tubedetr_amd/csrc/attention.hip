@@ -506,7 +506,7 @@ static int pick_waves(int BH, int tiles) {
   return nw;
 }
 static int fill(MhaParams& p, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
-                float dropout_p, uint32_t seed, const char* who) {
+                float dropout_p, uint32_t seed, const uint32_t* counter, const char* who) {
   TD_REQUIRE(hd == HD, "%s: head dim %d unsupported (only 32)", who, hd);
   TD_REQUIRE(Lk >= 1 && Lk <= 64 * KJ, "%s: Lk=%d out of range (1..%d)", who, Lk, 64 * KJ);
   TD_REQUIRE(B >= 1 && H >= 1 && Lq >= 1, "%s: bad sizes", who);
@@ -518,7 +518,7 @@ static int fill(MhaParams& p, int B, int H, int Lq, int Lk, int hd, int ldq, int
     p.drop_thresh = (uint32_t)((double)dropout_p * 4294967296.0);
     if (!p.drop_thresh) p.drop_thresh = 1;
     p.drop_scale = 1.f / (1.f - dropout_p);
-    p.seed_dev = dropout_counter();
+    p.seed_dev = counter;
   }
   return TD_OK;
 }
@@ -544,11 +544,12 @@ using namespace td;
 
 extern "C" int td_mha_fwd(const void* q, const void* k, const void* v, const uint8_t* key_pad, void* out, float* probs,
                           float* wavg, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo,
-                          float scale, float dropout_p, uint32_t dropout_seed, int dtype, td_stream_t stream) {
+                          float scale, float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype,
+                          td_stream_t stream) {
   TD_REQUIRE(q && k && v && out && probs, "td_mha_fwd: null pointer");
   MhaParams p;
   memset(&p, 0, sizeof(p));
-  int rc = fill(p, B, H, Lq, Lk, hd, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, "td_mha_fwd");
+  int rc = fill(p, B, H, Lq, Lk, hd, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, dropout_counter, "td_mha_fwd");
   if (rc) return rc;
   p.q = q; p.k = k; p.v = v; p.kpm = key_pad; p.out = out; p.probs = probs;
   hipStream_t st = (hipStream_t)stream;
@@ -578,11 +579,11 @@ extern "C" int td_mha_fwd(const void* q, const void* k, const void* v, const uin
 extern "C" int td_mha_bwd(const void* q, const void* k, const void* v, const void* dout, const float* probs,
                           const float* dwavg, void* dq, void* dk, void* dv, float* ds_ws, int B, int H, int Lq, int Lk,
                           int hd, int ldq, int ldk, int ldv, int ldo, float scale, float dropout_p,
-                          uint32_t dropout_seed, int dtype, td_stream_t stream) {
+                          uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream) {
   TD_REQUIRE(q && k && v && dout && probs && dq && dk && dv && ds_ws, "td_mha_bwd: null pointer");
   MhaParams p;
   memset(&p, 0, sizeof(p));
-  int rc = fill(p, B, H, Lq, Lk, hd, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, "td_mha_bwd");
+  int rc = fill(p, B, H, Lq, Lk, hd, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, dropout_counter, "td_mha_bwd");
   if (rc) return rc;
   p.q = q; p.k = k; p.v = v; p.dout = dout; p.probs = (float*)probs; p.dwavg = dwavg;
   p.dq = dq; p.dk = dk; p.dv = dv; p.ds_ws = ds_ws;

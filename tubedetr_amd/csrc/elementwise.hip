@@ -363,7 +363,8 @@ extern "C" int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, flo
   return check_launch("td_relu_bwd");
 }
 
-extern "C" int td_dropout(const void* x, void* y, size_t n, float p, uint32_t seed, int dtype, td_stream_t stream) {
+extern "C" int td_dropout(const void* x, void* y, size_t n, float p, uint32_t seed, const uint32_t* dropout_counter, int dtype,
+                          td_stream_t stream) {
   TD_REQUIRE(x && y, "td_dropout: null pointer");
   TD_REQUIRE(p >= 0.f && p < 1.f, "td_dropout: p out of range");
   if (n == 0) return TD_OK;
@@ -374,8 +375,8 @@ extern "C" int td_dropout(const void* x, void* y, size_t n, float p, uint32_t se
   if (p > 0.f && !thresh) thresh = 1;
   float scale = 1.f / (1.f - p);
   TD_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "td_dropout: pointers must be 16-byte aligned");
-  TD_DISPATCH(dtype, (ew_kernel<u16, 2><<<gr, 256, 0, st>>>((const u16*)x, nullptr, (u16*)y, n, scale, thresh, seed, thresh ? dropout_counter() : nullptr)),
-              (ew_kernel<float, 2><<<gr, 256, 0, st>>>((const float*)x, nullptr, (float*)y, n, scale, thresh, seed, thresh ? dropout_counter() : nullptr)), "td_dropout");
+  TD_DISPATCH(dtype, (ew_kernel<u16, 2><<<gr, 256, 0, st>>>((const u16*)x, nullptr, (u16*)y, n, scale, thresh, seed, thresh ? dropout_counter : nullptr)),
+              (ew_kernel<float, 2><<<gr, 256, 0, st>>>((const float*)x, nullptr, (float*)y, n, scale, thresh, seed, thresh ? dropout_counter : nullptr)), "td_dropout");
   return check_launch("td_dropout");
 }
 

@@ -968,7 +968,7 @@ static int validate(const td_conv_desc* d, int dtype, const char* who) {
 
 using namespace td;
 
-static unsigned long long* g_dbg = nullptr;
+static thread_local unsigned long long* g_dbg = nullptr;  // debug hook (tools/stamp_*.py): per calling thread
 static int persist_min_tiles() {
   static const int v = [] { const char* e = getenv("TD_PW_PERSIST_MIN"); return e ? atoi(e) : 4; }();
   return v;
@@ -1011,7 +1011,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
       if (p.drop_thresh == 0) p.drop_thresh = 1;
       p.drop_scale = 1.f / (1.f - e->dropout_p);
       p.seed = e->dropout_seed;
-      p.seed_dev = dropout_counter();
+      p.seed_dev = e->dropout_counter;
     }
   }
   TD_REQUIRE(d->ldc >= d->Nc, "td_conv_gemm: ldc < Nc");

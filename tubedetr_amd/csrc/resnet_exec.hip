@@ -249,29 +249,6 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
   size_t bump = 0;
   std::vector<td_wgrad_job> jobs;
   hipStream_t st = (hipStream_t)stream;
-  // Weight gradients do not feed the dgrad chain: they (and their finalize kernels) run on an internal second stream,
-  // concurrently with the next layers' dgrad GEMMs - two latency-bound kernel families sharing the chip.  Fork/join
-  // is by events only (no host sync); the call still appears stream-ordered to the caller.
-  static hipStream_t side = nullptr;
-  static std::vector<hipEvent_t> evpool;
-  static const bool use_side = [] { const char* e = getenv("TD_WGRAD_STREAM"); return e && e[0] == '1'; }();  // opt-in: measured neutral (eager) to negative (inside a graph)
-  if (use_side && !side) {
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
-  }
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cap);  // inside a graph capture everything stays on the captured stream
-  static const bool side_in_capture = [] { const char* e = getenv("TD_WGRAD_STREAM_CAPTURE"); return e && e[0] == '1'; }();
-  hipStream_t wst = (use_side && side && (cap == hipStreamCaptureStatusNone || side_in_capture)) ? side : st;
-  size_t evi = 0;
-  auto next_event = [&]() -> hipEvent_t {
-    if (evi == evpool.size()) {
-      hipEvent_t e;
-      hipEventCreateWithFlags(&e, hipEventDisableTiming);
-      evpool.push_back(e);
-    }
-    return evpool[evi++];
-  };
-  hipEvent_t slot_busy[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // last side-stream reader of a ring slot
   int rix = 0;
   auto galloc = [&](const Tens& t) {
     if (batched) {
@@ -280,13 +257,8 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
       return q;
     }
     const int s_ = rix++ % 6;
-    if (wst != st && slot_busy[s_]) {
-      hipStreamWaitEvent(st, slot_busy[s_], 0);  // do not overwrite a gradient a pending wgrad still reads
-      slot_busy[s_] = nullptr;
-    }
     return ring + (size_t)s_ * slot;
   };
-  auto slot_of = [&](const void* g) { return (int)(((const char*)g - ring) / slot); };
   if (!batched && hipMemsetAsync(base, 0, dwb, st) != hipSuccess) {
     set_error("td_resnet_bwd: memset failed");
     return TD_ERR_LAUNCH;
@@ -308,21 +280,9 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
       return TD_OK;
     }
     float* dwk = (float*)(base + dwoff[ci]);
-    if (wst != st) {  // g (and the memset) were produced on the caller's stream
-      hipEvent_t ready = next_event();
-      hipEventRecord(ready, st);
-      hipStreamWaitEvent(wst, ready, 0);
-    }
-    int r = td_conv_wgrad(g, acts + xin.off, dwk, &d, c.cout, dtype, 0, (td_stream_t)wst);
+    int r = td_conv_wgrad(g, acts + xin.off, dwk, &d, c.cout, dtype, 0, stream);
     if (r) return r;
-    r = td_wgrad_finalize(dwk, scale[ci], dW[ci], c.cout, c.cin, c.k, c.k, c.cin, 0, (td_stream_t)wst);
-    if (r) return r;
-    if (wst != st) {
-      hipEvent_t done = next_event();
-      hipEventRecord(done, wst);
-      slot_busy[slot_of(g)] = done;
-    }
-    return TD_OK;
+    return td_wgrad_finalize(dwk, scale[ci], dW[ci], c.cout, c.cin, c.k, c.k, c.cin, 0, stream);
   };
   auto dgrad = [&](const void* g, const Tens& gt, const Tens& xin, int ci, const void* residual, const void* mask, void* out) -> int {
     const ConvSpec& c = P.convs[ci];
@@ -332,13 +292,6 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     e.residual = residual;
     e.mask_src = mask;
     return td_conv_gemm(g, w_dgrad[ci], out, &d, &e, dtype, stream);
-  };
-  auto join = [&]() {
-    if (wst != st) {
-      hipEvent_t fin = next_event();
-      hipEventRecord(fin, wst);
-      hipStreamWaitEvent(st, fin, 0);
-    }
   };
   int last = (int)P.blocks.size() - 1;
   int first = 0;
@@ -379,7 +332,6 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     }
     g_out = dx;
   }
-  join();
   if (batched && !jobs.empty())
     return td_conv_wgrad_batch(jobs.data(), (int)jobs.size(), dtype, table_host, table_dev, table_bytes, stream);
   return TD_OK;

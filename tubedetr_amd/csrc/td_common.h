@@ -26,10 +26,18 @@ int check_launch(const char* what);
     }                                   \
   } while (0)
 
-// optional device-side dropout step counter (td_set_dropout_step_counter): kernels add *ptr * golden to their seed, so
-// a captured HIP graph draws fresh masks on every replay without re-recording launches
-const uint32_t* dropout_counter();
-__device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint32_t* ctr) { return ctr ? seed + ctr[0] * 0x9E3779B1u : seed; }
+// optional device-side dropout step counter (the `dropout_counter` argument of the dropout-capable entry points): the
+// kernels re-key their seed with a HASH of (seed, *ptr), so a captured HIP graph draws fresh, independent masks on
+// every replay without re-recording launches.  (A linear re-keying - seed + ctr * golden - would make the mask of step
+// c the step-0 mask shifted by c elements, because hash32() below also enters the element index through
+// idx * golden + seed.)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint32_t* ctr) {
+  return ctr ? mix32(mix32(seed ^ 0xA511E9B3u) + ctr[0] * 0xC2B2AE3Du) : seed;
+}
 
 // bench-only launch timing (api.cpp)
 bool prof_on();
@@ -76,9 +84,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // counter-based dropout RNG: keep-probability test on a 32-bit hash of (seed, element index).
 __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t idx) {
-  uint32_t x = idx * 0x9E3779B1u + seed;
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
+  return mix32(idx * 0x9E3779B1u + seed);
 }
 __device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t idx, uint32_t thresh) { return hash32(seed, idx) >= thresh; }
 

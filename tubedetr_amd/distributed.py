@@ -39,6 +39,9 @@ class FlatGradAllReducer:
             off += p.numel()
         self.numel = n
         self.always_communicate = False  # diagnostic: issue the collective even in a 1-rank group
+        self._had_grad: Optional[List[bool]] = None     # which parameters had a local gradient at the last gather()
+        self._global_used: Optional[List[bool]] = None  # ... on ANY rank (exchanged once, see _sync_usage)
+        self._attached = False
 
     # ---- three phases; `reduce()` runs them back to back ----
     def gather(self, grads: Optional[List[Optional[torch.Tensor]]] = None) -> None:
@@ -51,10 +54,33 @@ class FlatGradAllReducer:
             torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        self._had_grad = [g is not None for g in grads]
+        had = [g is not None for g in grads]
+        if self._global_used is not None and any(h and not u for h, u in zip(had, self._global_used)):
+            # a parameter no rank used when the usage map was exchanged now has a gradient here: ranks that still skip it
+            # would silently diverge, so the map is re-exchanged (every rank must see the same change: data-dependent
+            # parameter usage is not supported by the reference's model either)
+            self._global_used = None
+        self._had_grad = had
+
+    def _sync_usage(self) -> None:
+        """DDP(find_unused_parameters=True) hands every rank the reduced gradient of a parameter ANY rank used and leaves
+        globally unused ones (RoBERTa's pooler) at grad=None.  Same rule here: the usage bitmap is exchanged once (one
+        small all-reduce + one host read, at the first step only) and kept; ``attach`` / ``scatter`` then serve every
+        parameter that any rank used, so replicas cannot diverge when usage differs between ranks."""
+        had = self._had_grad if self._had_grad is not None else [True] * len(self.params)
+        if self.world > 1:
+            flags = torch.tensor([1.0 if h else 0.0 for h in had], dtype=torch.float32, device=self.flat.device)
+            dist.all_reduce(flags, group=self.group)
+            self._global_used = [bool(v > 0) for v in flags.tolist()]
+        else:
+            self._global_used = list(had)
+        if self._attached:
+            self.attach()
 
     def all_reduce(self) -> None:
         """The one collective of a training step: average the flat buffer over the ranks (in place)."""
+        if self._global_used is None:
+            self._sync_usage()
         if not (self.world > 1 or self.always_communicate):
             return
         avg = dist.is_initialized() and dist.get_backend(self.group) == "nccl"  # RCCL averages in the reduction itself
@@ -71,14 +97,21 @@ class FlatGradAllReducer:
     def attach(self) -> None:
         """Zero-copy hand-over: ``.grad`` of every parameter that had a gradient becomes its view of the flat buffer
         (what a fused optimizer wants anyway)."""
-        had = getattr(self, "_had_grad", [True] * len(self.params))
-        for p, v, h in zip(self.params, self.views, had):
-            if h:
+        used = self._global_used if self._global_used is not None else (self._had_grad or [True] * len(self.params))
+        for p, v, u in zip(self.params, self.views, used):
+            if u:
                 p.grad = v
+        self._attached = True
 
     def scatter(self) -> None:
         """Copy the averaged values back into the existing ``.grad`` tensors (keeps their storage)."""
-        have = [(p.grad, v) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        used = self._global_used if self._global_used is not None else [True] * len(self.params)
+        have = []
+        for v, p, u in zip(self.views, self.params, used):
+            if p.grad is None and u:
+                p.grad = v.clone()  # unused on this rank, used elsewhere: every replica applies the same update
+            elif p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                have.append((p.grad, v))
         if have:
             torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
 

@@ -7,10 +7,9 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .util.misc import NestedTensor
+from .util.misc import LRUCache, NestedTensor
 
-
-_IDX: dict = {}
+_IDX = LRUCache()
 
 
 class FixedTokenizer:

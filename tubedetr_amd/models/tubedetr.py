@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import functional as Fk
-from ..util.misc import NestedTensor
+from ..util.misc import LRUCache, NestedTensor
 from .backbone import build_backbone
 from .transformer import build_transformer
 
@@ -60,7 +60,7 @@ class TubeDETR(nn.Module):
         self.sted = sted
         if sted:
             self.sted_embed = MLP(hidden_dim, hidden_dim, 2, 2, dropout=0.5)
-        self._idx_cache: dict = {}
+        self._idx_cache = LRUCache()
         # Opt-in (bench.py / callers whose data pipeline guarantees it, like datasets/vidstg.py:250-251 does): the slow
         # frames ARE the fast frames [::stride] of each video.  The trunk then runs once over the fast frames only
         # (slow ones first, so backward still walks a contiguous prefix) instead of recomputing the same pixels.
@@ -237,8 +237,8 @@ class SetCriterion(nn.Module):
         super().__init__()
         self.losses = losses
         self.sigma = sigma
-        self._pm_cache: dict = {}
-        self._tgt_cache: dict = {}
+        self._pm_cache = LRUCache()
+        self._tgt_cache = LRUCache()
         self.external_num_boxes = None
 
     # ---- per-loss math on stacked layers: leading dim = decoder layer ----

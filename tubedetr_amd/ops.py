@@ -73,8 +73,26 @@ def _desc(N, Hs, Ws, Cs, Ho, Wo, R, S, stride, pad, mode, Nc, ldc, out_sp=1, out
     return ConvDesc(N, Hs, Ws, Cs, Ho, Wo, R, S, stride, pad, mode, Nc, ldc, out_sp, out_H, out_W)
 
 
+_DROPOUT_COUNTER = [None]  # device uint32/int32 tensor or None
+
+
+def set_dropout_counter(counter: Optional[torch.Tensor]) -> None:
+    """Device-resident step counter handed to every dropout-capable launch from now on (None = plain seeds).  A step
+    captured in a HIP graph re-keys its dropout masks from it at every replay: increment it between replays.  This is
+    host-side launch context only - the C ABI takes the pointer per call and keeps no state."""
+    if counter is not None:
+        assert counter.is_cuda and counter.numel() == 1 and counter.element_size() == 4
+    _DROPOUT_COUNTER[0] = counter
+
+
+def _ctr():
+    c = _DROPOUT_COUNTER[0]
+    return c.data_ptr() if c is not None else None
+
+
 def _epi(bias=None, residual=None, mask_src=None, relu=False, sigmoid=False, dropout_p=0.0, seed=0, alpha=1.0) -> Epilogue:
-    return Epilogue(ptr(bias), ptr(residual), ptr(mask_src), int(relu), int(sigmoid), float(dropout_p), int(seed) & 0xFFFFFFFF, float(alpha))
+    return Epilogue(ptr(bias), ptr(residual), ptr(mask_src), int(relu), int(sigmoid), float(dropout_p), int(seed) & 0xFFFFFFFF, float(alpha),
+                    _ctr() if dropout_p > 0 else None)
 
 
 def conv_gemm_raw(src: Tensor, w: Tensor, out: Tensor, desc: ConvDesc, epi: Optional[Epilogue]):
@@ -342,7 +360,8 @@ def mha_fwd(q: Tensor, k: Tensor, v: Tensor, key_pad: Optional[Tensor], H: int, 
     wavg = torch.empty((B, Lq, Lk), dtype=torch.float32, device=q.device) if need_wavg else None
     kp = key_pad.to(torch.uint8).contiguous() if key_pad is not None else None
     check(_hip.lib().td_mha_fwd(ptr(q), ptr(k), ptr(v), ptr(kp), ptr(out), ptr(probs), ptr(wavg), B, H, Lq, Lk, hd, q.stride(1), k.stride(1),
-                                v.stride(1), E, scale, dropout_p, seed & 0xFFFFFFFF, dtype_code(q.dtype), stream_ptr()), "td_mha_fwd")
+                                v.stride(1), E, scale, dropout_p, seed & 0xFFFFFFFF, _ctr() if dropout_p > 0 else None, dtype_code(q.dtype), stream_ptr()),
+          "td_mha_fwd")
     return out, probs, wavg
 
 
@@ -357,12 +376,13 @@ def mha_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, probs: Tensor, dwavg:
     for a, b in ((q, dq), (k, dk), (v, dv)):
         assert a.stride() == b.stride() and a.shape == b.shape
     check(_hip.lib().td_mha_bwd(ptr(q), ptr(k), ptr(v), ptr(dout), ptr(probs), ptr(dwavg), ptr(dq), ptr(dk), ptr(dv), ptr(ws), B, H, Lq, Lk, hd,
-                                q.stride(1), k.stride(1), v.stride(1), E, scale, dropout_p, seed & 0xFFFFFFFF, dtype_code(q.dtype), stream_ptr()),
-          "td_mha_bwd")
+                                q.stride(1), k.stride(1), v.stride(1), E, scale, dropout_p, seed & 0xFFFFFFFF, _ctr() if dropout_p > 0 else None,
+                                dtype_code(q.dtype), stream_ptr()), "td_mha_bwd")
     return dq, dk, dv
 
 
 def dropout(x: Tensor, p: float, seed: int) -> Tensor:
     y = torch.empty_like(x)
-    check(_hip.lib().td_dropout(ptr(x), ptr(y), x.numel(), p, seed & 0xFFFFFFFF, dtype_code(x.dtype), stream_ptr()), "td_dropout")
+    check(_hip.lib().td_dropout(ptr(x), ptr(y), x.numel(), p, seed & 0xFFFFFFFF, _ctr() if p > 0 else None, dtype_code(x.dtype), stream_ptr()),
+          "td_dropout")
     return y

@@ -52,3 +52,36 @@ class NestedTensor(object):
 
     def __repr__(self):
         return repr(self.tensors)
+
+
+class LRUCache:
+    """Tiny bounded mapping for the per-(durations, inter_idx) device index / target tensors: a real dataset produces a
+    new key almost every batch, so an unbounded dict would leak device memory over an epoch; the synthetic bench (and a
+    captured HIP graph, which must keep seeing the same tensors) cycles through a handful of keys."""
+
+    def __init__(self, maxsize: int = 32):
+        from collections import OrderedDict
+
+        self.maxsize, self._d = maxsize, OrderedDict()
+
+    def get(self, key, default=None):
+        if key in self._d:
+            self._d.move_to_end(key)
+            return self._d[key]
+        return default
+
+    def __contains__(self, key):
+        return key in self._d
+
+    def __getitem__(self, key):
+        self._d.move_to_end(key)
+        return self._d[key]
+
+    def __setitem__(self, key, value):
+        self._d[key] = value
+        self._d.move_to_end(key)
+        while len(self._d) > self.maxsize:
+            self._d.popitem(last=False)
+
+    def __len__(self):
+        return len(self._d)
