@@ -14,6 +14,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("TD_EFENCE") == "1":
+        # electric-fence run (tests/efence/): every device tensor ends at an unmapped guard range, so an out-of-bounds
+        # access by any kernel faults at the access; must be installed before the first device allocation
+        sys.path.insert(0, os.path.join(ROOT, "tests", "efence"))
+        import install as _efence_install
+
+        _efence_install.install()
 
 
 def pytest_collection_modifyitems(config, items):

@@ -385,3 +385,32 @@ def test_mha_strided_qkv_views():
     d2q, d2k, _ = ops.mha_bwd(qkb[..., :E].contiguous(), qkb[..., E:].contiguous(), vb, dout, p2, None, H, 0.17,
                               torch.empty_like(vb), torch.empty_like(vb), torch.empty_like(vb))
     assert torch.equal(dq[..., :E], d2q) and torch.equal(dq[..., E:], d2k)
+
+
+def test_dropout_masks_of_consecutive_steps_are_independent():
+    """The device step counter re-keys the counter-based RNG through a hash: the mask of step c must not be the step-0
+    mask shifted by c elements (what a linear seed + c * golden re-keying produces), and masks of different steps must
+    be uncorrelated."""
+    from tubedetr_amd import ops
+
+    n, p = 1 << 16, 0.5
+    x = torch.ones(n, device=dev())
+    ctr = torch.zeros(1, dtype=torch.int32, device=dev())
+    masks = []
+    try:
+        ops.set_dropout_counter(ctr)
+        for c in range(4):
+            ctr.fill_(c)
+            masks.append(ops.dropout(x, p, 1234) > 0)
+        again = ops.dropout(x, p, 1234) > 0
+    finally:
+        ops.set_dropout_counter(None)
+    assert torch.equal(masks[3], again)  # same (seed, counter) -> same mask (backward regenerates it)
+    for c in range(1, 4):
+        m0, mc = masks[0], masks[c]
+        assert abs(mc.float().mean().item() - (1 - p)) < 0.02
+        for shift in (0, c, -c):  # a shifted copy would agree on ~100 % of the overlap; independent masks on ~50 %
+            a = m0[max(0, shift) : n + min(0, shift)]
+            b = mc[max(0, -shift) : n - max(0, shift)]
+            agree = (a == b).float().mean().item()
+            assert 0.45 < agree < 0.55, (c, shift, agree)

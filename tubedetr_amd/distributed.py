@@ -23,6 +23,17 @@ import torch
 import torch.distributed as dist
 
 
+def _all_reduce(t: torch.Tensor, op, group=None) -> None:
+    """dist.all_reduce; with the `gloo` backend (CPU tests, single-GPU debugging with several ranks on one device) a
+    device buffer is moved through the host, since gloo builds without device support reject CUDA tensors."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 class FlatGradAllReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], wire_dtype: torch.dtype = torch.float32, group=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -70,7 +81,7 @@ class FlatGradAllReducer:
         had = self._had_grad if self._had_grad is not None else [True] * len(self.params)
         if self.world > 1:
             flags = torch.tensor([1.0 if h else 0.0 for h in had], dtype=torch.float32, device=self.flat.device)
-            dist.all_reduce(flags, group=self.group)
+            _all_reduce(flags, dist.ReduceOp.SUM, self.group)
             self._global_used = [bool(v > 0) for v in flags.tolist()]
         else:
             self._global_used = list(had)
@@ -87,10 +98,10 @@ class FlatGradAllReducer:
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         if self.wire is not self.flat:
             self.wire.copy_(self.flat)
-            dist.all_reduce(self.wire, op=op, group=self.group)
+            _all_reduce(self.wire, op, self.group)
             self.flat.copy_(self.wire)
         else:
-            dist.all_reduce(self.flat, op=op, group=self.group)
+            _all_reduce(self.flat, op, self.group)
         if not avg:
             self.flat.div_(self.world)
 
@@ -131,7 +142,7 @@ def sync_num_boxes(n_local: int, out: torch.Tensor, group=None) -> torch.Tensor:
     (models/tubedetr.py:407-413), without a host synchronisation."""
     out.fill_(float(n_local))
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(out, group=group)
+        _all_reduce(out, dist.ReduceOp.SUM, group)
         out.div_(dist.get_world_size(group))
     out.clamp_(min=1)
     return out
