@@ -55,24 +55,27 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
 
 
-def make_batch(T, res, k, L, seed, device):
-    """SURVEY.md 8d synthetic clip, generated directly in HBM: video ~ N(0,1), slow = video[::k], fast = all frames."""
+def make_batch(T, res, k, L, seed, device, clips=1):
+    """SURVEY.md 8d synthetic clips, generated directly in HBM: video ~ N(0,1), slow = video[::k], fast = all frames; `clips`
+    videos of equal duration per batch (video-major frame order, like util/misc.py's collate)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    video = torch.randn(T, 3, res, res, generator=g, device=device)
-    ids = torch.randint(3, 50000, (1, L), generator=torch.Generator().manual_seed(seed))  # token ids start on the host, like a tokenizer's output
+    video = torch.randn(clips * T, 3, res, res, generator=g, device=device)
+    ids = torch.randint(3, 50000, (clips, L), generator=torch.Generator().manual_seed(seed))  # token ids start on the host, like a tokenizer's output
     ids[:, 0], ids[:, -1] = 0, 2
-    cxcy = torch.rand(T, 2, generator=g, device=device) * 0.6 + 0.2
-    wh = torch.rand(T, 2, generator=g, device=device) * 0.3 + 0.1
+    cxcy = torch.rand(clips * T, 2, generator=g, device=device) * 0.6 + 0.2
+    wh = torch.rand(clips * T, 2, generator=g, device=device) * 0.3 + 0.1
+    n_slow = math.ceil(T / k)
+    slow = video.view(clips, T, 3, res, res)[:, ::k].reshape(clips * n_slow, 3, res, res).contiguous()
     return {
-        "frames": video[::k].contiguous(),
-        "frames_mask": torch.zeros((math.ceil(T / k), res, res), dtype=torch.bool, device=device),
+        "frames": slow,
+        "frames_mask": torch.zeros((clips * n_slow, res, res), dtype=torch.bool, device=device),
         "frames_fast": video,
-        "fast_mask": torch.zeros((T, res, res), dtype=torch.bool, device=device),
-        "durations": [T],
+        "fast_mask": torch.zeros((clips * T, res, res), dtype=torch.bool, device=device),
+        "durations": [T] * clips,
         "input_ids": ids,
-        "attention_mask": torch.ones(1, L, dtype=torch.long),
+        "attention_mask": torch.ones(clips, L, dtype=torch.long),
         "target_boxes": torch.cat([cxcy, wh], 1),
-        "inter_idx": [[0, T - 1]],
+        "inter_idx": [[0, T - 1]] * clips,
     }
 
 
@@ -129,6 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
+    ap.add_argument("--clips-per-gpu", type=int, default=1, help="videos per GPU per step (the reference's --batch_size, main.py:63)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--roofline-steps", type=int, default=2)
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-baseline sample clip (0 = skip)")
@@ -151,6 +155,12 @@ def main():
                          "hipGraphLaunch, and the only configuration in which a replay ever hit a GPU memory fault)")
     a = ap.parse_args()
 
+    if os.environ.get("TD_EFENCE") == "1":  # diagnostic: electric-fence device allocator (tests/efence/), eager launches only
+        sys.path.insert(0, os.path.join(ROOT, "tests", "efence"))
+        import install as efence_install
+
+        efence_install.install()
+        a.graph, a.child = False, True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and not a.child and not a.force_ddp and a.graph and os.environ.get("TD_BENCH_ISOLATE", "1") != "0":
         # Single-GPU run: the measurement happens in a child process.  A GPU memory fault during a graph replay (seen
@@ -218,7 +228,7 @@ def main():
         reducer.always_communicate = a.force_ddp  # exercise the RCCL call in the 1-rank diagnostic
 
     n_batches = a.warmup + a.steps + a.roofline_steps
-    batches = [make_batch(T, res, k, L, 1000 * rank + s, dev) for s in range(min(n_batches, 4))]
+    batches = [make_batch(T, res, k, L, 1000 * rank + s, dev, a.clips_per_gpu) for s in range(min(n_batches, 4))]
 
     from tubedetr_amd.functional import invalidate_prepared
 
@@ -306,6 +316,11 @@ def main():
             torch.cuda.synchronize()
             execution = f"eager (graph capture failed: {type(exc).__name__}: {str(exc)[:120]})"
 
+    if os.environ.get("TD_BENCH_MEMMAP"):  # fault triage: where every allocator segment / block lives before the replays start
+        torch.cuda.synchronize()
+        snap = [{"address": s_["address"], "total_size": s_["total_size"], "stream": s_["stream"], "segment_type": s_["segment_type"],
+                 "blocks": [(b_["address"] if "address" in b_ else None, b_["size"], b_["state"]) for b_ in s_["blocks"]]} for s_ in torch.cuda.memory_snapshot()]
+        json.dump(snap, open(os.environ["TD_BENCH_MEMMAP"], "w"))
     for i in range(a.warmup):
         step(i)
         if os.environ.get("TD_BENCH_TRACE"):
@@ -388,8 +403,10 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 cpu = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
 
+    if os.environ.get("TD_EFENCE") == "1":
+        print(f"[bench] electric fence: every allocation fenced = {efence_install.protected()}", file=sys.stderr, flush=True)
     if rank == 0:
-        clips = world * a.steps
+        clips = world * a.steps * a.clips_per_gpu
         value = clips / elapsed
         step_tflop = ALGO_TFLOP_PER_CLIP.get(a.workload)
         out = {
@@ -397,8 +414,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "execution": execution, "gradient_exchange": (None if not distributed else ("torch DDP (find_unused_parameters)" if a.ddp else f"flat all-reduce, {a.grad_wire_dtype} on the wire")),
-            "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, 1 clip/GPU, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}",
-                       "global_batch": world, "parallelism": f"dp{world}", "weights": "random init (reference scheme), seed 42+rank"},
+            "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, {a.clips_per_gpu} clip(s)/GPU/step, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}",
+                       "global_batch": world * a.clips_per_gpu, "parallelism": f"dp{world}", "weights": "random init (reference scheme), seed 42+rank"},
             "flops_note": ("slow frames not recomputed in the fast pass (identical pixels): executed trunk-forward work is 100/125 of the "
                            "reference algorithm's; roofline fractions use executed FLOPs, step_frac_of_mfma_peak the reference algorithm's 6.847 TFLOP") if (model.slow_frames_are_strided_fast and not a.no_fast) else None,
             "step_frac_of_mfma_peak": round(step_tflop * value / world / PEAK_BF16_TFLOPS, 4) if (step_tflop and a.dtype == "bf16") else None,

@@ -109,6 +109,8 @@ int td_conv_wgrad_bias(const void* g, const void* src, float* dw, float* dbias, 
  * conv layers.  dW of every job is written in the parameter's own [Nc][ci_real][R][S] fp32 layout with `scale[co]`
  * (the FrozenBN factor, may be NULL) folded in - overwritten, not accumulated.  With thousands of output tiles in flight
  * a job needs no reduction splits (no atomics, no accumulator memset, no finalize pass) unless its M is very long.
+ * A linear layer is a job with R=S=1 (dW = the parameter's [out][in]); its bias gradient rides along (`dbias`).  The
+ * transformer's ~94 weight gradients of one step are deferred to the end of backward and run as ONE such launch.
  * `jobs` is a host array, consumed before the call returns.  The per-launch job table lives in caller-provided
  * memory of td_conv_wgrad_batch_table_bytes(n_jobs) bytes each: `table_host` (page-locked host memory, written by this
  * call) and `table_dev` (device memory, filled by ONE hipMemcpyAsync on `stream`).  Both must stay untouched until the
@@ -124,6 +126,7 @@ typedef struct td_wgrad_job {
   td_conv_desc d;     /* forward geometry (mode 0) */
   int ldg;
   int ci_real;        /* input channels of the parameter (d.C may be padded) */
+  float* dbias;       /* optional [Nc] fp32: column sums of g (bias gradient of a Linear / Conv2d with bias), overwritten */
 } td_wgrad_job;
 size_t td_conv_wgrad_batch_table_bytes(int n_jobs);
 int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev, size_t table_bytes,
@@ -233,6 +236,38 @@ int td_mha_bwd(const void* q, const void* k, const void* v, const void* dout, co
                void* dq, void* dk, void* dv, float* ds_ws, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk,
                int ldv, int ldo, float scale, float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter,
                int dtype, td_stream_t stream);
+
+
+/* ---- optimizer-side tail of a training step over FLAT fp32 buffers -------------------------------
+ * All trainable parameters of the model lie back to back in one buffer (`param`), their gradients in the same order in
+ * another (the flat buffer of the data-parallel exchange).  The buffers are tiled by at most TD_OPTIM_MAX_SEGMENTS
+ * segments; a segment belongs to one parameter group (learning rate index: 0 = transformer + heads, 1 = backbone,
+ * 2 = text encoder, main.py:381-405) and is `active` unless its parameters received no gradient (RoBERTa's pooler:
+ * torch skips p.grad is None in clip_grad_norm_ and in optimizer.step()). */
+#define TD_OPTIM_MAX_SEGMENTS 32
+#define TD_OPTIM_MAX_GROUPS 4
+#define TD_OPTIM_NORM_BLOCKS 2048
+typedef struct td_optim_segment {
+  long long begin, end; /* element range [begin, end) */
+  int group;            /* index into lr_dev[] */
+  int active;           /* 0: left untouched */
+} td_optim_segment;
+/* Replaces torch.nn.utils.clip_grad_norm_ (engine.py:149-150): norm_clip[0] = L2 norm of all active gradients,
+ * norm_clip[1] = min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0); *step (device int, may be NULL) += 1.
+ * ws: td_grad_norm_ws_bytes() bytes of device scratch.  Two launches. */
+size_t td_grad_norm_ws_bytes(void);
+int td_grad_norm_clip(const float* grad, size_t n, const td_optim_segment* segs, int n_segs, float max_norm, void* ws,
+                      size_t ws_bytes, float* norm_clip, int* step, td_stream_t stream);
+/* Replaces optimizer.step() of torch.optim.AdamW with three parameter groups (main.py:406-413, engine.py:151) and
+ * update_ema (util/optim.py:8-25) in ONE launch: g = grad * norm_clip[1] (norm_clip may be NULL); param *= 1 - lr*wd;
+ * exp_avg = lerp(exp_avg, g, 1-beta1); exp_avg_sq = beta2*exp_avg_sq + (1-beta2) g^2; param -= lr/(1-beta1^t) *
+ * exp_avg / (sqrt(exp_avg_sq)/sqrt(1-beta2^t) + eps); ema = ema*ema_decay + (1-ema_decay)*param (ema may be NULL).
+ * lr_dev: TD_OPTIM_MAX_GROUPS device floats (written by the host's adjust_learning_rate, util/optim.py:28-95);
+ * step_dev: device int holding t (already incremented by td_grad_norm_clip). */
+int td_adamw_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, size_t n,
+                      const td_optim_segment* segs, int n_segs, const float* lr_dev, const float* norm_clip,
+                      const int* step_dev, float beta1, float beta2, float eps, float weight_decay, float ema_decay,
+                      td_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,10 @@ extern "C" void* td_efence_malloc(ssize_t size, int device, hipStream_t) {
     if (e == hipSuccess) e = hipMemSetAccess((char*)r.base + g_gran, r.mapped, &acc, 1);
     if (e == hipSuccess) {
       void* p = (char*)r.base + g_gran + r.mapped - need;  // the tensor ends where the mapping ends
+      // TD_EFENCE_POISON=1: fresh memory is filled with 0xFF bytes (NaN as fp32 / bf16, -1 as integers), so a kernel that
+      // READS memory nobody has written shows up as NaN in its results instead of depending on what the pages held
+      static const bool poison = env_sz("TD_EFENCE_POISON", 0) != 0;
+      if (poison) (void)hipMemset((char*)r.base + g_gran, 0xFF, r.mapped);
       g_live[p] = r;
       return p;
     }

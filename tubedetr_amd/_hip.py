@@ -27,7 +27,12 @@ class PrepItem(C.Structure):
 
 class WgradJob(C.Structure):
     """td_wgrad_job (include/tubedetr_hip.h)."""
-    _fields_ = [("g", C.c_void_p), ("src", C.c_void_p), ("dW", C.c_void_p), ("scale", C.c_void_p), ("d", ConvDesc), ("ldg", C.c_int), ("ci_real", C.c_int)]
+    _fields_ = [("g", C.c_void_p), ("src", C.c_void_p), ("dW", C.c_void_p), ("scale", C.c_void_p), ("d", ConvDesc), ("ldg", C.c_int), ("ci_real", C.c_int), ("dbias", C.c_void_p)]
+
+
+class OptimSegment(C.Structure):
+    """td_optim_segment."""
+    _fields_ = [("begin", C.c_longlong), ("end", C.c_longlong), ("group", C.c_int), ("active", C.c_int)]
 
 
 class Epilogue(C.Structure):
@@ -72,10 +77,13 @@ _SIGS = {
     "td_relu_bwd": [_P, _P, _P, _SZ, _F, _I, _P],
     "td_dropout": [_P, _P, _SZ, _F, _U32, _P, _I, _P],
     "td_pos_sine": [_P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "td_grad_norm_clip": [_P, _SZ, C.POINTER(OptimSegment), _I, _F, _P, _SZ, _P, _P, _P],
+    "td_adamw_ema_step": [_P, _P, _P, _P, _P, _SZ, C.POINTER(OptimSegment), _I, _P, _P, _P, _F, _F, _F, _F, _F, _P],
     "td_mha_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
     "td_mha_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
 }
 _SIZE_SIGS = {
+    "td_grad_norm_ws_bytes": [],
     "td_conv_wgrad_batch_table_bytes": [_I],
     "td_resnet_bwd_table_bytes": [C.POINTER(C.c_int), _I],
     "td_resnet_fwd_ws_bytes": [_I, _I, _I, C.POINTER(C.c_int), _I, _I],

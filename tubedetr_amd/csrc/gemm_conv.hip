@@ -877,7 +877,9 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int coo = co0 + wy * 64 + i * 16 + 4 * lg + rr;
-        if (coo < d.Nc) atomicAdd(p.dbias + coo, accb[i][rr]);
+        if (coo >= d.Nc) continue;
+        if (p.out_mode == 2) p.dbias[coo] = accb[i][rr];  // single split: this workgroup owns the column sums of its channels
+        else atomicAdd(p.dbias + coo, accb[i][rr]);
       }
   }
   if (p.out_mode == 0) {
@@ -1220,12 +1222,14 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
     if (rc) return rc;
     TD_REQUIRE(j.ci_real >= 1 && j.ci_real <= j.d.C, "td_conv_wgrad_batch: job %d: ci_real=%d out of range", i, j.ci_real);
     p.dw = j.dW;
+    p.dbias = j.dbias;
     p.scale = j.scale;
     p.ci_real = j.ci_real;
     p.out_mode = splits == 1 ? 2 : 1;
     p.first = splits;  // (temporarily: the split count, replaced by the first workgroup index below)
     if (splits > 1 &&
-        hipMemsetAsync(j.dW, 0, (size_t)j.d.Nc * j.ci_real * j.d.R * j.d.S * sizeof(float), st) != hipSuccess) {
+        (hipMemsetAsync(j.dW, 0, (size_t)j.d.Nc * j.ci_real * j.d.R * j.d.S * sizeof(float), st) != hipSuccess ||
+         (j.dbias && hipMemsetAsync(j.dbias, 0, (size_t)j.d.Nc * sizeof(float), st) != hipSuccess))) {
       set_error("td_conv_wgrad_batch: memset failed");
       return TD_ERR_LAUNCH;
     }

@@ -276,6 +276,7 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
       j.d = d;
       j.ldg = c.cout;
       j.ci_real = c.cin;
+      j.dbias = nullptr;
       jobs.push_back(j);
       return TD_OK;
     }

@@ -163,11 +163,120 @@ def _seed() -> int:
     return _SEED_STATE["rng"].getrandbits(31)
 
 
+# ---- deferred weight gradients -------------------------------------------------------------------------------------
+# The weight / bias gradients of the transformer's ~94 linear layers do not feed the backward chain.  Launched where
+# autograd reaches them they are 94 latency-bound launches with split-M fp32 atomics into zero-filled buffers; instead
+# each backward only RESERVES its gradient tensors, queues (g, x, dW*, db*) and the whole queue runs as ONE
+# td_conv_wgrad_batch launch from an autograd final callback (end of loss.backward(), before it returns, on the
+# caller's stream): thousands of output tiles fill the chip, nothing needs zero-initialising, no atomics.
+# Deferral is skipped (immediate launch) whenever the reserved tensor could be read before the callback runs: a
+# parameter that already has a .grad (AccumulateGrad would add in place) or carries gradient hooks (DDP's reducer).
+import os as _os
+import threading as _threading
+
+_DEFER_ON = [_os.environ.get("TD_WGRAD_DEFER", "1") != "0"]
+_DEFER_LOCK = _threading.Lock()
+_DEFER_JOBS: list = []
+_ARMED = [False]  # the final callback of the running backward pass has been queued
+
+
+def set_wgrad_deferral(on: bool) -> None:
+    _DEFER_ON[0] = bool(on)
+
+
+_USES: dict = {}  # id(leaf parameter) -> number of deferral-capable forward uses since the last backward
+
+
+def _leaf(p):
+    if p is None or p.is_leaf:
+        return p
+    return p._base if (p._base is not None and p._base.is_leaf) else None
+
+
+def _note_use(recording: bool, *params) -> None:
+    """Forward-side bookkeeping (``recording`` = this node is part of an autograd graph): a parameter that enters more than
+    one node of the same graph (input_proj runs on the slow and on the fast features) has its gradients SUMMED by the
+    engine before the final callback runs, so its nodes must produce them immediately."""
+    _drop_stale_deferred()
+    if not recording:
+        return
+    for p in params:
+        q = _leaf(p)
+        if q is not None and q.requires_grad:
+            _USES[id(q)] = _USES.get(id(q), 0) + 1
+
+
+def _can_defer(*params) -> bool:
+    if not _DEFER_ON[0]:
+        return False
+    for p in params:
+        if p is None:
+            continue
+        q = _leaf(p)
+        if q is None:
+            return False
+        if not q.requires_grad:
+            continue
+        if _USES.get(id(q), 0) != 1 or q.grad is not None or q._backward_hooks or getattr(q, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
+
+
+def _flush_deferred_wgrads():
+    with _DEFER_LOCK:
+        jobs = list(_DEFER_JOBS)
+        _DEFER_JOBS.clear()
+        _USES.clear()
+        _ARMED[0] = False
+    if jobs:
+        ops.linear_wgrad_batch(jobs)
+
+
+def _drop_stale_deferred():
+    """Called from the forward functions: a queue that is non-empty here belongs to a backward pass that died before its
+    final callback ran; its reserved outputs are gone, so the jobs must never be launched."""
+    if _ARMED[0]:
+        with _DEFER_LOCK:
+            _DEFER_JOBS.clear()
+            _USES.clear()
+            _ARMED[0] = False
+
+
+def _arm():
+    """First thing in every backward of the linear-layer functions: make sure the end-of-backward callback is queued
+    (it also resets the per-step use counts when nothing was deferred)."""
+    with _DEFER_LOCK:
+        if _ARMED[0]:
+            return
+        _ARMED[0] = True
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrads)
+
+
+def _wgrad(g: Tensor, x: Tensor, defer: bool, *, want_bias: bool, out: Optional[Tensor] = None, dbias: Optional[Tensor] = None):
+    """(dW [N,K] fp32, db [N] fp32 | None) of a linear layer y = x W^T + b from g = dL/dy.  ``out`` / ``dbias``: row
+    slices of a packed gradient (MHA in_proj) to write into.  defer=True: outputs are reserved now and filled by the
+    batched launch at the end of backward."""
+    M, K = x.shape
+    N = g.shape[1]
+    dev = g.device
+    if not defer:
+        db = dbias if dbias is not None else (ops.zeros_f32(N, dev) if want_bias else None)
+        dW = ops.linear_wgrad(g, x, out=out, dbias=db)
+        return dW, db
+    dW = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = dbias if dbias is not None else (torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None)
+    with _DEFER_LOCK:
+        # only raw pointers of the outputs are kept: a second reference would stop AccumulateGrad from adopting the tensor
+        _DEFER_JOBS.append((g, x, dW.data_ptr(), db.data_ptr() if db is not None else None))
+    return dW, db
+
+
 class LinearFn(Function):
     """y = dropout(act(x @ W^T + b)); act in {none, relu}.  x [M,K], W fp32 [N,K], b fp32 [N]."""
 
     @staticmethod
     def forward(ctx, x, W, b, relu: bool, dropout_p: float, seed: int):
+        _note_use(ctx.needs_input_grad[1], W, b)
         N = W.shape[0]
         vec = ops.vec_of(x.dtype)
         Np = ops.pad_to(N, vec)
@@ -178,10 +287,12 @@ class LinearFn(Function):
         y = ops.linear_fwd(x, wf, bias, relu=relu, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(x, y if (relu or dropout_p > 0) else None, wd)
         ctx.cfg = (relu, dropout_p, seed, N, Np, b is not None)
+        ctx.params = (W, b)
         return y[:, :N].contiguous() if Np != N else y
 
     @staticmethod
     def backward(ctx, dy):
+        _arm()
         x, y, wd = ctx.saved_tensors
         relu, p, seed, N, Np, has_b = ctx.cfg
         dy = dy.contiguous()
@@ -199,8 +310,8 @@ class LinearFn(Function):
         want_w, want_b = ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]
         dW = db = None
         if want_w:  # the bias gradient (column sums of g) rides along in the weight-gradient launch
-            db_full = ops.zeros_f32(g.shape[1], g.device) if want_b else None
-            dW = ops.linear_wgrad(g, x, dbias=db_full)[:N]
+            dW_full, db_full = _wgrad(g, x, _can_defer(*ctx.params), want_bias=want_b)
+            dW = dW_full[:N]
             db = db_full[:N] if want_b else None
         elif want_b:
             db = ops.colsum(g)[:N]
@@ -217,25 +328,27 @@ class FFNFn(Function):
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, p: float, seed1: int, seed2: int):
+        _note_use(ctx.needs_input_grad[1], W1, b1, W2, b2)
         w1f, w1d, _, _ = prepared(W1, x.dtype)
         w2f, w2d, _, _ = prepared(W2, x.dtype)
         h = ops.linear_fwd(x, w1f, b1.detach(), relu=True, dropout_p=p, seed=seed1)
         y = ops.linear_fwd(h, w2f, b2.detach(), dropout_p=p, seed=seed2)
         ctx.save_for_backward(x, h, w1d, w2d)
         ctx.cfg = (p, seed1, seed2)
+        ctx.params = (W1, b1, W2, b2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        _arm()
         x, h, w1d, w2d = ctx.saved_tensors
         p, seed1, seed2 = ctx.cfg
+        defer = _can_defer(*ctx.params)
         g2 = ops.dropout(dy.contiguous(), p, seed2) if p > 0 else dy.contiguous()
-        db2 = ops.zeros_f32(g2.shape[1], g2.device)
-        dW2 = ops.linear_wgrad(g2, h, dbias=db2)
+        dW2, db2 = _wgrad(g2, h, defer, want_bias=True)
         # dh = (g2 @ W2) * (h > 0) / (1-p): mask + scale fused in the GEMM epilogue
         dh = ops.linear_fwd(g2, w2d, mask_src=h, alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
-        db1 = ops.zeros_f32(dh.shape[1], dh.device)
-        dW1 = ops.linear_wgrad(dh, x, dbias=db1)
+        dW1, db1 = _wgrad(dh, x, defer, want_bias=True)
         dx = ops.linear_fwd(dh, w1d) if ctx.needs_input_grad[0] else None
         return dx, dW1, db1, dW2, db2, None, None, None
 
@@ -288,6 +401,7 @@ class MHAFn(Function):
 
     @staticmethod
     def forward(ctx, q_in, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_w, p_attn, seed_attn, p_out, seed_out):
+        _note_use(ctx.needs_input_grad[3], W_in, b_in, W_out, b_out)
         E = q_in.shape[1]
         dt = q_in.dtype
         same_qk = k_in is None  # self-attention with q = k = x + pos: one fused [rows, 2E] projection
@@ -311,19 +425,25 @@ class MHAFn(Function):
         out = ops.linear_fwd(ctxv.view(B * Lq, E), wo_f, b_out.detach(), dropout_p=p_out, seed=seed_out)
         ctx.save_for_backward(q_in, k_in, v_in, q, k, v, probs, ctxv, wv_d, wo_d, *wd_list)
         ctx.cfg = (B, Lq, Lk, H, E, same_qk, scale, p_attn, seed_attn, p_out, seed_out)
+        ctx.params = (W_in, b_in, W_out, b_out)
         return out, (wavg if need_w else None)
 
     @staticmethod
     def backward(ctx, dout, dwavg):
+        _arm()
         q_in, k_in, v_in, q, k, v, probs, ctxv, wv_d, wo_d, *wd_list = ctx.saved_tensors
         B, Lq, Lk, H, E, same_qk, scale, p_attn, seed_attn, p_out, seed_out = ctx.cfg
         dt = q_in.dtype
         dev = q_in.device
+        defer = _can_defer(*ctx.params)
         g = ops.dropout(dout.contiguous(), p_out, seed_out) if p_out > 0 else dout.contiguous()
-        dW_in = ops.zeros_f32((3 * E, E), dev)
-        db_in = ops.zeros_f32(3 * E, dev)
-        db_out = ops.zeros_f32(E, dev)
-        dW_out = ops.linear_wgrad(g, ctxv.view(B * Lq, E), dbias=db_out)
+        if defer:  # every row block is written by exactly one deferred job: no zero fill
+            dW_in = torch.empty((3 * E, E), dtype=torch.float32, device=dev)
+            db_in = torch.empty(3 * E, dtype=torch.float32, device=dev)
+        else:
+            dW_in = ops.zeros_f32((3 * E, E), dev)
+            db_in = ops.zeros_f32(3 * E, dev)
+        dW_out, db_out = _wgrad(g, ctxv.view(B * Lq, E), defer, want_bias=True)
         dctx = ops.linear_fwd(g, wo_d).view(B, Lq, E)
         if same_qk:
             dqk = torch.empty((B, Lq, 2 * E), dtype=dt, device=dev)
@@ -335,18 +455,18 @@ class MHAFn(Function):
         dwa = dwavg.contiguous().float() if dwavg is not None else None
         ops.mha_bwd(q, k, v, dctx, probs, dwa, H, scale, dq, dk, dv, dropout_p=p_attn, seed=seed_attn)
         dv2 = dv.view(B * Lk, E)
-        ops.linear_wgrad(dv2, v_in, out=dW_in[2 * E :], dbias=db_in[2 * E :])
+        _wgrad(dv2, v_in, defer, want_bias=True, out=dW_in[2 * E :], dbias=db_in[2 * E :])
         d_v_in = ops.linear_fwd(dv2, wv_d) if ctx.needs_input_grad[2] else None
         d_q_in = d_k_in = None
         if same_qk:
             dqk2 = dqk.view(B * Lq, 2 * E)
-            ops.linear_wgrad(dqk2, q_in, out=dW_in[: 2 * E], dbias=db_in[: 2 * E])
+            _wgrad(dqk2, q_in, defer, want_bias=True, out=dW_in[: 2 * E], dbias=db_in[: 2 * E])
             if ctx.needs_input_grad[0]:
                 d_q_in = ops.linear_fwd(dqk2, wd_list[0])
         else:
             dq2, dk2 = dq.view(B * Lq, E), dk.view(B * Lk, E)
-            ops.linear_wgrad(dq2, q_in, out=dW_in[:E], dbias=db_in[:E])
-            ops.linear_wgrad(dk2, k_in, out=dW_in[E : 2 * E], dbias=db_in[E : 2 * E])
+            _wgrad(dq2, q_in, defer, want_bias=True, out=dW_in[:E], dbias=db_in[:E])
+            _wgrad(dk2, k_in, defer, want_bias=True, out=dW_in[E : 2 * E], dbias=db_in[E : 2 * E])
             if ctx.needs_input_grad[0]:
                 d_q_in = ops.linear_fwd(dq2, wd_list[0])
             if ctx.needs_input_grad[1]:

@@ -208,13 +208,35 @@ def conv_wgrad_batch(jobs) -> list:
         outs.append(dw)
         a.g, a.src, a.dW, a.scale = g.data_ptr(), x.data_ptr(), dw.data_ptr(), (scale.data_ptr() if scale is not None else None)
         a.d = _desc(N, H, W, Cs, Ho, Wo, R, S, stride, pad, 0, Co, Co)
-        a.ldg, a.ci_real = Co, ci_real
+        a.ldg, a.ci_real, a.dbias = Co, ci_real, None
     nbytes = _hip.lib().td_conv_wgrad_batch_table_bytes(len(jobs))
     th, td_, done = job_tables.take(nbytes, jobs[0][0].device)
     check(_hip.lib().td_conv_wgrad_batch(arr, len(jobs), dtype_code(jobs[0][0].dtype), th.data_ptr(), td_.data_ptr(), nbytes, stream_ptr()),
           "td_conv_wgrad_batch")
     done()
     return outs
+
+
+def linear_wgrad_batch(jobs) -> None:
+    """ONE launch for the weight (and bias) gradients of many linear layers: jobs = list of (g [M,N], x [M,K], dW data
+    pointer of an [N,K] fp32 buffer, dbias data pointer of an [N] fp32 buffer or None).  Every output element is written
+    (no zero-initialisation needed).  g and x must stay alive until the stream has passed the launch."""
+    if not jobs:
+        return
+    arr = (_hip.WgradJob * len(jobs))()
+    for a, (g, x, dw_ptr, db_ptr) in zip(arr, jobs):
+        M, K = x.shape
+        Nn = g.shape[1]
+        assert g.shape[0] == M and g.is_contiguous() and x.is_contiguous() and g.dtype == x.dtype
+        a.g, a.src, a.dW, a.scale, a.dbias = g.data_ptr(), x.data_ptr(), dw_ptr, None, db_ptr
+        a.d = _desc(1, M, 1, K, M, 1, 1, 1, 1, 0, 0, Nn, Nn)
+        a.ldg, a.ci_real = Nn, K
+    nbytes = _hip.lib().td_conv_wgrad_batch_table_bytes(len(jobs))
+    dev = jobs[0][0].device
+    th, td_, done = job_tables.take(nbytes, dev)
+    check(_hip.lib().td_conv_wgrad_batch(arr, len(jobs), dtype_code(jobs[0][0].dtype), th.data_ptr(), td_.data_ptr(), nbytes, stream_ptr()),
+          "td_conv_wgrad_batch(linears)")
+    done()
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, residual=None, relu=False, sigmoid=False,
