@@ -53,7 +53,8 @@ def main():
             ins = []
             tensors_of((args, kw), ins)
             torch.cuda.synchronize()
-            ok_in = all(finite(t) for t in ins if t.is_cuda)
+            # an argument that is pure poison (every element NaN) is an output buffer handed in by the caller, not an input
+            ok_in = all(finite(t) or bool(torch.isnan(t.float()).all()) for t in ins if t.is_cuda and t.numel())
             r = fn(*args, **kw)
             torch.cuda.synchronize()
             outs = []
