@@ -269,6 +269,25 @@ int td_adamw_ema_step(float* param, const float* grad, float* exp_avg, float* ex
                       const int* step_dev, float beta1, float beta2, float eps, float weight_decay, float ema_decay,
                       td_stream_t stream);
 
+/* ---- SetCriterion as one launch ------------------------------------------------------------------
+ * The 24 losses of models/tubedetr.py:270-372,397-460 (L1 + GIoU over the annotated frames' boxes, start / end KL
+ * divergence against Gaussian targets, guided-attention loss) for the main output and the auxiliary decoder layers,
+ * stacked on a leading layer axis, all fp32:
+ *   boxes [nl][b*T][4] predicted cxcywh of EVERY frame; keep [n] = frame indices of the annotated frames (the
+ *   keep-gather of engine.py:83-97), tgt [n][4] their target boxes; sted [nl][b][T][2] logits (or NULL);
+ *   weights [nl][b][T][T] temporal self-attention weights (or NULL); time_mask / positive [b][T] uint8;
+ *   inter [b][2] annotated (start, end); num_boxes: device scalar if non-NULL (kept by the data-parallel harness) else
+ *   num_boxes_host; both are clamped to >= 1.
+ * losses [nl][4] = (loss_bbox, loss_giou, loss_sted, loss_guided_attn) per layer.  The same launch stores the
+ * derivative of every loss with respect to its inputs (g_l1, g_giou: [nl][b*T][4]; g_sted like sted; g_w like weights);
+ * td_criterion_bwd combines them with the upstream gradient dlosses [nl][4] into d_boxes / d_sted / d_weights. */
+int td_criterion_fwd(const float* boxes, const float* tgt, const long long* keep, const float* sted, const float* weights,
+                     const uint8_t* time_mask, const uint8_t* positive, const int* inter, const float* num_boxes_dev,
+                     float num_boxes_host, float sigma, int nl, int b, int T, int n, float* losses, float* g_l1, float* g_giou,
+                     float* g_sted, float* g_w, td_stream_t stream);
+int td_criterion_bwd(const float* dlosses, const float* g_l1, const float* g_giou, const float* g_sted, const float* g_w,
+                     float* d_boxes, float* d_sted, float* d_weights, int nl, int b, int T, td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

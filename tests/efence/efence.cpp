@@ -86,7 +86,10 @@ extern "C" void* td_efence_malloc(ssize_t size, int device, hipStream_t) {
       // TD_EFENCE_POISON=1: fresh memory is filled with 0xFF bytes (NaN as fp32 / bf16, -1 as integers), so a kernel that
       // READS memory nobody has written shows up as NaN in its results instead of depending on what the pages held
       static const bool poison = env_sz("TD_EFENCE_POISON", 0) != 0;
-      if (poison) (void)hipMemset((char*)r.base + g_gran, 0xFF, r.mapped);
+      if (poison) {  // (hipMemset may return before the fill has run: wait, or the fill could land on top of a kernel's output)
+        (void)hipMemset((char*)r.base + g_gran, 0xFF, r.mapped);
+        (void)hipDeviceSynchronize();
+      }
       g_live[p] = r;
       return p;
     }

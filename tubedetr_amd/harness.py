@@ -10,6 +10,7 @@ import torch
 from .util.misc import LRUCache, NestedTensor
 
 _IDX = LRUCache()
+_FUSED_CRITERION = [__import__("os").environ.get("TD_FUSED_CRITERION", "1") != "0"]  # 0: the stacked torch criterion (SetCriterion.forward)
 
 
 class FixedTokenizer:
@@ -58,12 +59,22 @@ def forward_step(model, criterion, weight_dict: Dict[str, float], batch: dict):
             time_mask[i, :d] = True
         hit = _IDX[key] = (torch.tensor(keep, dtype=torch.long, device=dev), time_mask.to(dev))
     keep, time_mask = hit
+    targets = batch["target_boxes"]  # (n_annotated_frames, 4); the criterion also accepts the reference's list of dicts
+    core = getattr(model, "module", model)  # DDP wrapper
+    st = getattr(core, "_last_stacked", None)
+    if (_FUSED_CRITERION[0] and st is not None and hasattr(criterion, "forward_fused") and "pred_sted" in outputs and st["pred_sted"] is not None
+            and st["weights"] is not None and tuple(st["weights"].shape[1:]) == (len(durations), t, t) and torch.is_tensor(targets)):
+        # one launch for the keep-gather + all 24 losses, one multiply + sum for the weighted total (engine.py:83-126)
+        core._last_stacked = None
+        assert len(targets) == keep.numel()
+        loss_dict = criterion.forward_fused(st, keep, targets, batch["inter_idx"], time_mask)
+        loss = (criterion.last_loss_matrix * criterion.weight_matrix(weight_dict, st["pred_boxes"].shape[0], dev)).sum()
+        return loss, loss_dict, raw, memory_cache
     outputs["pred_boxes"] = outputs["pred_boxes"][keep]
     for a in outputs.get("aux_outputs", []):
         a["pred_boxes"] = a["pred_boxes"][keep]
     if "pred_sted" not in outputs:
         time_mask = None
-    targets = batch["target_boxes"]  # (n_annotated_frames, 4); the criterion also accepts the reference's list of dicts
     assert len(targets) == len(outputs["pred_boxes"])
     loss_dict = criterion(outputs, targets, batch["inter_idx"], time_mask)
     loss = sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)

@@ -188,6 +188,10 @@ class TubeDETR(nn.Module):
         if self.sted:
             outputs_sted = Fk.cast(self.sted_embed(rows), torch.float32).view(nl, b, t, 2)
         outputs_coord = Fk.cast(self.bbox_embed(rows), torch.float32).view(nl, b * t, 4).sigmoid()
+        # the per-layer entries below are views of these stacked tensors; the fused criterion (SetCriterion.forward_fused)
+        # consumes them directly instead of re-stacking six dict entries
+        self._last_stacked = {"pred_boxes": outputs_coord, "pred_sted": outputs_sted if self.sted else None,
+                              "weights": weights if self.guided_attn else None, "b": b, "t": t}
         out["pred_boxes"] = outputs_coord[-1]
         if self.sted:
             out["pred_sted"] = outputs_sted[-1]
@@ -228,6 +232,50 @@ def _paired_giou(a, b):
     return inter / union - (hull - union) / hull
 
 
+class CriterionFn(torch.autograd.Function):
+    """All 24 losses in one HIP launch (csrc/criterion.hip); the launch also stores every loss's derivative, backward is
+    one more tiny launch that scales them by the upstream gradient of the [layers, 4] loss matrix."""
+
+    @staticmethod
+    def forward(ctx, boxes, sted, weights, tgt, keep, tm_u8, pm_u8, inter_dev, num_boxes, sigma):
+        from .. import _hip
+
+        nl, bt, _ = boxes.shape
+        b, T = tm_u8.shape
+        dev = boxes.device
+        boxes, tgt = boxes.contiguous(), tgt.contiguous().float()
+        sted = sted.contiguous() if sted is not None else None
+        weights = weights.contiguous() if weights is not None else None
+        losses = torch.empty((nl, 4), dtype=torch.float32, device=dev)
+        g_l1, g_giou = torch.empty_like(boxes), torch.empty_like(boxes)
+        g_sted = torch.empty_like(sted) if sted is not None else None
+        g_w = torch.empty_like(weights) if weights is not None else None
+        nb_dev = num_boxes if torch.is_tensor(num_boxes) else None
+        _hip.check(_hip.lib().td_criterion_fwd(_hip.ptr(boxes), _hip.ptr(tgt), _hip.ptr(keep), _hip.ptr(sted), _hip.ptr(weights), _hip.ptr(tm_u8),
+                                               _hip.ptr(pm_u8), _hip.ptr(inter_dev), _hip.ptr(nb_dev), 0.0 if nb_dev is not None else float(num_boxes),
+                                               float(sigma), nl, b, T, keep.numel(), _hip.ptr(losses), _hip.ptr(g_l1), _hip.ptr(g_giou),
+                                               _hip.ptr(g_sted), _hip.ptr(g_w), _hip.stream_ptr()), "td_criterion_fwd")
+        ctx.save_for_backward(g_l1, g_giou, g_sted, g_w)
+        ctx.dims = (nl, b, T)
+        return losses
+
+    @staticmethod
+    def backward(ctx, dl):
+        from .. import _hip
+
+        g_l1, g_giou, g_sted, g_w = ctx.saved_tensors
+        nl, b, T = ctx.dims
+        d_boxes = torch.empty_like(g_l1)
+        d_sted = torch.empty_like(g_sted) if g_sted is not None else None
+        d_w = torch.empty_like(g_w) if g_w is not None else None
+        _hip.check(_hip.lib().td_criterion_bwd(_hip.ptr(dl.contiguous().float()), _hip.ptr(g_l1), _hip.ptr(g_giou), _hip.ptr(g_sted), _hip.ptr(g_w),
+                                               _hip.ptr(d_boxes), _hip.ptr(d_sted), _hip.ptr(d_w), nl, b, T, _hip.stream_ptr()), "td_criterion_bwd")
+        return d_boxes, d_sted, d_w, None, None, None, None, None, None, None
+
+
+LOSS_COLUMNS = ("loss_bbox", "loss_giou", "loss_sted", "loss_guided_attn")
+
+
 class SetCriterion(nn.Module):
     """Same loss names / formulas as the reference (tubedetr.py:270-372, 397-460).  The reference loops over the main
     output and the 5 auxiliary decoder layers in Python (24 x ~15 tiny kernels + as many autograd nodes); here the six
@@ -240,6 +288,8 @@ class SetCriterion(nn.Module):
         self._pm_cache = LRUCache()
         self._tgt_cache = LRUCache()
         self.external_num_boxes = None
+        self.last_loss_matrix = None
+        self._fused_keys: set = set()
 
     # ---- per-loss math on stacked layers: leading dim = decoder layer ----
     def _boxes(self, src, tgt, num_boxes):  # src (Lyr, n, 4), tgt (n, 4)
@@ -290,6 +340,71 @@ class SetCriterion(nn.Module):
             return self.loss_guided_attn(outputs, num_boxes, inter_idx, positive_map, time_mask)
         raise AssertionError(f"do you really want to compute {loss} loss?")
 
+    def _num_boxes(self, n_local, dev):
+        if self.external_num_boxes is not None:
+            # the caller keeps clamp(all_reduce(#boxes)/world, 1) in a device scalar (tubedetr_amd.distributed.
+            # sync_num_boxes) so that the step itself holds no collective (HIP-graph replay on every rank)
+            return self.external_num_boxes
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            nb = torch.as_tensor([n_local], dtype=torch.float, device=dev)
+            torch.distributed.all_reduce(nb)
+            # stays a device scalar: no .item() host sync in the step (the reference syncs here, tubedetr.py:413)
+            return torch.clamp(nb / torch.distributed.get_world_size(), min=1)[0]
+        return float(max(n_local, 1))
+
+    def _positive_map(self, inter_idx, time_mask):
+        key = (tuple(map(tuple, inter_idx)), tuple(time_mask.shape), str(time_mask.device))
+        positive_map = self._pm_cache.get(key)
+        if positive_map is None:
+            pm = torch.zeros(time_mask.shape, dtype=torch.bool)
+            for kk, idx in enumerate(inter_idx):
+                if idx[0] >= 0:
+                    pm[kk, idx[0] : idx[1] + 1] = True
+            positive_map = self._pm_cache[key] = pm.to(time_mask.device)
+        return positive_map
+
+    def weight_matrix(self, weight_dict, nl: int, device) -> torch.Tensor:
+        """[layers, 4] coefficients of ``weight_dict`` in the layout of ``forward_fused``'s loss matrix (0 where a loss has
+        no weight), cached on the device: the weighted total is then one multiply + one sum."""
+        key = ("wm", tuple(sorted(weight_dict.items())), nl, str(device))
+        m = self._pm_cache.get(key)
+        if m is None:
+            rows = []
+            for l in range(nl):
+                sfx = "" if l == nl - 1 else f"_{l}"
+                rows.append([float(weight_dict.get(c + sfx, 0.0)) if (c + sfx) in self._fused_keys else 0.0 for c in LOSS_COLUMNS])
+            m = self._pm_cache[key] = torch.tensor(rows, dtype=torch.float32).to(device)
+        return m
+
+    def forward_fused(self, stacked, keep, tgt_boxes, inter_idx, time_mask):
+        """Same 24 values as ``forward`` from the decoder's stacked outputs (boxes [layers, b*t, 4] of every frame + the
+        keep indices, sted [layers, b, t, 2], weights [layers, b, t, t]) in ONE kernel launch.  Returns the reference's
+        loss dict; ``self.last_loss_matrix`` ([layers, 4], differentiable) holds the same numbers for a fused weighted sum."""
+        boxes = stacked["pred_boxes"]
+        sted = stacked["pred_sted"] if "sted" in self.losses else None
+        weights = stacked["weights"] if "guided_attn" in self.losses else None
+        dev = boxes.device
+        nl = boxes.shape[0]
+        b = len(inter_idx)
+        num_boxes = self._num_boxes(int(tgt_boxes.shape[0]), dev)
+        positive_map = self._positive_map(inter_idx, time_mask)
+        key = ("fz", tuple(map(tuple, inter_idx)), tuple(time_mask.shape), str(dev))
+        hit = self._tgt_cache.get(key)
+        if hit is None:
+            hit = self._tgt_cache[key] = (time_mask.to(torch.uint8).contiguous(), positive_map.to(torch.uint8).contiguous(),
+                                          torch.tensor([[int(x[0]), int(x[1])] for x in inter_idx], dtype=torch.int32).to(dev))
+        tm_u8, pm_u8, inter_dev = hit
+        L = CriterionFn.apply(boxes, sted, weights, tgt_boxes, keep, tm_u8, pm_u8, inter_dev, num_boxes, float(self.sigma))
+        self.last_loss_matrix = L
+        losses, self._fused_keys = {}, set()
+        for l in range(nl):
+            sfx = "" if l == nl - 1 else f"_{l}"
+            for j, c in enumerate(LOSS_COLUMNS):
+                if (c in ("loss_bbox", "loss_giou") and "boxes" in self.losses) or (c == "loss_sted" and sted is not None) or (c == "loss_guided_attn" and weights is not None):
+                    losses[c + sfx] = L[l, j]
+                    self._fused_keys.add(c + sfx)
+        return losses
+
     def forward(self, outputs, targets, inter_idx=None, time_mask=None):
         dev = next(iter(outputs.values())).device
         if torch.is_tensor(targets):  # already concatenated (n, 4) target boxes
@@ -297,27 +412,10 @@ class SetCriterion(nn.Module):
         else:
             n_local = sum(len(t["boxes"]) for t in targets)
             tgt_boxes = torch.cat([t["boxes"] for t in targets], dim=0) if "boxes" in self.losses else None
-        if self.external_num_boxes is not None:
-            # the caller keeps clamp(all_reduce(#boxes)/world, 1) in a device scalar (tubedetr_amd.distributed.
-            # sync_num_boxes) so that the step itself holds no collective (HIP-graph replay on every rank)
-            num_boxes = self.external_num_boxes
-        elif torch.distributed.is_available() and torch.distributed.is_initialized():
-            nb = torch.as_tensor([n_local], dtype=torch.float, device=dev)
-            torch.distributed.all_reduce(nb)
-            # stays a device scalar: no .item() host sync in the step (the reference syncs here, tubedetr.py:413)
-            num_boxes = torch.clamp(nb / torch.distributed.get_world_size(), min=1)[0]
-        else:
-            num_boxes = float(max(n_local, 1))
+        num_boxes = self._num_boxes(n_local, dev)
         positive_map = None
         if inter_idx is not None and time_mask is not None:
-            key = (tuple(map(tuple, inter_idx)), tuple(time_mask.shape), str(time_mask.device))
-            positive_map = self._pm_cache.get(key)
-            if positive_map is None:
-                pm = torch.zeros(time_mask.shape, dtype=torch.bool)
-                for kk, idx in enumerate(inter_idx):
-                    if idx[0] >= 0:
-                        pm[kk, idx[0] : idx[1] + 1] = True
-                positive_map = self._pm_cache[key] = pm.to(time_mask.device)
+            positive_map = self._positive_map(inter_idx, time_mask)
         aux = outputs.get("aux_outputs", [])
         layers = list(aux) + [outputs]  # main output last
         stacked = {}
