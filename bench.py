@@ -2,30 +2,38 @@
 """bench.py - training clips/sec (forward + backward) of the TubeDETR hot path on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
-torch.distributed.run with one rank per GPU (RCCL).  A "step" = one pass of the hot path over one synthetic clip
+torch.distributed.run with one rank per GPU (RCCL).  A "step" = one pass of the hot path over one synthetic batch
 per GPU: the two model calls of engine.py:67-80 (video-text encoder, then space-time decoder), the criterion, and
-the backward pass; at N>1 followed by ONE flat all-reduce of the gradients (tubedetr_amd/distributed.py; `--ddp`
-uses torch DistributedDataParallel like main.py:372-376 instead).  Rank 0 prints ONE JSON line.
+the backward pass; at N>1 plus the gradient exchange.  Rank 0 prints ONE JSON line.
 
-Workload at N=1: BASELINE.json configs[2] (the config the metric is quoted on): T=100 frames, stride k=4,
-res=352, L=30 text tokens, 1 clip per GPU, bf16 MFMA kernels with fp32 accumulation, random-init weights,
-train mode (dropout active), weights re-prepared every step (as after an optimizer step), all 125 trunk-forward
-frames executed (`--dedupe` skips the 25 slow frames inside the fast pass).  Inputs are generated on the device before
-the timed region.
+Workload at N=1: BASELINE.json configs[2] (the config the metric is quoted on): T=100 frames, stride k=4, res=352,
+L=30 text tokens, bf16 MFMA kernels with fp32 accumulation, random-init weights, train mode (dropout active),
+weights re-prepared every step (as after an optimizer step), all 125 trunk-forward frames of every clip executed
+(`--dedupe` skips the 25 slow frames inside the fast pass).  `--clips-per-gpu B` videos per GPU per step (the
+reference's --batch_size, main.py:63; 288 GB of HBM hold B = 4 clips = 50 GB of activations, and every latency-bound
+launch of the step - the 100-row decoder, RoBERTa on 30 tokens, the 12 100-row trunk backward - then does B times the
+work): `value` counts clips, not steps.  Inputs are generated on the device before the timed region.
 
-Execution: the whole step is captured once in a single-stream HIP graph and replayed (`--no-graph`: eager launches,
-host-bound).  At N=1 the measurement runs in a child process; if that process dies (a GPU memory fault was seen
-intermittently with the forked two-stream graph, `--text-stream`), the parent re-measures with eager launches, so a
-bench line is always produced; `attempts` in the JSON records what happened.
+Execution: the step is captured once in HIP graph(s) and replayed (`--no-graph`: eager launches, host-bound).
+  N = 1 : one single-stream graph.
+  N > 1 : the step is cut at the ResNet trunk boundary (harness.backward_in_stages) and captured as TWO graphs; the
+          all-reduce of the gradients that are final after the first one (heads, decoder, encoder, RoBERTa, input_proj:
+          0.57 of 0.74 GB) is started between the two replays and overlaps the trunk backward, the trunk's own 0.17 GB
+          follow (tubedetr_amd/distributed.py).  `--no-overlap`: one graph + one flat all-reduce after it; `--ddp`: torch
+          DistributedDataParallel like main.py:372-376.
+At N=1 the measurement runs in a child process; if it dies the parent re-measures with eager launches, so a bench line
+is always produced; `attempts` in the JSON records what happened.
 
 Extra legs (rank 0, after the timed region, not part of `value`):
   roofline     : `--roofline-steps` more identical steps, launched eagerly, with HIP events recorded on the launch
                  stream around every launch of the MFMA kernel families; per family achieved = algorithmic FLOPs or
-                 algorithmic HBM bytes / summed duration, bound = the roof it sits closer to, traffic = PMC-measured
-                 HBM bytes per launch (profiles/r01_pmc_traffic.json).  `roofline` is the family with the largest
-                 share of the step, the others follow in `other_mfma_kernels`.
+                 algorithmic HBM bytes / summed event-bracketed duration (nothing subtracted: the bracketing itself adds a
+                 few us per launch, reported as `event_pair_overhead_us`, so `frac` errs low against rocprofv3), bound = the
+                 roof it sits closer to.  `traffic` / `mfma_util` are NOT measured by this process: they are the
+                 rocprofv3 PMC results committed under profiles/ (counters cannot be read from inside the timed process).
+                 `roofline` is the family with the largest share of the step, the others follow in `other_mfma_kernels`.
   cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on the host cores on a bounded
-                 sample (a T=`--cpu-frames` clip of the same resolution, fwd+bwd) and scaled to T=100.
+                 sample (a T=`--cpu-frames` clip of the same resolution, fwd+bwd, median of 3) and scaled to T=100.
 """
 from __future__ import annotations
 
@@ -51,8 +59,11 @@ WORKLOADS = {
 }
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
-# algorithmic GFLOP per clip fwd+bwd
+# algorithmic TFLOP per clip fwd+bwd
 ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
+DEFAULT_CLIPS_PER_GPU = 4
+PMC_TRAFFIC = "r02_pmc_traffic.json"
+PMC_MFMA = "r02_pmc_mfma.json"
 
 
 def make_batch(T, res, k, L, seed, device, clips=1):
@@ -94,8 +105,19 @@ class BatchTokenizer:
         return be
 
 
+def cpu_model_name() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(T_sample, res, k, L, T_full):
-    """Reference algorithm on the host cores (oracle port), fwd+bwd of a T_sample-frame clip, scaled to T_full frames."""
+    """Reference algorithm on the host cores (oracle port), fwd+bwd of a T_sample-frame clip (median of 3 after one warm-up
+    unless the budget runs out), scaled to T_full frames."""
     from oracle.tubedetr_oracle import OracleConfig, train_step
     from oracle.weights import fill_state, state_spec, synthetic_batch
 
@@ -104,26 +126,37 @@ def cpu_baseline(T_sample, res, k, L, T_full):
     cfg = OracleConfig(stride=k)
     sd = fill_state(state_spec(cfg), 1, requires_grad=True)
     batch = synthetic_batch(T=T_sample, res=res, k=k, L=L, seed=5)
-    best, spent = None, 0.0
-    for _ in range(2):  # second pass = steady state; skipped when the first one already used the time budget
+    times, spent = [], 0.0
+    for it in range(4):  # pass 0 = warm-up (allocator, thread pool), then up to three measured passes within ~30 s
         for v in sd.values():
             v.grad = None
         t0 = time.time()
         loss, _, _, _ = train_step(sd, cfg, batch)
         loss.backward()
         dt = time.time() - t0
-        best = dt if best is None else min(best, dt)
         spent += dt
-        if spent > 20.0:
+        if it > 0 or spent > 15.0:
+            times.append(dt)
+        if spent > 30.0 and times:
             break
-    per_clip = best * (T_full / T_sample)
-    return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"fwd+bwd of a T={T_sample} clip (k={k}, res={res}, L={L}) by the CPU oracle in {best:.1f}s, scaled x{T_full}/{T_sample} to T={T_full}"}
+    times.sort()
+    med = times[len(times) // 2]
+    per_clip = med * (T_full / T_sample)
+    return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": cores, "cpu": cpu_model_name(), "host_logical_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"fwd+bwd of a T={T_sample} clip (k={k}, res={res}, L={L}) by the CPU oracle, median {med:.1f}s of {len(times)} passes "
+                      f"({', '.join(f'{t_:.1f}' for t_ in times)}), scaled x{T_full}/{T_sample} to T={T_full}"}
 
 
 def _trace(msg):
     if os.environ.get("TD_BENCH_TRACE"):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def _load_profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
 
 
 def main():
@@ -132,27 +165,26 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
-    ap.add_argument("--clips-per-gpu", type=int, default=1, help="videos per GPU per step (the reference's --batch_size, main.py:63)")
+    ap.add_argument("--clips-per-gpu", type=int, default=DEFAULT_CLIPS_PER_GPU, help="videos per GPU per step (the reference's --batch_size, main.py:63)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--roofline-steps", type=int, default=2)
+    ap.add_argument("--roofline-steps", type=int, default=1)
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-baseline sample clip (0 = skip)")
     ap.add_argument("--keep-prepared-weights", action="store_true", help="diagnostic: reuse prepared bf16 weights across steps")
     ap.add_argument("--dedupe", action="store_true",
                     help="do not recompute the slow frames inside the fast pass (exact, slow = video[::k]); off by default so the timed step "
                          "executes the same work as the reference's")
-    ap.add_argument("--no-dedupe", action="store_true", help="(default behaviour; kept for compatibility)")
-    ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="capture the step in a HIP graph (N=1 only)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="capture the step in HIP graph(s)")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--force-ddp", action="store_true", help="diagnostic: run the N>1 code path (process group + gradient exchange) with one rank")
-    ap.add_argument("--ddp", action="store_true", help="N>1: use torch DistributedDataParallel like main.py:372-376 instead of the flat all-reduce")
+    ap.add_argument("--ddp", action="store_true", help="N>1: use torch DistributedDataParallel like main.py:372-376 instead of the flat exchange")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: one flat all-reduce after the whole backward instead of the staged, overlapped exchange")
     ap.add_argument("--grad-wire-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the wire")
     ap.add_argument("--no-fast", action="store_true")
     ap.add_argument("--no-tsa", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: run in eval mode")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--text-stream", action="store_true",
-                    help="graph mode: keep RoBERTa on its own stream (a forked graph branch: ~0.5 ms less GPU time per step but a 24 ms "
-                         "hipGraphLaunch, and the only configuration in which a replay ever hit a GPU memory fault)")
+                    help="graph mode: keep RoBERTa on its own stream (a forked graph branch: ~0.5 ms less GPU time per step but a 24 ms hipGraphLaunch)")
     a = ap.parse_args()
 
     if os.environ.get("TD_EFENCE") == "1":  # diagnostic: electric-fence device allocator (tests/efence/), eager launches only
@@ -163,9 +195,8 @@ def main():
         a.graph, a.child = False, True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and not a.child and not a.force_ddp and a.graph and os.environ.get("TD_BENCH_ISOLATE", "1") != "0":
-        # Single-GPU run: the measurement happens in a child process.  A GPU memory fault during a graph replay (seen
-        # intermittently on fresh boxes with the forked two-stream graph) kills the process that owns the HIP context;
-        # the parent then re-measures with eager launches, which never faulted, instead of losing the bench line.
+        # Single-GPU run: the measurement happens in a child process; should it die, the parent re-measures with eager
+        # launches instead of losing the bench line.
         import subprocess
 
         argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]
@@ -198,44 +229,44 @@ def main():
     import tubedetr_amd
     from tubedetr_amd import _hip
     from tubedetr_amd import ops as ops_
-    from tubedetr_amd.harness import forward_step
+    from tubedetr_amd.functional import invalidate_prepared, set_wgrad_deferral
+    from tubedetr_amd.harness import backward_in_stages, forward_step, set_split_backward
     from tubedetr_amd.models import build_model
 
     T, res, k, L = WORKLOADS[a.workload]
+    B = max(1, a.clips_per_gpu)
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(42 + rank)  # main.py:358
     args = tubedetr_amd.default_args(stride=k, fast=not a.no_fast, no_tsa=a.no_tsa, compute_dtype=cdt, video_max_len_train=max(200, T))
     model, criterion, weight_dict = build_model(args)
     model.to(dev)
-    model.slow_frames_are_strided_fast = bool(a.dedupe and not a.no_dedupe)  # legal because the synthetic clip has slow = video[::k]
+    model.slow_frames_are_strided_fast = bool(a.dedupe)  # legal because the synthetic clip has slow = video[::k]
     model.train(not a.eval_dropout_off)
     tok = BatchTokenizer()
     model.transformer.tokenizer = tok
     net = model
     distributed = world > 1 or a.force_ddp
+    staged = distributed and not a.ddp and not a.no_overlap
     reducer = None
     if distributed and a.ddp:
+        set_wgrad_deferral(False)  # DDP's reducer hooks read every gradient the moment autograd produces it
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True)  # main.py:372-376
     elif distributed:
-        # replicas start from rank 0's weights (what DDP's constructor does), then exchange gradients with ONE flat
-        # all-reduce per step (tubedetr_amd/distributed.py); the step itself holds no collective
+        # replicas start from rank 0's weights (what DDP's constructor does), then exchange gradients through one flat
+        # buffer (tubedetr_amd/distributed.py); the forward / backward of the step itself holds no collective
         from tubedetr_amd.distributed import FlatGradAllReducer, sync_num_boxes
 
         for t_ in list(model.parameters()) + list(model.buffers()):
             torch.distributed.broadcast(t_.data, 0)
-        reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32)
+        late = [p_ for n_, p_ in model.named_parameters() if n_.startswith("backbone.") and p_.requires_grad] if staged else None
+        reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32, late=late)
         criterion.external_num_boxes = torch.ones(1, dtype=torch.float32, device=dev)
         reducer.always_communicate = a.force_ddp  # exercise the RCCL call in the 1-rank diagnostic
+        set_split_backward(model, staged)
 
     n_batches = a.warmup + a.steps + a.roofline_steps
-    batches = [make_batch(T, res, k, L, 1000 * rank + s, dev, a.clips_per_gpu) for s in range(min(n_batches, 4))]
-
-    from tubedetr_amd.functional import invalidate_prepared
-
+    batches = [make_batch(T, res, k, L, 1000 * rank + s, dev, B) for s in range(min(n_batches, 4))]
     params = [p_ for p_ in model.parameters() if p_.requires_grad]
-
-    def step(i):
-        return eager_step(i)
 
     def eager_step(i):
         b = batches[i % len(batches)]
@@ -247,18 +278,25 @@ def main():
         if reducer is not None:
             sync_num_boxes(b["target_boxes"].shape[0], criterion.external_num_boxes)
         loss, _, _, _ = forward_step(net, criterion, weight_dict, b)
-        loss.backward()
-        if reducer is not None:
-            reducer.reduce(attach=True)  # gather, ONE all-reduce, .grad re-pointed at the flat buffer (no copy back)
+        if staged:
+            backward_in_stages(model, loss, after_first_stage=lambda: reducer.launch(early=True))  # exchange overlaps the trunk backward
+            reducer.launch(early=False)
+            reducer.finish(attach=True)
+        else:
+            loss.backward()
+            if reducer is not None:
+                reducer.reduce(attach=True)  # gather, ONE all-reduce, .grad re-pointed at the flat buffer (no copy back)
         return loss
+
+    step = eager_step
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # ---- optional whole-step HIP graph (single GPU): the ~1500 launches of a step are captured once and replayed, so
-    # the host only copies the next clip into the static input buffers and bumps the dropout step counter ----
+    # ---- HIP graph(s): the ~1500 launches of a step are captured once and replayed, so the host only copies the next
+    # batch into the static input buffers and bumps the dropout step counter ----
     execution = "eager"
     if a.graph and not (distributed and a.ddp):
         try:
@@ -268,14 +306,21 @@ def main():
             counter = torch.zeros(1, dtype=torch.int32, device=dev)
             ops_.set_dropout_counter(counter)
 
-            def body():
+            def body1():
                 tok.batch = static
                 invalidate_prepared()
                 l_, _, _, _ = forward_step(net, criterion, weight_dict, static)
-                l_.backward()
+                l_.backward()  # staged: stops at the trunk boundary
                 if reducer is not None:
-                    reducer.gather()  # no collective: part of the captured step
+                    if staged:
+                        reducer.gather_stage(early=True)
+                    else:
+                        reducer.gather()  # no collective: part of the captured step
                 return l_
+
+            def body2():
+                model.backbone[0].body.backward_trunk()
+                reducer.gather_stage(early=False)
 
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -283,7 +328,9 @@ def main():
                 for _ in range(3):
                     for p_ in params:
                         p_.grad = None
-                    body()
+                    body1()
+                    if staged:
+                        body2()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             for p_ in params:
@@ -291,7 +338,12 @@ def main():
             _trace("eager warm-up on the capture side stream done")
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_loss = body()
+                static_loss = body1()
+            graph2 = None
+            if staged:
+                graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph2, pool=graph.pool()):
+                    body2()
             torch.cuda.synchronize()
             _trace("capture done")
             if reducer is not None:
@@ -305,15 +357,21 @@ def main():
                 counter.add_(1)
                 if reducer is not None:
                     sync_num_boxes(b_["target_boxes"].shape[0], criterion.external_num_boxes)
-                graph.replay()  # ends with the gather of the gradients into the flat exchange buffer
-                if reducer is not None:
+                graph.replay()
+                if staged:
+                    reducer.exchange_stage(early=True)   # 0.57 GB, overlaps the second graph (trunk backward)
+                    graph2.replay()
+                    reducer.exchange_stage(early=False)  # the trunk's 0.17 GB
+                    reducer.finish(attach=None)
+                elif reducer is not None:
                     reducer.all_reduce()  # the only collective of the step, outside the graph
                 return static_loss
 
-            execution = "hip_graph"
+            execution = "hip_graph" if not staged else "2 hip_graphs (cut at the trunk boundary, exchange overlapped)"
         except Exception as exc:  # capture not possible: measure the eager path
             ops_.set_dropout_counter(None)
             torch.cuda.synchronize()
+            step = eager_step
             execution = f"eager (graph capture failed: {type(exc).__name__}: {str(exc)[:120]})"
 
     if os.environ.get("TD_BENCH_MEMMAP"):  # fault triage: where every allocator segment / block lives before the replays start
@@ -321,6 +379,10 @@ def main():
         snap = [{"address": s_["address"], "total_size": s_["total_size"], "stream": s_["stream"], "segment_type": s_["segment_type"],
                  "blocks": [(b_["address"] if "address" in b_ else None, b_["size"], b_["state"]) for b_ in s_["blocks"]]} for s_ in torch.cuda.memory_snapshot()]
         json.dump(snap, open(os.environ["TD_BENCH_MEMMAP"], "w"))
+        open(os.environ["TD_BENCH_MEMMAP"] + ".maps", "w").write(open("/proc/self/maps").read())  # every mapping of the process (host, pinned, device apertures)
+        from tubedetr_amd.ops import job_tables as jt_
+        json.dump({"job_tables_host": [(s_[0].data_ptr(), s_[0].numel()) for s_ in jt_.slots + jt_.retired],
+                   "job_tables_dev": [(s_[1].data_ptr(), s_[1].numel()) for s_ in jt_.slots + jt_.retired]}, open(os.environ["TD_BENCH_MEMMAP"] + ".ptrs", "w"))
     for i in range(a.warmup):
         step(i)
         if os.environ.get("TD_BENCH_TRACE"):
@@ -353,16 +415,9 @@ def main():
             tname = "unsigned short" if cdt == torch.bfloat16 else "float"
             peak = PEAK_BF16_TFLOPS if cdt == torch.bfloat16 else 157.3
             fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128, *, *>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128, *, *>",
-                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, *, *>", 2: f"td::conv_wgrad_kernel|conv_wgrad_batch_kernel<{tname}>", 4: "td::pw_resident_kernel<*>"}  # * = all pipeline depths, pointwise and generic instances
-            # PMC-measured HBM traffic per launch of the same command (tools/pmc_traffic.py, committed under profiles/):
-            # counters cannot be read from inside the process being timed
-            pmc = {}
-            try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
-            except Exception:
-                pass
-            # an (event, event) pair around nothing: what the bracketing itself adds to every launch; subtracted below so
-            # that the averages can be compared with rocprofv3's kernel durations (profiles/)
+                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, *, *>", 2: f"td::conv_wgrad_batch_kernel<{tname}>", 4: "td::pw_resident_kernel<*>"}  # * = all pipeline depths, pointwise and generic instances
+            pmc, mfma = _load_profile_json(PMC_TRAFFIC), _load_profile_json(PMC_MFMA)
+            # an (event, event) pair around nothing: what the bracketing itself adds to every launch (reported, NOT subtracted)
             cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
             for e0_, e1_ in cal:
                 e0_.record()
@@ -375,20 +430,21 @@ def main():
                 _hip.check(L_.td_prof_collect(fam, code, C.byref(n), C.byref(ms), C.byref(fl)), "td_prof_collect")
                 _hip.check(L_.td_prof_collect_bytes(fam, code, C.byref(by)), "td_prof_collect_bytes")
                 if n.value:
-                    ms.value = max(ms.value - n.value * ev_over_ms, 0.5 * ms.value)
                     tfl = fl.value / (ms.value * 1e-3) / 1e12
                     gbs = by.value / (ms.value * 1e-3) / 1e9
                     hbm_bound = gbs / PEAK_HBM_GBS > tfl / peak  # the roof this family sits closer to
-                    t_ = pmc.get(kname if fam != 2 else "td::conv_wgrad_batch_kernel<%s>" % tname)
+                    t_ = pmc.get(kname)
                     traffic = (t_["fetch_bytes_per_launch"] + t_["write_bytes_per_launch"]) if (t_ and t_.get("fetch_bytes_per_launch") and t_.get("write_bytes_per_launch")) else None
+                    mu = mfma.get(kname, {}).get("mfma_util") if isinstance(mfma.get(kname), dict) else None
                     rec = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
                            "achieved": round(gbs if hbm_bound else tfl, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tfl / peak), 4),
-                           "traffic": traffic if fam != 2 else None,
-                           "traffic_note": ("HBM bytes per launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE averaged over the family's launches "
-                                            "(profiles/r01_pmc_traffic.json)") if (traffic and fam != 2) else None,
+                           "traffic": traffic,
+                           "traffic_source": (f"STATIC, not measured by this run: HBM bytes per launch from the committed rocprofv3 PMC passes of the same command "
+                                              f"(FETCH_SIZE x2 + WRITE_SIZE, profiles/{PMC_TRAFFIC})") if traffic else None,
+                           "mfma_util": mu, "mfma_util_source": (f"STATIC: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), profiles/{PMC_MFMA}") if mu is not None else None,
                            "algorithmic_bytes_per_launch": round(by.value / n.value), "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfl, 2),
-                           "launches_per_step": n.value // a.roofline_steps, "event_pair_overhead_us_subtracted": round(ev_over_ms * 1e3, 2),
+                           "launches_per_step": n.value // a.roofline_steps, "event_pair_overhead_us": round(ev_over_ms * 1e3, 2),
                            "avg_launch_us": round(ms.value * 1e3 / n.value, 2), "kernel_ms_per_step": round(ms.value / a.roofline_steps, 3),
                            "algorithmic_gflop_per_step": round(fl.value / a.roofline_steps / 1e9, 1)}
                     per.append(rec)
@@ -397,6 +453,9 @@ def main():
                 per.sort(key=lambda r: -r["kernel_ms_per_step"])
                 roofline = dict(per[0])  # the dominant kernel (largest share of the step)
                 roofline["other_mfma_kernels"] = per[1:]
+                grp = mfma.get("decoder_attention_group") if isinstance(mfma, dict) else None
+                if grp:
+                    roofline["decoder_attention_group"] = grp  # north_star's sub-target, static from profiles/
         if world == 1 and a.cpu_frames > 0:
             try:
                 cpu = cpu_baseline(max(a.cpu_frames, k), res, k, L, T)
@@ -406,16 +465,18 @@ def main():
     if os.environ.get("TD_EFENCE") == "1":
         print(f"[bench] electric fence: every allocation fenced = {efence_install.protected()}", file=sys.stderr, flush=True)
     if rank == 0:
-        clips = world * a.steps * a.clips_per_gpu
+        clips = world * a.steps * B
         value = clips / elapsed
         step_tflop = ALGO_TFLOP_PER_CLIP.get(a.workload)
         out = {
             "metric": ("training clips/sec (fwd+bwd) at T=100 k=4 res=352, 1/2/4/8 MI355X" if a.workload == "cfg3" else "training clips/sec (fwd+bwd)"), "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "clips_per_step_per_gpu": B, "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "execution": execution, "gradient_exchange": (None if not distributed else ("torch DDP (find_unused_parameters)" if a.ddp else f"flat all-reduce, {a.grad_wire_dtype} on the wire")),
-            "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, {a.clips_per_gpu} clip(s)/GPU/step, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}",
-                       "global_batch": world * a.clips_per_gpu, "parallelism": f"dp{world}", "weights": "random init (reference scheme), seed 42+rank"},
+            "execution": execution,
+            "gradient_exchange": (None if not distributed else ("torch DDP (find_unused_parameters)" if a.ddp else
+                                  (f"staged flat all-reduce overlapped with the trunk backward, {a.grad_wire_dtype} on the wire" if staged else f"flat all-reduce after backward, {a.grad_wire_dtype} on the wire"))),
+            "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, {B} clip(s)/GPU/step, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random init (reference scheme), seed 42+rank"},
             "flops_note": ("slow frames not recomputed in the fast pass (identical pixels): executed trunk-forward work is 100/125 of the "
                            "reference algorithm's; roofline fractions use executed FLOPs, step_frac_of_mfma_peak the reference algorithm's 6.847 TFLOP") if (model.slow_frames_are_strided_fast and not a.no_fast) else None,
             "step_frac_of_mfma_peak": round(step_tflop * value / world / PEAK_BF16_TFLOPS, 4) if (step_tflop and a.dtype == "bf16") else None,

@@ -160,7 +160,46 @@ def _flat_rank_dependent_usage(rank, world):
         assert m.never.weight.grad is None and m.a.weight.grad is not None
 
 
-@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce, _flat_rank_dependent_usage])
+def _flat_staged_overlap(rank, world):
+    """Staged exchange (launch(early) while the last backward stage still runs, launch(late), finish) == one flat
+    all-reduce; the early collectives are started before the late parameters even have a gradient."""
+    from tubedetr_amd.distributed import FlatGradAllReducer
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.head, self.trunk, self.tail, self.never = (torch.nn.Linear(4, 4) for _ in range(4))
+
+    for wire in (torch.float32, torch.bfloat16):
+        m = M()
+        x = torch.randn(3, 4, generator=torch.Generator().manual_seed(rank))
+        feat = m.trunk(x)
+        leaf = feat.detach().requires_grad_()
+        (m.head(leaf).sum() + m.tail(leaf).pow(2).sum()).backward()  # stage 1: stops at the trunk boundary
+        red = FlatGradAllReducer(m.parameters(), wire, late=list(m.trunk.parameters()))
+        assert [r[2] for r in red.runs] == [False, True, False]
+        assert m.trunk.weight.grad is None
+        red.launch(early=True)
+        feat.backward(leaf.grad)  # stage 2
+        red.launch(early=False)
+        red.finish(attach=True)
+        ref = M()
+        want = None
+        for r in range(world):
+            ref.zero_grad()
+            xr = torch.randn(3, 4, generator=torch.Generator().manual_seed(r))
+            f = ref.trunk(xr)
+            (ref.head(f).sum() + ref.tail(f).pow(2).sum()).backward()
+            g = [p.grad.clone() for p in (ref.head.weight, ref.trunk.weight, ref.tail.bias)]
+            want = g if want is None else [a + b for a, b in zip(want, g)]
+        tol = 1e-6 if wire == torch.float32 else 2e-2
+        for got, w in zip((m.head.weight.grad, m.trunk.weight.grad, m.tail.bias.grad), want):
+            assert torch.allclose(got, w / world, atol=tol * max(1.0, w.abs().max().item())), wire
+        assert m.never.weight.grad is None
+
+
+@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce, _flat_rank_dependent_usage, _flat_staged_overlap])
 def test_world_size_2_gloo(fn):
     _run(fn)
 

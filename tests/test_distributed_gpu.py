@@ -164,3 +164,99 @@ def test_world_size_2_real_model_one_gpu(tmp_path):
     mp.spawn(_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
     worst, n = open(out).read().split()
     assert int(n) > 300 and float(worst) < 1.0, (worst, n)  # every |got - mean| <= 1e-4 * max|mean| + 1e-6
+
+
+def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step():
+    """The N>1 execution bench.py uses: the step is cut at the trunk boundary and captured as TWO HIP graphs (forward +
+    first backward stage + gather of the early gradients | trunk backward + gather of the trunk's gradients); the
+    all-reduce of the early 0.57 GB is launched between the two replays and overlaps the trunk backward.  With a 1-rank
+    RCCL group the result must equal the gradients of a plain single-backward step."""
+    import torch.distributed as dist
+
+    from tubedetr_amd.distributed import FlatGradAllReducer, sync_num_boxes
+    from tubedetr_amd.harness import FixedTokenizer, backward_in_stages, forward_step, set_split_backward
+    from tubedetr_amd.functional import invalidate_prepared
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    os.environ["TD_TEXT_STREAM"] = "0"
+    try:
+        model, criterion, weight_dict = _small_model(torch.bfloat16)
+        batch = _clip(4)
+        model.transformer.tokenizer = FixedTokenizer(batch["input_ids"], batch["attention_mask"])
+        params = [p for p in model.parameters() if p.requires_grad]
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        criterion.external_num_boxes = torch.ones(1, dtype=torch.float32, device=dev)
+        sync_num_boxes(batch["target_boxes"].shape[0], criterion.external_num_boxes)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for p in params:
+                    p.grad = None
+                _step(model, criterion, weight_dict, batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        plain = [None if p.grad is None else p.grad.detach().float().clone() for p in params]
+        # staged, eager
+        set_split_backward(model, True)
+        late = [p for n, p in model.named_parameters() if n.startswith("backbone.") and p.requires_grad]
+        reducer = FlatGradAllReducer(params, late=late)
+        reducer.always_communicate = True
+        assert [r[2] for r in reducer.runs] == [False, True, False] and sum(r[1] - r[0] for r in reducer.runs if r[2]) == sum(p.numel() for p in late)
+        for p in params:
+            p.grad = None
+        invalidate_prepared()
+        loss, _, _, _ = forward_step(model, criterion, weight_dict, batch)
+        backward_in_stages(model, loss, after_first_stage=lambda: reducer.launch(early=True))
+        reducer.launch(early=False)
+        reducer.finish(attach=True)
+        torch.cuda.synchronize()
+
+        def check(tag):
+            n_ok = 0
+            for n, p, ref in zip(names, params, plain):
+                if ref is None:
+                    assert p.grad is None, (tag, n)
+                    continue
+                scale = ref.abs().max().clamp_min(1e-4)
+                err = ((p.grad.float() - ref).abs().max() / scale).item()
+                assert err < 2e-2, (tag, n, err)
+                n_ok += 1
+            assert n_ok > 300
+
+        check("eager")
+        # staged, two graphs sharing one memory pool
+        for p in params:
+            p.grad = None
+        reducer2 = FlatGradAllReducer(params, late=late)
+        reducer2.always_communicate = True
+        with torch.cuda.stream(side):  # job tables / caches of the split path exist before capture
+            invalidate_prepared()
+            l_, _, _, _ = forward_step(model, criterion, weight_dict, batch)
+            backward_in_stages(model, l_)
+            for p in params:
+                p.grad = None
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            invalidate_prepared()
+            l_, _, _, _ = forward_step(model, criterion, weight_dict, batch)
+            l_.backward()
+            reducer2.gather_stage(early=True)
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            model.backbone[0].body.backward_trunk()
+            reducer2.gather_stage(early=False)
+        for _ in range(3):
+            g1.replay()
+            reducer2.exchange_stage(early=True)
+            g2.replay()
+            reducer2.exchange_stage(early=False)
+            reducer2.finish(attach=True)
+        torch.cuda.synchronize()
+        check("two graphs")
+    finally:
+        os.environ.pop("TD_TEXT_STREAM", None)
+        dist.destroy_process_group()

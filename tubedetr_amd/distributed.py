@@ -35,8 +35,14 @@ def _all_reduce(t: torch.Tensor, op, group=None) -> None:
 
 
 class FlatGradAllReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], wire_dtype: torch.dtype = torch.float32, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], wire_dtype: torch.dtype = torch.float32, group=None, late=None):
+        """``late``: optional set of parameters (or ids) whose gradient only becomes final in the LAST backward stage (the
+        ResNet trunk when the step is split at the trunk boundary, harness.backward_in_stages): everything else is
+        exchanged by ``launch(early=True)`` while that stage still runs - the overlap DDP's bucketed reducer gives the
+        reference (main.py:372-376), with two collectives instead of ~30 buckets."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        late_ids = {id(p) if torch.is_tensor(p) else p for p in (late or [])}
+        self.is_late = [id(p) in late_ids for p in self.params]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         dev = self.params[0].device
@@ -49,6 +55,15 @@ class FlatGradAllReducer:
             self.views.append(self.flat[off : off + p.numel()].view_as(p))
             off += p.numel()
         self.numel = n
+        # maximal runs of consecutive parameters of the same stage: (first element, end element, late?)
+        self.runs, off = [], 0
+        for p, lt in zip(self.params, self.is_late):
+            if self.runs and self.runs[-1][2] == lt:
+                self.runs[-1][1] = off + p.numel()
+            else:
+                self.runs.append([off, off + p.numel(), lt])
+            off += p.numel()
+        self._pending: list = []
         self.always_communicate = False  # diagnostic: issue the collective even in a 1-rank group
         self._had_grad: Optional[List[bool]] = None     # which parameters had a local gradient at the last gather()
         self._global_used: Optional[List[bool]] = None  # ... on ANY rank (exchanged once, see _sync_usage)
@@ -104,6 +119,71 @@ class FlatGradAllReducer:
             _all_reduce(self.flat, op, self.group)
         if not avg:
             self.flat.div_(self.world)
+
+    # ---- staged form: exchange what is final while the rest of backward still runs ----
+    def gather_stage(self, early: bool) -> None:
+        """Fused multi-tensor copy of one stage's gradients into the flat buffer (no collective: may be captured in the
+        HIP graph of that stage)."""
+        sel = [i for i, lt in enumerate(self.is_late) if lt != early]
+        grads = [self.params[i].grad for i in sel]
+        have = [(self.views[i], g) for i, g in zip(sel, grads) if g is not None and g.data_ptr() != self.views[i].data_ptr()]
+        missing = [self.views[i] for i, g in zip(sel, grads) if g is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if self._had_grad is None or len(self._had_grad) != len(self.params):
+            self._had_grad = [True] * len(self.params)
+        for i, g in zip(sel, grads):
+            self._had_grad[i] = g is not None
+
+    def exchange_stage(self, early: bool) -> None:
+        """Start the all-reduce of one stage's runs WITHOUT waiting for it (async_op: the collective is ordered after the
+        work enqueued on the current stream so far and runs on the backend's own stream); ``finish()`` joins."""
+        if not (self.world > 1 or self.always_communicate):
+            return
+        avg = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        for a, b, lt in self.runs:
+            if lt == early:
+                continue
+            buf = self.flat[a:b]
+            if self.wire is not self.flat:
+                self.wire[a:b].copy_(buf)
+                buf = self.wire[a:b]
+            if buf.is_cuda and dist.get_backend(self.group) == "gloo":  # host-staged (tests): synchronous
+                _all_reduce(buf, op, self.group)
+                work = None
+            else:
+                work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+            self._pending.append((work, a, b, avg))
+
+    def launch(self, early: bool) -> None:
+        """gather_stage + exchange_stage: exchange what is final (early: everything but the ``late`` parameters) while the
+        rest of backward still runs."""
+        self.gather_stage(early)
+        self.exchange_stage(early)
+
+    def finish(self, attach: Optional[bool] = True) -> None:
+        """Wait (on the current stream) for the collectives started by ``launch`` and hand the averaged gradients over
+        (attach=True: ``.grad`` becomes the view of the flat buffer; False: copied back into the existing ``.grad``; None:
+        nothing - the views were attached earlier, e.g. when the step replays from HIP graphs)."""
+        for work, a, b, avg in self._pending:
+            if work is not None:
+                work.wait()
+            if self.wire is not self.flat:
+                self.flat[a:b].copy_(self.wire[a:b])
+            if not avg:
+                self.flat[a:b].div_(self.world)
+        self._pending = []
+        if self._global_used is None:
+            self._sync_usage()
+        if attach is None:
+            return
+        if attach:
+            self.attach()
+        else:
+            self.scatter()
 
     def attach(self) -> None:
         """Zero-copy hand-over: ``.grad`` of every parameter that had a gradient becomes its view of the flat buffer

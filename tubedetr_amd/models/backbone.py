@@ -93,6 +93,8 @@ class ResNetBody(nn.Module):
             setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
         self.out_channels = inplanes
         self.layers = tuple(layers)
+        self.split_backward = False
+        self._split = None
 
     def blocks(self):
         for li in range(1, 5):
@@ -106,7 +108,26 @@ class ResNetBody(nn.Module):
         """x (N,3,H,W) fp32 NCHW -> layer4 features [N,h,w,2048] NHWC in ``compute_dtype``.  ``n_grad``: only the first
         n_grad frames are back-propagated (the rest are the reference's no_grad "fast" frames run in the same pass)."""
         tw = self.trainable_weights() if torch.is_grad_enabled() else []
-        return ResNetTrunkFn.apply(self, x, compute_dtype, x.shape[0] if n_grad is None else int(n_grad), *tw)
+        feat = ResNetTrunkFn.apply(self, x, compute_dtype, x.shape[0] if n_grad is None else int(n_grad), *tw)
+        if self.split_backward and tw:
+            # cut the autograd graph at the trunk output: loss.backward() then stops here (stage 1: decoder, encoder, text
+            # encoder, input_proj) and backward_trunk() runs the trunk's backward as a separate stage - the gradient
+            # exchange of everything else overlaps it (tubedetr_amd.harness.backward_in_stages)
+            leaf = feat.detach().requires_grad_()
+            self._split = (feat, leaf)
+            return leaf
+        return feat
+
+    def backward_trunk(self) -> bool:
+        """Second backward stage of a split step; returns False when there is nothing to do."""
+        if self._split is None:
+            return False
+        feat, leaf = self._split
+        self._split = None
+        if leaf.grad is None:
+            return False
+        feat.backward(leaf.grad)
+        return True
 
 
 def _prep(conv: ConvWeight, bn: FrozenBatchNorm2d, dt, need_dgrad, cpad=None):
