@@ -6,8 +6,11 @@
 // Used by tests/efence/run_efence.py (see DESIGN.md "memory-fault investigation").
 //
 // Frees are deferred: the VA stays mapped until the next drain (device synchronise, then unmap), so in-flight kernels
-// never lose their memory; with TD_EFENCE_KEEP=1 freed ranges are unmapped but their VA is never reused, which turns
-// use-after-free into a fault as well.
+// never lose their memory.  Freed ranges are unmapped but their virtual addresses are NEVER handed out again (default,
+// TD_EFENCE_KEEP=1), which turns use-after-free into a fault as well.  TD_EFENCE_KEEP=0 returns the address ranges with
+// hipMemAddressFree - measured unusable on ROCm 7.0.2: once ranges are re-reserved and re-mapped, kernels observe stale
+// contents / NaNs in tensors nobody wrote to and eventually abort with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION (the same
+// tests are clean with KEEP=1 and with the caching allocator), i.e. an artefact of VA recycling, not of the code under test.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -40,7 +43,7 @@ size_t env_sz(const char* n, size_t dflt) {
 void drain_locked() {
   if (g_dead.empty()) return;
   (void)hipDeviceSynchronize();
-  static const bool keep = env_sz("TD_EFENCE_KEEP", 0) != 0;
+  static const bool keep = env_sz("TD_EFENCE_KEEP", 1) != 0;
   for (auto& r : g_dead) {
     if (r.vmm) {
       (void)hipMemUnmap((char*)r.base + g_gran, r.mapped);

@@ -1,0 +1,42 @@
+"""Time the spatial (3x3) trunk convolutions, forward and input-gradient, on the benchmark's shapes.  A/B an env knob of the
+library by running it twice, e.g. TD_CONV_TAP_UNIFORM=0 vs 1 (the knobs are read once per process).
+usage: conv3x3_ab.py [frames]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tubedetr_amd import ops
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 125
+dev = torch.device("cuda:0")
+SHAPES = [  # (H=W, C, stride): layer3 / layer2 / layer4 conv2 and the strided first blocks
+    (22, 256, 1), (44, 128, 1), (11, 512, 1), (44, 256, 2), (88, 128, 2)]
+g = torch.Generator(device=dev).manual_seed(0)
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(True), torch.cuda.Event(True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+
+
+for H, Cc, st in SHAPES:
+    x = torch.randn(frames, H, H, Cc, device=dev, generator=g).bfloat16()
+    wf = (torch.randn(Cc, 9 * Cc, device=dev, generator=g) * 0.02).bfloat16()
+    bias = torch.randn(Cc, device=dev, generator=g)
+    Ho = (H + 2 - 3) // st + 1
+    y = torch.empty(frames, Ho, Ho, Cc, device=dev, dtype=torch.bfloat16)
+    us = timeit(lambda: ops.conv_fwd(x, wf, bias, 3, 3, st, 1, relu=True, out=y))
+    fl = 2.0 * frames * Ho * Ho * Cc * 9 * Cc
+    print(f"fwd   N={frames} {H}x{H} C={Cc} s{st}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s")
+    if st == 1:
+        gy = torch.randn(frames, Ho, Ho, Cc, device=dev, generator=g).bfloat16()
+        wd = (torch.randn(Cc, 9 * Cc, device=dev, generator=g) * 0.02).bfloat16()
+        dx = torch.empty(frames, H, H, Cc, device=dev, dtype=torch.bfloat16)
+        us = timeit(lambda: ops.conv_dgrad(gy, wd, (H, H), 3, 3, st, 1, mask_src=x, out=dx))
+        print(f"dgrad N={frames} {H}x{H} C={Cc} s{st}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s")

@@ -1,0 +1,110 @@
+"""rocprofv3 PMC output -> per-kernel sums, and the round's MFMA-utilisation table.
+
+  aggregate:  python tools/pmc_collect.py agg <dir or *_counter_collection.csv> out.csv
+              per kernel name and counter: dispatches, sum of Counter_Value, summed duration (ns)
+              (the format tools/pmc_traffic.py reads: kernel,counter,dispatches,sum[,duration_ns])
+  mfma:       python tools/pmc_collect.py mfma <agg.csv> profiles/r02_pmc_mfma.json
+              needs SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES and GRBM_GUI_ACTIVE in the aggregate (one rocprofv3 --pmc
+              pass: SQ and GRBM counters come from different blocks, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+              mfma_util of a kernel family = sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs):
+              the fraction of SIMD-cycles of the launches' wall time in which a matrix pipe was busy
+              (SQ_VALU_MFMA_BUSY_CYCLES counts per-SIMD busy cycles summed over the chip; MI355X_MICROARCH.md, per-instruction
+              constants).  Families as in bench.py; plus north_star's group "decoder attention + its K/V projections".
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def family(name):
+    m = re.search(r"td::conv_gemm_kernel<([^,]+), (\d+), (\d+), (\d+), (true|false)", name)
+    if m:
+        return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, *, *>"
+    if "td::pw_resident_kernel" in name:
+        return "td::pw_resident_kernel<*>"
+    m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)
+    if m:
+        return f"td::{m.group(1)}<{m.group(2)}>"
+    m = re.search(r"(?<![a-z_])(td::[a-z0-9_]+)", name)
+    return m.group(1) if m else None
+
+
+def agg(src, dst):
+    files = [src] if os.path.isfile(src) else sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True))
+    acc = {}
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            key = (r["Kernel_Name"], r["Counter_Name"])
+            a = acc.setdefault(key, [0, 0.0, 0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            try:
+                a[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            except Exception:
+                pass
+    with open(dst, "w", newline="") as fo:
+        w = csv.writer(fo)
+        w.writerow(["kernel", "counter", "dispatches", "sum", "duration_ns"])
+        for (k, c), (n, s, d) in sorted(acc.items()):
+            w.writerow([k, c, n, s, d])
+    print(f"{len(acc)} (kernel, counter) rows from {len(files)} file(s) -> {dst}")
+
+
+def mfma(src, dst, command=""):
+    per = {}
+    for r in csv.DictReader(open(src)):
+        f = family(r["kernel"])
+        if f is None:
+            continue
+        d = per.setdefault(f, {})
+        a = d.setdefault(r["counter"], [0, 0.0, 0])
+        a[0] += int(r["dispatches"])
+        a[1] += float(r["sum"])
+        a[2] += int(float(r.get("duration_ns") or 0))
+    SIMDS = 256 * 4
+    res = {"_doc": "mfma_util = sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE * 1024 SIMDs) over the family's launches; "
+                   "cu_busy = sum SQ_BUSY_CU_CYCLES / (sum GRBM_GUI_ACTIVE * 256 CUs) where collected", "_command": command}
+
+    def util(names):
+        mf = ga = bc = 0.0
+        n = 0
+        for f in names:
+            c = per.get(f, {})
+            mf += c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0, 0.0, 0])[1]
+            ga += c.get("GRBM_GUI_ACTIVE", [0, 0.0, 0])[1]
+            bc += c.get("SQ_BUSY_CU_CYCLES", [0, 0.0, 0])[1]
+            n += c.get("GRBM_GUI_ACTIVE", [0, 0.0, 0])[0]
+        if ga <= 0:
+            return None
+        return {"dispatches": n, "mfma_util": round(mf / (ga * SIMDS), 4), "cu_busy": round(bc / (ga * 256), 4) if bc else None,
+                "mfma_busy_cycles": mf, "gui_active_cycles": ga}
+
+    for f in sorted(per):
+        u = util([f])
+        if u:
+            res[f] = u
+    # north_star: ">= 40 % MFMA utilisation on the space-time decoder attention (incl. its K/V projections)".  The attention
+    # kernels are separable by name; the K/V projections run on the shared GEMM kernel, so the group is reported as the
+    # attention kernels alone and as attention + the 64x128 GEMM family that carries the projections (an upper bound on
+    # the group's launches: the family also holds the encoder / decoder linears).
+    att = [f for f in per if "mha_" in f and "mfma" in f]
+    g = util(att)
+    if g:
+        res["decoder_attention_group"] = {"attention_kernels": g, "target": 0.40,
+                                          "with_gemm_family_64x128": util(att + [f for f in per if "conv_gemm_kernel" in f and ", 64, 128," in f])}
+    json.dump(res, open(dst, "w"), indent=1)
+    for f, v in res.items():
+        if isinstance(v, dict) and "mfma_util" in v:
+            print(f"{f:66s} n={v['dispatches']:5d}  mfma_util {v['mfma_util']:.3f}  cu_busy {v['cu_busy']}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "agg":
+        agg(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+    else:
+        raise SystemExit(__doc__)

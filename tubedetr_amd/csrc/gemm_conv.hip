@@ -145,8 +145,15 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // the short-K, HBM-bound 1x1 layers whose per-workgroup latency chain would otherwise be 5-6 exposed round trips.
 // PW = pointwise (1x1, stride 1, no padding, dense output rows): the gather degenerates to row m at offset m*K, so all
 // the (n,ho,wo)/(r,s,c) index arithmetic is compiled out.
-template <typename T, int BM, int BN, int NST, bool PW>
+// TU = tap-uniform tiles: a spatial conv whose channel count is a multiple of the K tile (C % BK == 0; every 3x3 of the
+// trunk) - all 8 chunks of a tile row then belong to ONE filter tap, so the tap, its validity and its pixel offset are
+// wave-uniform scalars that advance once per tile, and a DMA address is (row base + tap offset) * C + channel: a shift, an
+// and, a multiply-add and a select per instruction instead of ~20 VALU operations of per-lane (r, s, c) decomposition and
+// bounds tests.  Which taps fall inside the image is a per-row bit mask computed once per workgroup.  Forward geometry with
+// any stride, or input-gradient geometry with stride 1.
+template <typename T, int BM, int BN, int NST, bool PW, bool TU = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm_kernel(GemmParams p) {
+  static_assert(!(PW && TU), "pointwise layers have no taps");
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;   // elements per 16-byte chunk
   constexpr int BK = 128 / ES;   // K elements per tile (128 bytes per row)
@@ -181,6 +188,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
   int a_img[AI], a_hb[AI], a_wb[AI];
   bool a_ok[AI];
   uint32_t a_off[AI];
+  int a_base[AI];        // TU: pixel index of tap (0, 0) of this row (may be negative: only used for taps inside the image)
+  uint32_t a_mask[AI];   // TU: bit (r*S + s) set = tap (r, s) of this row lies inside the image
+  const int RS = d.R * d.S;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     int m = m0 + (i * 4 + wave) * 8 + lrow;
@@ -200,6 +210,19 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
         a_hb[i] = ho + d.pad;
         a_wb[i] = wo + d.pad;
       }
+      if constexpr (TU) {
+        a_base[i] = a_img[i] + a_hb[i] * d.Ws + a_wb[i];
+        uint32_t msk = 0;
+        for (int r = 0; r < d.R; ++r) {
+          const int hs = d.mode == 0 ? a_hb[i] + r : a_hb[i] - r;
+          for (int sx = 0; sx < d.S; ++sx) {
+            const int ws = d.mode == 0 ? a_wb[i] + sx : a_wb[i] - sx;
+            const bool in = (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
+            msk |= (in ? 1u : 0u) << (r * d.S + sx);
+          }
+        }
+        a_mask[i] = a_ok[i] ? msk : 0u;
+      }
     }
   }
   uint32_t b_off[BI];
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
   // running decomposition of this lane's k index into (r, s, c)
   int kk = chunk * VEC;
   int kr = 0, ks_ = 0, kc = kk;
-  if constexpr (!PW) {
+  if constexpr (!PW && !TU) {
     if (d.R * d.S > 1) {
       int tap = kk / d.C;
       kc = kk - tap * d.C;
@@ -219,15 +242,21 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
       ks_ = tap - kr * d.S;
     }
   }
+  // TU: wave-uniform tile position (tap, channel base, pixel offset of the tap); the lane only contributes its chunk
+  int t_tap = 0, t_ks = 0, t_kc = 0, t_pix = 0;
+  const int lane_c = chunk * VEC;
 
   auto issue_tile = [&](char* stage) {
     char* stA = stage;
     char* stB = stage + BM * 128;
-    const bool kvalid = kk < p.K;
+    const bool kvalid = TU ? (t_tap < RS) : (kk < p.K);
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       uint32_t off;
-      if constexpr (PW) {
+      if constexpr (TU) {
+        const bool ok = kvalid && ((a_mask[i] >> (t_tap & 31)) & 1u);
+        off = ok ? (uint32_t)((a_base[i] + t_pix) * d.C + t_kc + lane_c) * ES : OOB;
+      } else if constexpr (PW) {
         off = (kvalid && a_ok[i]) ? a_off[i] + (uint32_t)kk * ES : OOB;
       } else {
         int hs, ws;
@@ -260,7 +289,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
     }
     // advance this lane's k by one tile
     kk += BK;
-    if constexpr (!PW) {
+    if constexpr (TU) {
+      t_kc += BK;
+      if (t_kc >= d.C) {  // next tap (C is a multiple of BK: a tile never straddles two taps)
+        t_kc = 0;
+        ++t_tap;
+        if (++t_ks == d.S) { t_ks = 0; t_pix += d.mode == 0 ? d.Ws - (d.S - 1) : -(d.Ws - (d.S - 1)); }
+        else t_pix += d.mode == 0 ? 1 : -1;
+      }
+    } else if constexpr (!PW) {
       kc += BK;
       if (d.R * d.S > 1) {
         while (kc >= d.C) {
@@ -1082,9 +1119,14 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
     prof_set_bytes(by);
   }
   const bool pw = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && p.d.out_sp == 1 && d->Hs == d->Ho && d->Ws == d->Wo;
+  // tap-uniform addressing (see conv_gemm_kernel): spatial convs whose channel count is a multiple of the K tile
+  static const int tu_on = [] { const char* e_ = getenv("TD_CONV_TAP_UNIFORM"); return e_ ? atoi(e_) : 1; }();
+  const int bk = dtype == TD_BF16 ? 64 : 32;
+  const bool tu = tu_on && !pw && d->R * d->S > 1 && d->R * d->S <= 32 && d->C % bk == 0 && p.d.out_sp == 1 && (d->mode == 0 || d->stride == 1);
 #define TD_LAUNCH(TT, BMv, BNv)                                                                   \
   do {                                                                                            \
     if (pw) conv_gemm_kernel<TT, BMv, BNv, 2, true><<<grid, 256, 0, st>>>(p);                    \
+    else if (tu) conv_gemm_kernel<TT, BMv, BNv, 2, false, true><<<grid, 256, 0, st>>>(p);        \
     else conv_gemm_kernel<TT, BMv, BNv, 2, false><<<grid, 256, 0, st>>>(p);                      \
   } while (0)
   static const int deep = [] { const char* e_ = getenv("TD_CONV_DEEP"); return e_ ? atoi(e_) : 1; }();
@@ -1094,6 +1136,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   if (dtype == TD_BF16) {
     if (narrow) TD_LAUNCH(u16, 128, 64);
     else if (deep_ok && pw) conv_gemm_kernel<u16, 64, 128, 3, true><<<grid, 256, 0, st>>>(p);
+    else if (deep_ok && tu) conv_gemm_kernel<u16, 64, 128, 3, false, true><<<grid, 256, 0, st>>>(p);
     else if (deep_ok) conv_gemm_kernel<u16, 64, 128, 3, false><<<grid, 256, 0, st>>>(p);
     else if (small_m) TD_LAUNCH(u16, 64, 128);
     else TD_LAUNCH(u16, 128, 128);
