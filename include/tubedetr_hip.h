@@ -209,6 +209,11 @@ int td_add(const void* a, const void* b, void* y, size_t n, int dtype, td_stream
 /* g = dy * scale where y > 0 else 0   (ReLU / ReLU+dropout backward from the saved output y). */
 int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, float scale, int dtype, td_stream_t stream);
 
+/* GELU, exact erf form (the intermediate activation of HF RobertaModel, models/transformer.py:130-135,252-263):
+ * y = 0.5 x (1 + erf(x / sqrt 2));  backward dx = dy * (Phi(x) + x phi(x)) from the saved pre-activation x. */
+int td_gelu_fwd(const void* x, void* y, size_t n, int dtype, td_stream_t stream);
+int td_gelu_bwd(const void* dy, const void* x, void* dx, size_t n, int dtype, td_stream_t stream);
+
 /* y[i] = keep(seed, i) ? x[i] / (1-p) : 0 - the same counter-based mask as the fused epilogues
  * (element index i = row*ld + col), used standalone and to re-apply the mask in backward. */
 int td_dropout(const void* x, void* y, size_t n, float p, uint32_t seed, const uint32_t* dropout_counter, int dtype,

@@ -75,6 +75,8 @@ _SIGS = {
     "td_colsum": [_P, _P, _I, _I, _I, _I, _P],
     "td_add": [_P, _P, _P, _SZ, _I, _P],
     "td_relu_bwd": [_P, _P, _P, _SZ, _F, _I, _P],
+    "td_gelu_fwd": [_P, _P, _SZ, _I, _P],
+    "td_gelu_bwd": [_P, _P, _P, _SZ, _I, _P],
     "td_dropout": [_P, _P, _SZ, _F, _U32, _P, _I, _P],
     "td_pos_sine": [_P, _P, _I, _I, _I, _I, _F, _I, _P],
     "td_criterion_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],

@@ -198,8 +198,15 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* g, float* out,
   }
 }
 
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// d/dx of x * Phi(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
 // elementwise kernels move 16 bytes per lane per access (8 bf16 / 4 fp32); OP selects the operation:
 // 0: y = a + b (b optional)   1: y = a * scale where b > 0 else 0 (ReLU backward)   2: y = dropout(a)
+// 3: y = gelu(a) (exact erf form, HF RoBERTa's intermediate activation)   4: y = a * gelu'(b) (its backward, b = pre-activation)
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void ew_kernel(const T* a, const T* b, T* y, size_t n, float scale, uint32_t thresh, uint32_t seed_in, const uint32_t* seed_dev) {
   const uint32_t seed = (OP == 2) ? effective_seed(seed_in, seed_dev) : seed_in;
@@ -218,6 +225,8 @@ __global__ __launch_bounds__(256) void ew_kernel(const T* a, const T* b, T* y, s
       float x = Elem<T>::load(ea, k), r;
       if (OP == 0) r = x + (b ? Elem<T>::load(eb, k) : 0.f);
       else if (OP == 1) r = Elem<T>::load(eb, k) > 0.f ? x * scale : 0.f;
+      else if (OP == 3) r = gelu_f(x);
+      else if (OP == 4) r = x * gelu_grad_f(Elem<T>::load(eb, k));
       else r = dropout_keep(seed, (uint32_t)(v * VEC + k), thresh) ? x * scale : 0.f;
       Elem<T>::store(eo, k, r);
     }
@@ -227,6 +236,8 @@ __global__ __launch_bounds__(256) void ew_kernel(const T* a, const T* b, T* y, s
     float x = Elem<T>::load(a, k), r;
     if (OP == 0) r = x + (b ? Elem<T>::load(b, k) : 0.f);
     else if (OP == 1) r = Elem<T>::load(b, k) > 0.f ? x * scale : 0.f;
+    else if (OP == 3) r = gelu_f(x);
+    else if (OP == 4) r = x * gelu_grad_f(Elem<T>::load(b, k));
     else r = dropout_keep(seed, (uint32_t)k, thresh) ? x * scale : 0.f;
     Elem<T>::store(y, k, r);
   }
@@ -361,6 +372,30 @@ extern "C" int td_relu_bwd(const void* dy, const void* y, void* g, size_t n, flo
   TD_DISPATCH(dtype, (ew_kernel<u16, 1><<<gr, 256, 0, st>>>((const u16*)dy, (const u16*)y, (u16*)g, n, scale, 0, 0, nullptr)),
               (ew_kernel<float, 1><<<gr, 256, 0, st>>>((const float*)dy, (const float*)y, (float*)g, n, scale, 0, 0, nullptr)), "td_relu_bwd");
   return check_launch("td_relu_bwd");
+}
+
+extern "C" int td_gelu_fwd(const void* x, void* y, size_t n, int dtype, td_stream_t stream) {
+  TD_REQUIRE(x && y, "td_gelu_fwd: null pointer");
+  if (n == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned gr = nblk(n);
+  if (gr > 4096) gr = 4096;
+  TD_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "td_gelu_fwd: pointers must be 16-byte aligned");
+  TD_DISPATCH(dtype, (ew_kernel<u16, 3><<<gr, 256, 0, st>>>((const u16*)x, nullptr, (u16*)y, n, 1.f, 0, 0, nullptr)),
+              (ew_kernel<float, 3><<<gr, 256, 0, st>>>((const float*)x, nullptr, (float*)y, n, 1.f, 0, 0, nullptr)), "td_gelu_fwd");
+  return check_launch("td_gelu_fwd");
+}
+
+extern "C" int td_gelu_bwd(const void* dy, const void* x, void* dx, size_t n, int dtype, td_stream_t stream) {
+  TD_REQUIRE(dy && x && dx, "td_gelu_bwd: null pointer");
+  if (n == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned gr = nblk(n);
+  if (gr > 4096) gr = 4096;
+  TD_REQUIRE(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) % 16 == 0, "td_gelu_bwd: pointers must be 16-byte aligned");
+  TD_DISPATCH(dtype, (ew_kernel<u16, 4><<<gr, 256, 0, st>>>((const u16*)dy, (const u16*)x, (u16*)dx, n, 1.f, 0, 0, nullptr)),
+              (ew_kernel<float, 4><<<gr, 256, 0, st>>>((const float*)dy, (const float*)x, (float*)dx, n, 1.f, 0, 0, nullptr)), "td_gelu_bwd");
+  return check_launch("td_gelu_bwd");
 }
 
 extern "C" int td_dropout(const void* x, void* y, size_t n, float p, uint32_t seed, const uint32_t* dropout_counter, int dtype,

@@ -482,6 +482,25 @@ def multihead_attention(q_in, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, 
                        pa, _seed() if pa > 0 else 0, po, _seed() if po > 0 else 0)
 
 
+class GeluFn(Function):
+    """Exact (erf) GELU on the elementwise kernel; backward from the saved pre-activation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(g.contiguous(), x)
+
+
+def gelu(x):
+    return GeluFn.apply(x)
+
+
 class DropoutFn(Function):
     @staticmethod
     def forward(ctx, x, p, seed):

@@ -247,6 +247,7 @@ class Transformer(nn.Module):
         self.d_model, self.nhead = d_model, nhead
         self.video_max_len, self.stride = video_max_len, stride
         self.compute_dtype = torch.float32
+        self.hip_text_encoder = __import__("os").environ.get("TD_HIP_ROBERTA", "1") != "0"  # 0: HF RobertaModel as a torch module
         self._idx_cache = LRUCache()
 
     # ---- init (transformer.py:154-176) ----
@@ -303,12 +304,18 @@ class Transformer(nn.Module):
                 else:
                     side.wait_stream(main)
                     tokenized = tokenized.to(device)
-                enc = self.text_encoder(input_ids=tokenized["input_ids"], attention_mask=None if no_padding else tokenized["attention_mask"])
-                hidden_side = enc.last_hidden_state
+                if self.hip_text_encoder:  # RoBERTa on this package's kernels (models/text_encoder.py), result in the compute dtype
+                    from .text_encoder import run_roberta
+
+                    hidden_side = run_roberta(self.text_encoder, tokenized["input_ids"], tokenized["attention_mask"], self.compute_dtype,
+                                              self.training, no_padding=no_padding)
+                else:  # HF module as a stock PyTorch-ROCm graph (fp32)
+                    enc = self.text_encoder(input_ids=tokenized["input_ids"], attention_mask=None if no_padding else tokenized["attention_mask"])
+                    hidden_side = enc.last_hidden_state
             main.wait_stream(side)
             for t_ in (hidden_side, tokenized["input_ids"], tokenized["attention_mask"]):
                 t_.record_stream(main)
-            hidden = hidden_side  # (B, L, 768) fp32
+            hidden = hidden_side  # (B, L, 768)
             Bt, L, _ = hidden.shape
             rows = Fk.cast(hidden.reshape(Bt * L, -1), self.compute_dtype)
             resized = self.resizer(rows).view(Bt, L, -1)  # batch-major [B, L, d]

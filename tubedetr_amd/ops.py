@@ -403,6 +403,18 @@ def mha_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, probs: Tensor, dwavg:
     return dq, dk, dv
 
 
+def gelu_fwd(x: Tensor) -> Tensor:
+    y = torch.empty_like(x)
+    check(_hip.lib().td_gelu_fwd(ptr(x), ptr(y), x.numel(), dtype_code(x.dtype), stream_ptr()), "td_gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy: Tensor, x: Tensor) -> Tensor:
+    dx = torch.empty_like(dy)
+    check(_hip.lib().td_gelu_bwd(ptr(dy), ptr(x), ptr(dx), dy.numel(), dtype_code(dy.dtype), stream_ptr()), "td_gelu_bwd")
+    return dx
+
+
 def dropout(x: Tensor, p: float, seed: int) -> Tensor:
     y = torch.empty_like(x)
     check(_hip.lib().td_dropout(ptr(x), ptr(y), x.numel(), p, seed & 0xFFFFFFFF, _ctr() if p > 0 else None, dtype_code(x.dtype), stream_ptr()),
