@@ -49,14 +49,15 @@ def test_hip_roberta_matches_hf_module(padded):
     err = ((out - out_ref) * att[..., None]).abs().max().item()
     assert err < 2e-4 * out_ref.abs().max().item(), err
     gr = dict(ref.named_parameters())
-    worst = 0.0
+    gmax = max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)  # key biases have a mathematically zero gradient:
+    worst = 0.0                                                                           # errors are judged against the global gradient scale
     for n, p in hf.named_parameters():
         if "pooler" in n:
             assert p.grad is None
             continue
         a, b = p.grad, gr[n].grad
         assert a is not None and b is not None, n
-        e = ((a - b).abs().max() / (b.abs().max() + 1e-6)).item()
+        e = ((a - b).abs().max() / (b.abs().max() + 1e-3 * gmax)).item()
         worst = max(worst, e)
         assert e < 2e-3, (n, e)
     # bf16 throughput mode stays close
