@@ -75,10 +75,12 @@ def make_batch(T, res, k, L, seed, device, clips=1):
     ids[:, 0], ids[:, -1] = 0, 2
     cxcy = torch.rand(clips * T, 2, generator=g, device=device) * 0.6 + 0.2
     wh = torch.rand(clips * T, 2, generator=g, device=device) * 0.3 + 0.1
+    from tubedetr_amd.util.misc import FrameSources
+
     n_slow = math.ceil(T / k)
-    slow = video.view(clips, T, 3, res, res)[:, ::k].reshape(clips * n_slow, 3, res, res).contiguous()
+    slow_idx = (torch.arange(clips)[:, None] * T + torch.arange(0, T, k)[None, :]).reshape(-1).to(torch.int32).to(device)
     return {
-        "frames": slow,
+        "frames": FrameSources([(video, slow_idx)]),  # slow clip = video[::k] of every video: an index list over the same pixels (no copy)
         "frames_mask": torch.zeros((clips * n_slow, res, res), dtype=torch.bool, device=device),
         "frames_fast": video,
         "fast_mask": torch.zeros((clips * T, res, res), dtype=torch.bool, device=device),
@@ -301,6 +303,7 @@ def main():
     if a.graph and not (distributed and a.ddp):
         try:
             static = {k_: (v.clone() if torch.is_tensor(v) else v) for k_, v in batches[0].items()}
+            static["frames"] = type(batches[0]["frames"])([(static["frames_fast"], batches[0]["frames"].parts[0][1])])  # slow clip: index list over the static video
             for k_ in ("input_ids", "attention_mask"):
                 static[k_] = static[k_].to(dev)
             counter = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -23,6 +23,7 @@ extern "C" {
 
 #define TD_F32 0
 #define TD_BF16 1
+#define TD_U8 2 /* input pixels only (td_frame_source) */
 #define TD_OK 0
 #define TD_ERR_INVALID (-1)
 #define TD_ERR_LAUNCH (-2)
@@ -132,17 +133,34 @@ size_t td_conv_wgrad_batch_table_bytes(int n_jobs);
 int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev, size_t table_bytes,
                         td_stream_t stream);
 
+/* Input frames of the trunk: one or more sources of NCHW frames - fp32 (the reference's normalised samples.tensors /
+ * samples_fast.tensors, engine.py:55-57) or uint8 pixels (normalised here: (x/255 - mean[c]) * inv_std[c], the
+ * datasets' T.Normalize done on the device, so the host sends a quarter of the bytes) - concatenated in order into one
+ * NHWC T tensor with channels zero-padded to Cpad (8 bf16 / 4 fp32).  `index` (device int32[n], may be NULL) picks the
+ * source frame of every contributed frame: the slow clip is video[::k] of the SAME buffer as the fast frames
+ * (datasets/vidstg.py:250-251) - no second copy of the pixels, no concatenation.  mean / inv_std: host arrays of C floats
+ * or NULL (no normalisation). */
+typedef struct td_frame_source {
+  const void* data; /* [n_src][C][H][W] */
+  int dtype;        /* TD_F32 or TD_U8 */
+  int n;            /* frames contributed */
+  const int* index; /* device int32[n] or NULL (= 0..n-1) */
+} td_frame_source;
+int td_frames_to_nhwc(const td_frame_source* srcs, int n_srcs, int C, int H, int W, int Cpad, const float* mean,
+                      const float* inv_std, void* y, int dtype, td_stream_t stream);
+
 /* Native executor of the bottleneck-ResNet trunk (replaces the module-graph execution of torchvision resnet101 through
  * IntermediateLayerGetter, models/backbone.py:94-98, and its autograd backward).  Conv order in every array: stem,
- * then per block conv1, conv2, conv3[, downsample] (td_resnet_num_convs entries).  x_nchw: (N,3,H,W) fp32 frames;
+ * then per block conv1, conv2, conv3[, downsample] (td_resnet_num_convs entries).  srcs: the N = sum of srcs[i].n input
+ * frames (td_frames_to_nhwc: fp32 or uint8 + normalisation, optional frame index lists);
  * w_fwd/bias: prepared (FrozenBN-folded) weights of td_weight_prep; ws: caller-allocated workspace.  save=1 keeps every
  * activation for td_resnet_bwd; save=0 (the no_grad "fast" pass, models/tubedetr.py:128-129) runs in a 6-slot ring.
  * *feat points into ws: layer4 output NHWC [N][feat_hw[0]][feat_hw[1]][feat_hw[2]]. */
 size_t td_resnet_fwd_ws_bytes(int N, int H, int W, const int* nblocks, int dtype, int save);
 int td_resnet_num_convs(const int* nblocks);
-int td_resnet_fwd(const float* x_nchw, int N, int H, int W, const int* nblocks, const void* const* w_fwd,
-                  const float* const* bias, int save, void* ws, size_t ws_bytes, void** feat, int* feat_hw, int dtype,
-                  td_stream_t stream);
+int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const float* mean, const float* inv_std, int N, int H, int W,
+                  const int* nblocks, const void* const* w_fwd, const float* const* bias, int save, void* ws, size_t ws_bytes,
+                  void** feat, int* feat_hw, int dtype, td_stream_t stream);
 /* Backward through the stages >= first_train_stage (0..3; the reference trains layer2-4 = 1, backbone.py:82-89):
  * dfeat = gradient of *feat; fwd_ws = the save=1 workspace of the forward; dW[i] receives the gradient of conv i in
  * the parameter's own [Co][Ci][R][S] fp32 layout (FrozenBN scale un-folded); entries of frozen convs are ignored.

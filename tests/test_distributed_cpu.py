@@ -209,7 +209,9 @@ def test_bench_batches_are_sharded_by_rank():
 
     a = bench.make_batch(4, 32, 2, 5, 1000 * 0 + 3, torch.device("cpu"))
     b = bench.make_batch(4, 32, 2, 5, 1000 * 1 + 3, torch.device("cpu"))
-    assert a["frames"].shape == (2, 3, 32, 32) and a["frames_fast"].shape == (4, 3, 32, 32)
-    assert torch.equal(a["frames"], a["frames_fast"][::2])           # slow = every k-th fast frame (vidstg.py:250-251)
+    assert tuple(a["frames"].shape) == (2, 3, 32, 32) and a["frames_fast"].shape == (4, 3, 32, 32)
+    assert torch.equal(a["frames"].materialize(), a["frames_fast"][::2])  # slow = every k-th fast frame (vidstg.py:250-251), as an index list
+    c = bench.make_batch(4, 32, 2, 5, 3, torch.device("cpu"), clips=2)
+    assert torch.equal(c["frames"].materialize(), torch.cat([c["frames_fast"][0:4:2], c["frames_fast"][4:8:2]])) and c["durations"] == [4, 4]
     assert not torch.equal(a["frames_fast"], b["frames_fast"])       # different clip per rank
     assert a["durations"] == [4] and a["inter_idx"] == [[0, 3]] and a["target_boxes"].shape == (4, 4)

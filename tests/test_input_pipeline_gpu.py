@@ -1,0 +1,83 @@
+"""Device-side input path (tubedetr_amd/data.py + td_frames_to_nhwc): uint8 clips sent once, normalisation / layout / the
+slow-fast split done by the trunk's input kernel, against the reference's format (normalised fp32 frames, the slow clip
+as a second tensor, util/misc.py:106-178 + datasets/vidstg.py:250-251): same outputs, same losses, same gradients."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frames_to_nhwc_u8_index_matches_torch():
+    from tubedetr_amd import _hip
+    import ctypes as C
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    vid = torch.randint(0, 256, (7, 3, 10, 12), generator=g, dtype=torch.uint8).to(dev)
+    idx = torch.tensor([0, 3, 6, 2], dtype=torch.int32, device=dev)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for dt, cpad in ((torch.float32, 4), (torch.bfloat16, 8)):
+        out = torch.empty((4 + 7, 10, 12, cpad), dtype=dt, device=dev)
+        srcs = (_hip.FrameSource * 2)()
+        srcs[0].data, srcs[0].dtype, srcs[0].n, srcs[0].index = vid.data_ptr(), _hip.TD_U8, 4, idx.data_ptr()
+        srcs[1].data, srcs[1].dtype, srcs[1].n, srcs[1].index = vid.data_ptr(), _hip.TD_U8, 7, None
+        _hip.check(_hip.lib().td_frames_to_nhwc(srcs, 2, 3, 10, 12, cpad, (C.c_float * 3)(*mean), (C.c_float * 3)(*[1 / s for s in std]),
+                                                out.data_ptr(), _hip.dtype_code(dt), _hip.stream_ptr()), "td_frames_to_nhwc")
+        ref = (vid.float() / 255 - torch.tensor(mean, device=dev).view(1, 3, 1, 1)) / torch.tensor(std, device=dev).view(1, 3, 1, 1)
+        ref = torch.cat([ref[idx.long()], ref]).permute(0, 2, 3, 1)
+        tol = 1e-6 if dt == torch.float32 else 1e-2
+        assert (out[..., :3].float() - ref).abs().max().item() < tol * 3
+        assert out[..., 3:].abs().max().item() == 0
+
+
+def test_uint8_pipeline_equals_reference_format_step():
+    import tubedetr_amd
+    from oracle.weights import fill_state, state_spec
+    from oracle.tubedetr_oracle import OracleConfig
+    from tubedetr_amd.data import ClipPipeline
+    from tubedetr_amd.harness import FixedTokenizer, forward_step
+    from tubedetr_amd.models import build_model
+
+    dev = torch.device("cuda:0")
+    k, T, res, L = 2, 6, 64, 5
+    cfg = OracleConfig(stride=k)
+    sd = fill_state(state_spec(cfg), 3)
+    model, criterion, wd = build_model(tubedetr_amd.default_args(stride=k, compute_dtype=torch.float32))
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    videos = [torch.randint(0, 256, (T, 3, res, res), generator=g, dtype=torch.uint8), torch.randint(0, 256, (T, 3, res, res), generator=g, dtype=torch.uint8)]
+    ids = torch.randint(3, 50000, (2, L), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    att = torch.ones(2, L, dtype=torch.long)
+    boxes = torch.cat([torch.rand(2 * T, 2, generator=g) * 0.5 + 0.25, torch.rand(2 * T, 2, generator=g) * 0.3 + 0.1], 1)
+    inter = [[0, T - 1], [0, T - 1]]
+    model.transformer.tokenizer = FixedTokenizer(ids, att)
+    # (a) the new path
+    pipe = ClipPipeline(dev, k)
+    batch = pipe.collect(pipe.stage(videos, ids, att, boxes, inter))
+    params = [p for p in model.parameters() if p.requires_grad]
+    loss_a, ld_a, out_a, _ = forward_step(model, criterion, wd, batch)
+    loss_a.backward()
+    ga = [None if p.grad is None else p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    # (b) the reference's format: normalised fp32 frames, slow clip as a second tensor
+    body = model.backbone[0].body
+    mean = torch.tensor(body.pixel_mean).view(1, 3, 1, 1)
+    std = torch.tensor(body.pixel_std).view(1, 3, 1, 1)
+    fast = torch.cat([(v.float() / 255 - mean) / std for v in videos]).to(dev)
+    slow = torch.cat([fast[i * T : (i + 1) * T][::k] for i in range(2)])
+    ref = {"frames": slow, "frames_mask": torch.zeros(slow.shape[0], res, res, dtype=torch.bool, device=dev), "frames_fast": fast,
+           "fast_mask": torch.zeros(fast.shape[0], res, res, dtype=torch.bool, device=dev), "durations": [T, T], "input_ids": ids, "attention_mask": att,
+           "target_boxes": boxes.to(dev), "inter_idx": inter}
+    loss_b, ld_b, out_b, _ = forward_step(model, criterion, wd, ref)
+    loss_b.backward()
+    assert abs(loss_a.item() - loss_b.item()) < 1e-4 * abs(loss_b.item())
+    for key in ("pred_boxes", "pred_sted"):
+        assert (out_a[key] - out_b[key]).abs().max().item() < 1e-4
+    for p, a in zip(params, ga):
+        if a is None:
+            assert p.grad is None
+            continue
+        assert (a - p.grad).abs().max().item() <= 1e-3 * p.grad.abs().max().item() + 1e-6

@@ -30,6 +30,14 @@ class WgradJob(C.Structure):
     _fields_ = [("g", C.c_void_p), ("src", C.c_void_p), ("dW", C.c_void_p), ("scale", C.c_void_p), ("d", ConvDesc), ("ldg", C.c_int), ("ci_real", C.c_int), ("dbias", C.c_void_p)]
 
 
+TD_U8 = 2
+
+
+class FrameSource(C.Structure):
+    """td_frame_source."""
+    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int), ("n", C.c_int), ("index", C.c_void_p)]
+
+
 class OptimSegment(C.Structure):
     """td_optim_segment."""
     _fields_ = [("begin", C.c_longlong), ("end", C.c_longlong), ("group", C.c_int), ("active", C.c_int)]
@@ -61,7 +69,9 @@ _SIGS = {
     "td_conv_wgrad_bias": [_P, _P, _P, _P, C.POINTER(ConvDesc), _I, _I, _I, _P],
     "td_conv_wgrad_batch": [C.POINTER(WgradJob), _I, _I, _P, _P, _SZ, _P],
     "td_resnet_num_convs": [C.POINTER(C.c_int)],
-    "td_resnet_fwd": [_P, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ, C.POINTER(_P), C.POINTER(C.c_int), _I, _P],
+    "td_resnet_fwd": [C.POINTER(FrameSource), _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ,
+                      C.POINTER(_P), C.POINTER(C.c_int), _I, _P],
+    "td_frames_to_nhwc": [C.POINTER(FrameSource), _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P],
     "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _P, _P, _SZ, _I, _P],
     "td_weight_prep_batch": [_P, _I, _I, _I, _P],
     "td_weight_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],

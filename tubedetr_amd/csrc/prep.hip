@@ -162,6 +162,42 @@ __global__ void wgrad_finalize_kernel(const float* dw_k, const float* scale, flo
   dW[idx] = accumulate ? dW[idx] + v : v;
 }
 
+// frames of one source (NCHW, fp32 or uint8 pixels) -> NHWC T with channels zero-padded to Cpad, optionally picked by a
+// device index list and normalised on the fly ((x * in_scale - mean[c]) * inv_std[c]; uint8: in_scale = 1/255).  One thread
+// per pixel: C coalesced channel-plane reads, ONE 16-byte store of the Cpad packed channels (8 bf16 / 4 fp32).
+struct FrameNorm {
+  float mean[4], inv_std[4], in_scale;
+};
+template <typename T, typename S, int CP>
+__global__ __launch_bounds__(256) void frames_to_nhwc_kernel(const S* __restrict__ x, const int* __restrict__ index, T* __restrict__ y, int n_frames,
+                                                             int C, int H, int W, FrameNorm nm) {
+  const size_t hw = (size_t)H * W;
+  const size_t n = (size_t)n_frames * hw;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const size_t img = idx / hw, p = idx - img * hw;
+  const size_t src = index ? (size_t)index[img] : img;
+  float v[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    v[c] = 0.f;
+    if (c < C) v[c] = ((float)x[(src * C + c) * hw + p] * nm.in_scale - nm.mean[c]) * nm.inv_std[c];
+  }
+  if constexpr (sizeof(T) == 2) {
+    static_assert(CP == 8, "bf16 rows are padded to 8 channels");
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    ((uint4*)y)[idx] = o;
+  } else {
+    static_assert(CP == 4, "fp32 rows are padded to 4 channels");
+    ((float4*)y)[idx] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// generic fallback (any C / Cpad)
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* x, T* y, int N, int C, int H, int W, int Cpad) {
   const size_t n = (size_t)N * H * W;
@@ -237,9 +273,48 @@ extern "C" int td_wgrad_finalize(const float* dw_k, const float* scale, float* d
   return check_launch("td_wgrad_finalize");
 }
 
+extern "C" int td_frames_to_nhwc(const td_frame_source* srcs, int n_srcs, int C, int H, int W, int Cpad, const float* mean,
+                                 const float* inv_std, void* y, int dtype, td_stream_t stream) {
+  TD_REQUIRE(srcs && n_srcs >= 1 && y, "td_frames_to_nhwc: bad arguments");
+  TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "td_frames_to_nhwc: bad dtype");
+  TD_REQUIRE(C >= 1 && C <= 4 && Cpad == (dtype == TD_BF16 ? 8 : 4), "td_frames_to_nhwc: C must be 1..4 and Cpad the vector width of the dtype (%d)",
+             dtype == TD_BF16 ? 8 : 4);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t es = dtype == TD_BF16 ? 2 : 4;
+  size_t done = 0;
+  for (int s = 0; s < n_srcs; ++s) {
+    const td_frame_source& f = srcs[s];
+    TD_REQUIRE(f.data && f.n >= 0 && (f.dtype == TD_F32 || f.dtype == TD_U8), "td_frames_to_nhwc: source %d: null data or bad dtype", s);
+    if (f.n == 0) continue;
+    FrameNorm nm;
+    for (int c = 0; c < 4; ++c) {
+      nm.mean[c] = (mean && c < C) ? mean[c] : 0.f;
+      nm.inv_std[c] = (inv_std && c < C) ? inv_std[c] : 1.f;
+    }
+    nm.in_scale = f.dtype == TD_U8 ? 1.f / 255.f : 1.f;
+    if (f.dtype == TD_F32 && !mean) nm.in_scale = 1.f;
+    const size_t n = (size_t)f.n * H * W;
+    char* out = (char*)y + done * (size_t)H * W * Cpad * es;
+    const unsigned g = nblk(n);
+    if (dtype == TD_BF16) {
+      if (f.dtype == TD_U8) frames_to_nhwc_kernel<u16, uint8_t, 8><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
+      else frames_to_nhwc_kernel<u16, float, 8><<<g, 256, 0, st>>>((const float*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
+    } else {
+      if (f.dtype == TD_U8) frames_to_nhwc_kernel<float, uint8_t, 4><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, (float*)out, f.n, C, H, W, nm);
+      else frames_to_nhwc_kernel<float, float, 4><<<g, 256, 0, st>>>((const float*)f.data, f.index, (float*)out, f.n, C, H, W, nm);
+    }
+    done += f.n;
+  }
+  return check_launch("td_frames_to_nhwc");
+}
+
 extern "C" int td_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype,
                                td_stream_t stream) {
   TD_REQUIRE(x && y && Cpad >= C, "td_nchw_to_nhwc: bad arguments");
+  if (C <= 4 && Cpad == (dtype == TD_BF16 ? 8 : 4)) {
+    td_frame_source f = {x, TD_F32, N, nullptr};
+    return td_frames_to_nhwc(&f, 1, C, H, W, Cpad, nullptr, nullptr, y, dtype, stream);
+  }
   size_t n = (size_t)N * H * W;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TD_BF16) nchw_to_nhwc_kernel<u16><<<nblk(n), 256, 0, st>>>(x, (u16*)y, N, C, H, W, Cpad);

@@ -135,15 +135,20 @@ extern "C" int td_resnet_num_convs(const int* nblocks) {
   return n;
 }
 
-extern "C" int td_resnet_fwd(const float* x_nchw, int N, int H, int W, const int* nblocks, const void* const* w_fwd,
-                             const float* const* bias, int save, void* ws, size_t ws_bytes, void** feat, int* feat_hw,
-                             int dtype, td_stream_t stream) {
-  TD_REQUIRE(x_nchw && nblocks && w_fwd && bias && ws && feat, "td_resnet_fwd: null pointer");
+extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const float* mean, const float* inv_std, int N, int H, int W,
+                             const int* nblocks, const void* const* w_fwd, const float* const* bias, int save, void* ws,
+                             size_t ws_bytes, void** feat, int* feat_hw, int dtype, td_stream_t stream) {
+  TD_REQUIRE(srcs && n_srcs >= 1 && nblocks && w_fwd && bias && ws && feat, "td_resnet_fwd: null pointer");
   TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "td_resnet_fwd: bad dtype");
+  {
+    long long tot = 0;
+    for (int i = 0; i < n_srcs; ++i) tot += srcs[i].n;
+    TD_REQUIRE(tot == N, "td_resnet_fwd: the sources contribute %lld frames, N = %d", tot, N);
+  }
   Plan P = make_plan(N, H, W, nblocks, dtype, save);
   TD_REQUIRE(ws_bytes >= P.total, "td_resnet_fwd: workspace too small (%zu < %zu)", ws_bytes, P.total);
   char* base = (char*)ws;
-  int rc = td_nchw_to_nhwc(x_nchw, base + P.x.off, N, 3, H, W, P.x.C, dtype, stream);
+  int rc = td_frames_to_nhwc(srcs, n_srcs, 3, H, W, P.x.C, mean, inv_std, base + P.x.off, dtype, stream);
   if (rc) return rc;
   rc = run_conv(base, P.x, P.stem, N, P.convs[0], w_fwd[0], bias[0], nullptr, 1, dtype, stream);
   if (rc) return rc;

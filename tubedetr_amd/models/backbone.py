@@ -95,6 +95,8 @@ class ResNetBody(nn.Module):
         self.layers = tuple(layers)
         self.split_backward = False
         self._split = None
+        # normalisation applied on the device to uint8 input frames (datasets' T.Normalize with the ImageNet statistics)
+        self.pixel_mean, self.pixel_std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
     def blocks(self):
         for li in range(1, 5):
@@ -159,13 +161,28 @@ class ResNetTrunkFn(Function):
 
         from .. import _hip
 
-        assert x.dim() == 4 and x.shape[1] == 3, "frames must be (N,3,H,W)"
+        from ..util.misc import FrameSources
+
         L = _hip.lib()
         code = _hip.dtype_code(dt)
         vec = ops.vec_of(dt)
         save = 1 if len(trainable) > 0 else 0
-        x = x.detach().float().contiguous()
+        if not isinstance(x, FrameSources):  # one tensor of frames: fp32 (normalised, the reference's format) or uint8 pixels
+            x = x.detach()
+            x = FrameSources([((x if x.dtype == torch.uint8 else x.float()).contiguous(), None)])
+        assert len(x.shape) == 4 and x.shape[1] == 3, "frames must be (N,3,H,W)"
         N, _, H, W = x.shape
+        srcs = (_hip.FrameSource * len(x.parts))()
+        keep_alive = []
+        for fs, (t, idx) in zip(srcs, x.parts):
+            t = t.detach().contiguous()
+            keep_alive.append(t)
+            fs.data, fs.dtype = t.data_ptr(), (_hip.TD_U8 if t.dtype == torch.uint8 else _hip.TD_F32)
+            fs.n, fs.index = (idx.numel() if idx is not None else t.shape[0]), (idx.data_ptr() if idx is not None else None)
+        mean = inv_std = None
+        if x.dtype == torch.uint8:  # the datasets' T.Normalize, on the device
+            mean = (C.c_float * 3)(*body.pixel_mean)
+            inv_std = (C.c_float * 3)(*[1.0 / v for v in body.pixel_std])
         convs = _conv_list(body)
         preps = [prepared(c.weight, dt, bn=bn.fold(), need_dgrad=c.weight.requires_grad, cpad=vec if i == 0 else None)
                  for i, (c, bn) in enumerate(convs)]
@@ -174,8 +191,8 @@ class ResNetTrunkFn(Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         feat_p = C.c_void_p()
         hw = (C.c_int * 3)()
-        _hip.check(L.td_resnet_fwd(x.data_ptr(), N, H, W, nb, _ptr_array([p[0] for p in preps]), _ptr_array([p[2] for p in preps]), save,
-                                   ws.data_ptr(), nbytes, C.byref(feat_p), hw, code, _hip.stream_ptr()), "td_resnet_fwd")
+        _hip.check(L.td_resnet_fwd(srcs, len(x.parts), mean, inv_std, N, H, W, nb, _ptr_array([p[0] for p in preps]), _ptr_array([p[2] for p in preps]),
+                                   save, ws.data_ptr(), nbytes, C.byref(feat_p), hw, code, _hip.stream_ptr()), "td_resnet_fwd")
         off = feat_p.value - ws.data_ptr()
         n_el = N * hw[0] * hw[1] * hw[2]
         feat = ws[off : off + n_el * dt.itemsize].view(dt).view(N, hw[0], hw[1], hw[2])

@@ -291,7 +291,9 @@ class Transformer(nn.Module):
             main = torch.cuda.current_stream(device)
             import os
 
-            if os.environ.get("TD_TEXT_STREAM", "1") == "0":  # diagnostic: keep the text encoder on the main stream
+            if self.hip_text_encoder or os.environ.get("TD_TEXT_STREAM", "1") == "0":
+                # the HIP RoBERTa shares this step's prepared (re-cast) weights and deferred weight-gradient queue with the
+                # rest of the model: it runs on the main stream.  TD_TEXT_STREAM=0 keeps the HF module there as well.
                 side = main
             else:
                 side = self._text_stream = getattr(self, "_text_stream", None) or torch.cuda.Stream(device)
@@ -304,6 +306,15 @@ class Transformer(nn.Module):
                 else:
                     side.wait_stream(main)
                     tokenized = tokenized.to(device)
+                    if side is not main:
+                        # The ids were allocated on the MAIN stream but RoBERTa reads them on the text stream - in the forward
+                        # and again in the embedding backward (scatter-add by token id).  Without this the caching
+                        # allocator hands their block back to the main stream the moment autograd releases the saved tensor,
+                        # a main-stream kernel overwrites it while the embedding backward is still queued on the text
+                        # stream, and the scatter-add runs with garbage row indices: the GPU memory fault of round 1
+                        # ("memory-fault investigation").
+                        tokenized["input_ids"].record_stream(side)
+                        tokenized["attention_mask"].record_stream(side)
                 if self.hip_text_encoder:  # RoBERTa on this package's kernels (models/text_encoder.py), result in the compute dtype
                     from .text_encoder import run_roberta
 

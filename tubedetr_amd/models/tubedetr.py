@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import functional as Fk
-from ..util.misc import LRUCache, NestedTensor
+from ..util.misc import FrameSources, LRUCache, NestedTensor
 from .backbone import build_backbone
 from .transformer import build_transformer
 
@@ -38,6 +38,18 @@ class MLP(nn.Module):
             rows = Fk.linear(rows, layer.weight, layer.bias, relu=i < self.num_layers - 1,
                              dropout_p=float(self.dropout or 0.0), training=self.training)
         return rows
+
+
+def _parts(x):
+    return list(x.parts) if isinstance(x, FrameSources) else [(x, None)]
+
+
+def _one_tensor(x):
+    """The single un-indexed tensor behind ``x`` (a frame tensor, or a FrameSources wrapping exactly one)."""
+    if isinstance(x, FrameSources):
+        assert len(x.parts) == 1 and x.parts[0][1] is None, "dedupe needs the fast frames as one contiguous tensor"
+        return x.parts[0][0]
+    return x
 
 
 class TubeDETR(nn.Module):
@@ -125,7 +137,8 @@ class TubeDETR(nn.Module):
             n_slow = samples.tensors.shape[0]
             perm, inv = self._dedupe_index(durations, samples_fast.tensors.device)
             assert perm.numel() == samples_fast.tensors.shape[0] and n_slow == sum(math.ceil(d / k) for d in durations)
-            both = NestedTensor(samples_fast.tensors[perm], samples_fast.mask[perm])
+            # (the permutation is an index list handed to the trunk's input kernel: the pixels are not copied)
+            both = NestedTensor(FrameSources([(_one_tensor(samples_fast.tensors), perm)]), samples_fast.mask[perm])
             features, pos_all = self.backbone(both, n_slow)
             src_all, mask_all = features[-1].decompose()
             src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow]]
@@ -134,7 +147,7 @@ class TubeDETR(nn.Module):
             # slow (grad) and fast (no_grad, tubedetr.py:128-129) frames share the trunk weights: one launch sequence over
             # both, with the slow frames first; only they are saved-for / reached-by backward.
             n_slow = samples.tensors.shape[0]
-            both = NestedTensor(torch.cat([samples.tensors, samples_fast.tensors]), torch.cat([samples.mask, samples_fast.mask]))
+            both = NestedTensor(FrameSources(_parts(samples.tensors) + _parts(samples_fast.tensors)), torch.cat([samples.mask, samples_fast.mask]))
             features, pos_all = self.backbone(both, n_slow)
             src_all, mask_all = features[-1].decompose()
             src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow]]

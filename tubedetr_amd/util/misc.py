@@ -85,3 +85,41 @@ class LRUCache:
 
     def __len__(self):
         return len(self._d)
+
+
+class FrameSources:
+    """The trunk's input frames as an ordered list of sources instead of one concatenated tensor: each part is
+    ``(frames (n_src, 3, H, W) fp32 | uint8, index)`` where ``index`` (device int32 tensor or None) picks the source frame
+    of every contributed frame.  The slow clip and the fast frames of a step can then be two views of ONE buffer
+    (slow = video[::k], datasets/vidstg.py:250-251) and uint8 pixels are normalised on the device
+    (td_frames_to_nhwc) - no torch.cat / index copy of hundreds of MB of pixels, a quarter of the host-to-device bytes.
+    Quacks like the ``tensors`` field of a NestedTensor where the trunk needs it (shape, device, dtype, to)."""
+
+    def __init__(self, parts):
+        self.parts = [(t, (i.to(torch.int32).contiguous() if i is not None else None)) for t, i in parts]
+        t0 = self.parts[0][0]
+        assert all(t.dim() == 4 and t.shape[1:] == t0.shape[1:] and t.dtype == t0.dtype for t, _ in self.parts), "sources must share C, H, W and dtype"
+        assert t0.dtype in (torch.float32, torch.uint8), "frames must be fp32 (normalised) or uint8 pixels"
+
+    @property
+    def n_frames(self):
+        return sum((i.numel() if i is not None else t.shape[0]) for t, i in self.parts)
+
+    @property
+    def shape(self):
+        return torch.Size((self.n_frames,) + tuple(self.parts[0][0].shape[1:]))
+
+    @property
+    def device(self):
+        return self.parts[0][0].device
+
+    @property
+    def dtype(self):
+        return self.parts[0][0].dtype
+
+    def to(self, device, non_blocking: bool = False):
+        return FrameSources([(t.to(device, non_blocking=non_blocking), (i.to(device, non_blocking=non_blocking) if i is not None else None)) for t, i in self.parts])
+
+    def materialize(self) -> torch.Tensor:
+        """The concatenated (N, 3, H, W) tensor the sources describe (tests / fallbacks)."""
+        return torch.cat([(t[i.long()] if i is not None else t) for t, i in self.parts])
