@@ -311,6 +311,11 @@ int td_criterion_fwd(const float* boxes, const float* tgt, const long long* keep
 int td_criterion_bwd(const float* dlosses, const float* g_l1, const float* g_giou, const float* g_sted, const float* g_w,
                      float* d_boxes, float* d_sted, float* d_weights, int nl, int b, int T, td_stream_t stream);
 
+/* PostProcessSTVG (models/postprocessors.py:13-84): per video the (start, end) index pair with end > start that maximises
+ * log_softmax(steds[:, :, 0])[start] + log_softmax(steds[:, :, 1])[end]; first index on ties, like torch.max.
+ * steds [n_videos][T][2] fp32 logits (-inf on padded positions), start_end [n_videos][2] int64. */
+int td_sted_decode(const float* steds, long long* start_end, int n_videos, int T, td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

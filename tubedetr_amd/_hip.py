@@ -91,6 +91,7 @@ _SIGS = {
     "td_pos_sine": [_P, _P, _I, _I, _I, _I, _F, _I, _P],
     "td_criterion_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "td_criterion_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "td_sted_decode": [_P, _P, _I, _I, _P],
     "td_grad_norm_clip": [_P, _SZ, C.POINTER(OptimSegment), _I, _F, _P, _SZ, _P, _P, _P],
     "td_adamw_ema_step": [_P, _P, _P, _P, _P, _SZ, C.POINTER(OptimSegment), _I, _P, _P, _P, _F, _F, _F, _F, _F, _P],
     "td_mha_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],

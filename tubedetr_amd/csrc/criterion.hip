@@ -230,3 +230,63 @@ extern "C" int td_criterion_bwd(const float* dlosses, const float* g_l1, const f
                                                                                       n_box, n_sted, n_w, nl);
   return check_launch("td_criterion_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Evaluation path: PostProcessSTVG (models/postprocessors.py:13-84) - the most likely (start, end) pair
+// with end > start under the product of the start / end softmax distributions.  One workgroup per video; same arithmetic
+// order as the reference (log_softmax, then (log p_start[s] + log p_end[e]) maximised over s < e, first index on ties),
+// so the returned indices are bit-identical to torch's.
+namespace td {
+
+__global__ __launch_bounds__(256) void sted_decode_kernel(const float* __restrict__ steds, long long* __restrict__ out, int T) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ls = smem;          // log p_start
+  float* le = smem + T;      // log p_end
+  float* best = smem + 2 * T;  // per end index: best score
+  int* arg = (int*)(smem + 3 * T);
+  __shared__ float red[4];
+  const int v = blockIdx.x, t = threadIdx.x;
+  const float* z = steds + (size_t)v * T * 2;
+  for (int c = 0; c < 2; ++c) {
+    float mx = -INFINITY;
+    for (int j = t; j < T; j += 256) mx = fmaxf(mx, z[(size_t)j * 2 + c]);
+    mx = block_max(mx, red);
+    float se = 0.f;
+    for (int j = t; j < T; j += 256) se += expf(z[(size_t)j * 2 + c] - mx);
+    se = block_sum(se, red);
+    const float lse = logf(se);
+    float* dst = c == 0 ? ls : le;
+    for (int j = t; j < T; j += 256) dst[j] = (z[(size_t)j * 2 + c] - mx) - lse;  // log_softmax: (x - max) - log(sum exp(x - max))
+  }
+  __syncthreads();
+  for (int e = t; e < T; e += 256) {
+    float bv = -INFINITY;
+    int bs = 0;
+    const float lee = le[e];
+    for (int s = 0; s < e; ++s) {
+      const float val = ls[s] + lee;
+      if (val > bv) { bv = val; bs = s; }
+    }
+    best[e] = bv;
+    arg[e] = bs;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float bv = -INFINITY;
+    int be = 0;
+    for (int e = 0; e < T; ++e)
+      if (best[e] > bv) { bv = best[e]; be = e; }
+    out[v * 2 + 0] = arg[be];
+    out[v * 2 + 1] = be;
+  }
+}
+
+}  // namespace td
+
+extern "C" int td_sted_decode(const float* steds, long long* start_end, int n_videos, int T, td_stream_t stream) {
+  TD_REQUIRE(steds && start_end && n_videos >= 1 && T >= 1, "td_sted_decode: bad arguments");
+  const size_t lds = (size_t)4 * T * sizeof(float);
+  TD_REQUIRE(lds <= 60 * 1024, "td_sted_decode: T=%d too long (max 3840 frames per video)", T);
+  td::sted_decode_kernel<<<n_videos, 256, lds, (hipStream_t)stream>>>(steds, start_end, T);
+  return td::check_launch("td_sted_decode");
+}

@@ -291,9 +291,7 @@ class Transformer(nn.Module):
             main = torch.cuda.current_stream(device)
             import os
 
-            if self.hip_text_encoder or os.environ.get("TD_TEXT_STREAM", "1") == "0":
-                # the HIP RoBERTa shares this step's prepared (re-cast) weights and deferred weight-gradient queue with the
-                # rest of the model: it runs on the main stream.  TD_TEXT_STREAM=0 keeps the HF module there as well.
+            if os.environ.get("TD_TEXT_STREAM", "1") == "0":  # keep the text encoder on the main stream (single-stream HIP graph)
                 side = main
             else:
                 side = self._text_stream = getattr(self, "_text_stream", None) or torch.cuda.Stream(device)
@@ -301,6 +299,10 @@ class Transformer(nn.Module):
             # HIP stream, concurrently with the trunk's large GEMM kernels; autograd replays its backward there too.
             with torch.cuda.stream(side):
                 if ids.device.type == "cpu":  # async H2D from pinned memory, on the side stream: no sync with the trunk
+                    if self.hip_text_encoder and side is not main:
+                        # the HIP RoBERTa reads this step's prepared (re-cast) weights, which the main stream refreshed in the
+                        # backbone forward: order the side stream behind that launch (the HF module reads the fp32 parameters)
+                        side.wait_stream(main)
                     tokenized["input_ids"] = ids.pin_memory().to(device, non_blocking=True)
                     tokenized["attention_mask"] = att.pin_memory().to(device, non_blocking=True)
                 else:

@@ -45,7 +45,7 @@ class _ZeroArena:
         return out
 
 
-_ARENA = _ZeroArena()
+_ARENAS: dict = {}  # one arena per launch stream: a chunk returns to the allocator pool of the stream that allocated it
 
 
 _USE_ARENA = __import__("os").environ.get("TD_ZERO_ARENA", "1") != "0"
@@ -54,7 +54,11 @@ _USE_ARENA = __import__("os").environ.get("TD_ZERO_ARENA", "1") != "0"
 def zeros_f32(shape, device) -> torch.Tensor:
     if not _USE_ARENA:
         return torch.zeros(shape, dtype=torch.float32, device=device)
-    return _ARENA.take(tuple(shape) if not isinstance(shape, int) else (shape,), device)
+    key = (str(device), stream_ptr() if device.type == "cuda" else 0)
+    arena = _ARENAS.get(key)
+    if arena is None:
+        arena = _ARENAS[key] = _ZeroArena()
+    return arena.take(tuple(shape) if not isinstance(shape, int) else (shape,), device)
 
 
 def vec_of(dt: torch.dtype) -> int:

@@ -35,6 +35,40 @@ def reference_group(name: str) -> int:
     return 0
 
 
+def adjust_learning_rate(optimizer, epoch: int, curr_step: int, num_training_steps: int, args) -> None:
+    """The reference's schedule (util/optim.py:28-95) on any optimizer exposing the three ``param_groups`` (this module's
+    FusedAdamWEMA or torch's): "step" (all rates / 10 after lr_drop epochs), "multistep" (halved at lr_drop, then every 50
+    epochs), "linear_with_warmup" (text encoder: linear warm-up over fraction_warmup_steps, then linear decay to 0; the
+    rest as "step"), "all_linear_with_warmup" (every rate follows the text encoder's)."""
+    from bisect import bisect_right
+
+    warm = round(args.fraction_warmup_steps * num_training_steps)
+
+    def linear():
+        if curr_step < warm:
+            return float(curr_step) / float(max(1, warm))
+        return max(0.0, float(num_training_steps - curr_step) / float(max(1, num_training_steps - warm)))
+
+    if args.schedule == "step":
+        gamma = 0.1 ** (epoch // args.lr_drop)
+        text_gamma = gamma
+    elif args.schedule == "multistep":
+        gamma = 0.5 ** bisect_right(list(range(args.lr_drop, args.epochs, 50)), epoch)
+        text_gamma = gamma
+    elif args.schedule == "linear_with_warmup":
+        gamma = 0.1 ** (epoch // args.lr_drop)
+        text_gamma = linear()
+    elif args.schedule == "all_linear_with_warmup":
+        text_gamma = linear()
+        gamma = text_gamma
+    else:
+        raise NotImplementedError(args.schedule)
+    base = [args.lr, args.lr_backbone, args.text_encoder_lr]
+    assert len(optimizer.param_groups) == len(base)
+    for group, lr, gm in zip(optimizer.param_groups, base, [gamma, gamma, text_gamma]):
+        group["lr"] = lr * gm
+
+
 class FusedAdamWEMA:
     def __init__(self, model: torch.nn.Module, lr: float = 5e-5, lr_backbone: float = 1e-5, text_encoder_lr: float = 5e-5,
                  weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 0.1,

@@ -123,3 +123,26 @@ class FrameSources:
     def materialize(self) -> torch.Tensor:
         """The concatenated (N, 3, H, W) tensor the sources describe (tests / fallbacks)."""
         return torch.cat([(t[i.long()] if i is not None else t) for t, i in self.parts])
+
+
+def split_into_windows(batch: dict, div_vid: int) -> dict:
+    """Windowed inference over long videos (util/misc.py:70-101, ``video_collate_fn(..., div_vid)``): every video of
+    ``durations`` is cut into ceil(t / div_vid) consecutive forward windows; captions and video ids are repeated per
+    window and the annotated interval is clipped to each window ([-100, -100] where it does not intersect).  Returns the
+    updated entries (durations, captions, video_ids, inter_idx); PostProcessSTVG re-assembles windows sharing a video id."""
+    import math
+
+    if not div_vid:
+        return batch
+    out = dict(batch)
+    n_fwds = [math.ceil(t / div_vid) for t in batch["durations"]]
+    out["durations"] = [min(div_vid, t - i * div_vid) for t, n in zip(batch["durations"], n_fwds) for i in range(n)]
+    out["captions"] = [c for c, n in zip(batch["captions"], n_fwds) for _ in range(n)]
+    out["video_ids"] = [v for v, n in zip(batch["video_ids"], n_fwds) for _ in range(n)]
+    inter = []
+    for (start, end), n in zip(batch["inter_idx"], n_fwds):
+        for i in range(n):
+            lo, hi = max(i * div_vid, start), min((i + 1) * div_vid - 1, end)
+            inter.append([-100, -100] if lo > hi else [lo - i * div_vid, hi - i * div_vid])
+    out["inter_idx"] = inter
+    return out
