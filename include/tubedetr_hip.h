@@ -245,7 +245,8 @@ int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, fl
 /* Multi-head attention core on already projected q,k,v (nn.MultiheadAttention internals,
  * models/transformer.py:613,638-640 encoder; 661,713-719 temporal self-attention; 662,734-740
  * time-aligned cross-attention with Lq=1).  Batch-major rows: q [B][Lq] rows of stride ldq, head h in
- * columns h*hd..h*hd+hd-1 (hd = 32); k,v [B][Lk] likewise; key_pad [B][Lk] uint8 (1 = ignore) or NULL.
+ * columns h*hd..h*hd+hd-1 (hd = 32: TubeDETR's transformer, MFMA kernels in bf16; hd = 64: RoBERTa's 12 x 64 heads, fp32-math
+ * kernels in both dtypes); k,v [B][Lk] likewise; key_pad [B][Lk] uint8 (1 = ignore) or NULL.
  * scores = scale * q.k; probs [B][H][Lq][Lk] fp32 = softmax (pre-dropout, saved for backward);
  * out [B][Lq] rows of stride ldo = dropout(probs) @ v; wavg [B][Lq][Lk] fp32 = head average of the
  * post-dropout probabilities (what nn.MultiheadAttention returns) or NULL. */

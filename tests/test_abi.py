@@ -35,7 +35,7 @@ def test_errors_are_reported_not_swallowed():
     d = _hip.ConvDesc(1, 4, 4, 3, 4, 4, 1, 1, 1, 0, 0, 8, 8, 1, 0, 0)  # C=3 is not a multiple of the vector width
     rc = L.td_conv_gemm(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.byref(d), None, _hip.TD_BF16, None)
     assert rc != 0 and b"multiple" in L.td_last_error()
-    rc = L.td_mha_fwd(*( [ctypes.c_void_p(16)] * 3 + [None, ctypes.c_void_p(16), ctypes.c_void_p(16), None] + [1, 8, 4, 4, 64, 512, 512, 512, 512, 0.1, 0.0, 0, None, 0, None]))
+    rc = L.td_mha_fwd(*( [ctypes.c_void_p(16)] * 3 + [None, ctypes.c_void_p(16), ctypes.c_void_p(16), None] + [1, 8, 4, 4, 48, 512, 512, 512, 512, 0.1, 0.0, 0, None, 0, None]))
     assert rc != 0 and b"head dim" in L.td_last_error()
 
 

@@ -87,7 +87,8 @@ def test_graph_captured_gather_allreduce_attach_equals_plain_step():
         reducer = FlatGradAllReducer(params)
         reducer.always_communicate = True  # issue the RCCL call although the group has one rank
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: the RCCL watchdog thread may query its events while this thread captures (global mode would fail the capture or the watchdog)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             _step(model, criterion, weight_dict, batch)
             reducer.gather()
         reducer.attach()
@@ -106,8 +107,17 @@ def test_graph_captured_gather_allreduce_attach_equals_plain_step():
             assert err < 2e-2, (n, err)
             checked += 1
         assert checked > 300
+    except BaseException:
+        import traceback
+
+        traceback.print_exc()  # (a device error makes destroy_process_group abort the process: show the cause first)
+        raise
     finally:
         os.environ.pop("TD_TEXT_STREAM", None)
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
         dist.destroy_process_group()
 
 
@@ -241,12 +251,12 @@ def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
             invalidate_prepared()
             l_, _, _, _ = forward_step(model, criterion, weight_dict, batch)
             l_.backward()
             reducer2.gather_stage(early=True)
-        with torch.cuda.graph(g2, pool=g1.pool()):
+        with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
             model.backbone[0].body.backward_trunk()
             reducer2.gather_stage(early=False)
         for _ in range(3):
@@ -257,6 +267,15 @@ def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step():
             reducer2.finish(attach=True)
         torch.cuda.synchronize()
         check("two graphs")
+    except BaseException:
+        import traceback
+
+        traceback.print_exc()  # (a device error makes destroy_process_group abort the process: show the cause first)
+        raise
     finally:
         os.environ.pop("TD_TEXT_STREAM", None)
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
         dist.destroy_process_group()

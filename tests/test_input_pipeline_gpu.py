@@ -80,5 +80,7 @@ def test_uint8_pipeline_equals_reference_format_step():
         if a is None:
             assert p.grad is None
             continue
-        # (the two paths round the normalised pixels differently in the last bit; through the L1 / GIoU kinks that is ~1e-3 on some gradients)
-        assert (a - p.grad).abs().max().item() <= 5e-3 * p.grad.abs().max().item() + 1e-6
+        # the two paths round the normalised pixels differently in the last bit ((x * (1/255) - m) * (1/s) vs (x / 255 - m) / s);
+        # 104 convolutions and the min / max / sign kinks of the losses amplify that to ~1e-3 .. 1e-2 on individual gradient entries,
+        # so the comparison is per parameter in norm (a wrong frame order or normalisation constant would be O(1))
+        assert (a - p.grad).norm().item() <= 2e-2 * p.grad.norm().item() + 1e-6

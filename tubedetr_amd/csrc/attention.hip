@@ -31,29 +31,30 @@ struct MhaParams {
 
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <typename T>
+template <typename T, int HDV>
 __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int LS = HDV + 1;  // odd row stride: conflict-free column walks
   const int Lk = p.Lk, Lq = p.Lq;
   float* sK = sm;
-  float* sV = sK + Lk * 33;
-  float* sP = sV + Lk * 33;  // [4][Lk]
+  float* sV = sK + Lk * LS;
+  float* sP = sV + Lk * LS;  // [4][Lk]
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-  for (int idx = t; idx < Lk * HD; idx += 256) {
-    int kk = idx >> 5, d = idx & 31;
-    sK[kk * 33 + d] = Elem<T>::load(p.k, (size_t)(b * Lk + kk) * p.ldk + h * HD + d);
-    sV[kk * 33 + d] = Elem<T>::load(p.v, (size_t)(b * Lk + kk) * p.ldv + h * HD + d);
+  for (int idx = t; idx < Lk * HDV; idx += 256) {
+    int kk = idx / HDV, d = idx - kk * HDV;
+    sK[kk * LS + d] = Elem<T>::load(p.k, (size_t)(b * Lk + kk) * p.ldk + h * HDV + d);
+    sV[kk * LS + d] = Elem<T>::load(p.v, (size_t)(b * Lk + kk) * p.ldv + h * HDV + d);
   }
   __syncthreads();
   const int q0 = blockIdx.y * QT;
   const int q1 = min(Lq, q0 + QT);
   float* myP = sP + wave * Lk;
   for (int qi = q0 + wave; qi < q1; qi += 4) {
-    float qv[HD];
-    const size_t qoff = (size_t)(b * Lq + qi) * p.ldq + h * HD;
+    float qv[HDV];
+    const size_t qoff = (size_t)(b * Lq + qi) * p.ldq + h * HDV;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) qv[d] = Elem<T>::load(p.q, qoff + d);
+    for (int d = 0; d < HDV; ++d) qv[d] = Elem<T>::load(p.q, qoff + d);
     float s[KJ];
     float mx = -INFINITY;
 #pragma unroll
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaParams p) {
       if (kk < Lk) {
         float dot = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) dot += qv[d] * sK[kk * 33 + d];
+        for (int d = 0; d < HDV; ++d) dot += qv[d] * sK[kk * LS + d];
         dot *= p.scale;
         if (p.kpm && p.kpm[b * Lk + kk]) dot = -INFINITY;
         s[j] = dot;
@@ -91,11 +92,13 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaParams p) {
       }
     }
     LDS_FENCE();
-    const int d = lane & 31, half = lane >> 5;
+    // P V: lanes = (channel, key part); 64 / HDV parts, combined by shuffles
+    constexpr int PARTS = 64 / HDV;
+    const int d = lane % HDV, part = lane / HDV;
     float acc = 0.f;
-    for (int kk = half; kk < Lk; kk += 2) acc += myP[kk] * sV[kk * 33 + d];
-    acc += __shfl_xor(acc, 32, 64);
-    if (half == 0) Elem<T>::store(p.out, (size_t)(b * Lq + qi) * p.ldo + h * HD + d, acc);
+    for (int kk = part; kk < Lk; kk += PARTS) acc += myP[kk] * sV[kk * LS + d];
+    if (PARTS == 2) acc += __shfl_xor(acc, 32, 64);
+    if (part == 0) Elem<T>::store(p.out, (size_t)(b * Lq + qi) * p.ldo + h * HDV + d, acc);
     LDS_FENCE();
   }
 }
@@ -119,19 +122,20 @@ __global__ void avg_heads_kernel(const float* probs, float* wavg, int B, int H, 
 
 // Backward, kernel A: grid (batch*head, query tiles).  One wavefront per query row: dP = dO V^T (+ dwavg/H),
 // dS = P * (dP - sum(P dP)) written to ds_ws, dQ = scale * dS K.
-template <typename T>
+template <typename T, int HDV>
 __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int LS = HDV + 1;
   const int Lk = p.Lk, Lq = p.Lq;
   float* sK = sm;
-  float* sV = sK + Lk * 33;
-  float* sP = sV + Lk * 33;  // [4][Lk]
+  float* sV = sK + Lk * LS;
+  float* sP = sV + Lk * LS;  // [4][Lk]
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-  for (int idx = t; idx < Lk * HD; idx += 256) {
-    int kk = idx >> 5, d = idx & 31;
-    sK[kk * 33 + d] = Elem<T>::load(p.k, (size_t)(b * Lk + kk) * p.ldk + h * HD + d);
-    sV[kk * 33 + d] = Elem<T>::load(p.v, (size_t)(b * Lk + kk) * p.ldv + h * HD + d);
+  for (int idx = t; idx < Lk * HDV; idx += 256) {
+    int kk = idx / HDV, d = idx - kk * HDV;
+    sK[kk * LS + d] = Elem<T>::load(p.k, (size_t)(b * Lk + kk) * p.ldk + h * HDV + d);
+    sV[kk * LS + d] = Elem<T>::load(p.v, (size_t)(b * Lk + kk) * p.ldv + h * HDV + d);
   }
   __syncthreads();
   float* myP = sP + wave * Lk;
@@ -139,10 +143,10 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaParams p) {
   const int q0 = blockIdx.y * QT;
   const int q1 = min(Lq, q0 + QT);
   for (int qi = q0 + wave; qi < q1; qi += 4) {
-    float dov[HD];
-    const size_t ooff = (size_t)(b * Lq + qi) * p.ldo + h * HD;
+    float dov[HDV];
+    const size_t ooff = (size_t)(b * Lq + qi) * p.ldo + h * HDV;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) dov[d] = Elem<T>::load(p.dout, ooff + d);
+    for (int d = 0; d < HDV; ++d) dov[d] = Elem<T>::load(p.dout, ooff + d);
     const size_t prow = ((size_t)bh * Lq + qi) * Lk;
     float dp[KJ], pr[KJ];
     float delta = 0.f;
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaParams p) {
       if (kk < Lk) {
         float dot = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) dot += dov[d] * sV[kk * 33 + d];
+        for (int d = 0; d < HDV; ++d) dot += dov[d] * sV[kk * LS + d];
         if (p.dwavg) dot += p.dwavg[((size_t)b * Lq + qi) * Lk + kk] * invH;
         if (p.drop_thresh) dot = dropout_keep(effective_seed(p.seed, p.seed_dev), (uint32_t)(prow + kk), p.drop_thresh) ? dot * p.drop_scale : 0.f;
         dp[j] = dot;
@@ -172,11 +176,12 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaParams p) {
       }
     }
     LDS_FENCE();
-    const int d = lane & 31, half = lane >> 5;
+    constexpr int PARTS = 64 / HDV;
+    const int d = lane % HDV, part = lane / HDV;
     float acc = 0.f;
-    for (int kk = half; kk < Lk; kk += 2) acc += myP[kk] * sK[kk * 33 + d];
-    acc += __shfl_xor(acc, 32, 64);
-    if (half == 0) Elem<T>::store(p.dq, (size_t)(b * Lq + qi) * p.ldq + h * HD + d, acc * p.scale);
+    for (int kk = part; kk < Lk; kk += PARTS) acc += myP[kk] * sK[kk * LS + d];
+    if (PARTS == 2) acc += __shfl_xor(acc, 32, 64);
+    if (part == 0) Elem<T>::store(p.dq, (size_t)(b * Lq + qi) * p.ldq + h * HDV + d, acc * p.scale);
     LDS_FENCE();
   }
 }
@@ -184,42 +189,43 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaParams p) {
 // Backward, kernel B: grid (batch*head, tiles of 64 keys).  Thread = (key, 8-channel slice); loops over all queries:
 // dK = scale * dS^T Q, dV = dropout(P)^T dO.  Q / dO rows are wave-uniform LDS broadcasts, dS / P columns are
 // coalesced over keys.
-template <typename T>
+template <typename T, int HDV>
 __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int CH = HDV / 4;  // channels per thread: the 4 wavefronts of the workgroup split the head dim
   const int Lk = p.Lk, Lq = p.Lq;
-  float* sQ = sm;             // [Lq][32]
-  float* sO = sm + Lq * HD;   // [Lq][32]
+  float* sQ = sm;              // [Lq][HDV]
+  float* sO = sm + Lq * HDV;   // [Lq][HDV]
   const int t = threadIdx.x;
   const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-  for (int idx = t; idx < Lq * HD; idx += 256) {
-    int qq = idx >> 5, d = idx & 31;
-    sQ[idx] = Elem<T>::load(p.q, (size_t)(b * Lq + qq) * p.ldq + h * HD + d);
-    sO[idx] = Elem<T>::load(p.dout, (size_t)(b * Lq + qq) * p.ldo + h * HD + d);
+  for (int idx = t; idx < Lq * HDV; idx += 256) {
+    int qq = idx / HDV, d = idx - qq * HDV;
+    sQ[idx] = Elem<T>::load(p.q, (size_t)(b * Lq + qq) * p.ldq + h * HDV + d);
+    sO[idx] = Elem<T>::load(p.dout, (size_t)(b * Lq + qq) * p.ldo + h * HDV + d);
   }
   __syncthreads();
   const int kk = blockIdx.y * 64 + (t & 63);
-  const int part = t >> 6;  // wave-uniform: channels part*8 .. part*8+7
+  const int part = t >> 6;  // wave-uniform: channels part*CH .. part*CH+CH-1
   if (kk >= Lk) return;
-  float dK[8], dV[8];
+  float dK[CH], dV[CH];
 #pragma unroll
-  for (int d = 0; d < 8; ++d) dK[d] = dV[d] = 0.f;
+  for (int d = 0; d < CH; ++d) dK[d] = dV[d] = 0.f;
   for (int qq = 0; qq < Lq; ++qq) {
     const size_t pi = ((size_t)bh * Lq + qq) * Lk + kk;
     float ds = p.ds_ws[pi];
     float pr = p.probs[pi];
     if (p.drop_thresh) pr = dropout_keep(effective_seed(p.seed, p.seed_dev), (uint32_t)pi, p.drop_thresh) ? pr * p.drop_scale : 0.f;
-    const float4* q4 = (const float4*)(sQ + qq * HD + part * 8);
-    const float4* o4 = (const float4*)(sO + qq * HD + part * 8);
-    float4 a0 = q4[0], a1 = q4[1], o0 = o4[0], o1 = o4[1];
-    dK[0] += ds * a0.x; dK[1] += ds * a0.y; dK[2] += ds * a0.z; dK[3] += ds * a0.w;
-    dK[4] += ds * a1.x; dK[5] += ds * a1.y; dK[6] += ds * a1.z; dK[7] += ds * a1.w;
-    dV[0] += pr * o0.x; dV[1] += pr * o0.y; dV[2] += pr * o0.z; dV[3] += pr * o0.w;
-    dV[4] += pr * o1.x; dV[5] += pr * o1.y; dV[6] += pr * o1.z; dV[7] += pr * o1.w;
-  }
-  const size_t ko = (size_t)(b * Lk + kk) * p.ldk + h * HD + part * 8, vo = (size_t)(b * Lk + kk) * p.ldv + h * HD + part * 8;
+    const float* qrow = sQ + qq * HDV + part * CH;
+    const float* orow = sO + qq * HDV + part * CH;
 #pragma unroll
-  for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < CH; ++d) {
+      dK[d] += ds * qrow[d];
+      dV[d] += pr * orow[d];
+    }
+  }
+  const size_t ko = (size_t)(b * Lk + kk) * p.ldk + h * HDV + part * CH, vo = (size_t)(b * Lk + kk) * p.ldv + h * HDV + part * CH;
+#pragma unroll
+  for (int d = 0; d < CH; ++d) {
     Elem<T>::store(p.dk, ko + d, dK[d] * p.scale);
     Elem<T>::store(p.dv, vo + d, dV[d]);
   }
@@ -489,9 +495,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(MhaParams p) {
 }
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-static bool mfma_path_ok(const MhaParams& p, int dtype, bool bwd) {
+static bool mfma_path_ok(const MhaParams& p, int dtype, bool bwd, int hd) {
   static const bool off = [] { const char* e = getenv("TD_MHA_VALU"); return e && e[0] == '1'; }();
-  if (off || dtype != TD_BF16 || p.Lk > 256 || p.Lq > 448) return false;
+  if (off || hd != HD || dtype != TD_BF16 || p.Lk > 256 || p.Lq > 448) return false;
   if ((p.ldq | p.ldk | p.ldv | p.ldo) & 7) return false;
   if (!aligned16(p.q) || !aligned16(p.k) || !aligned16(p.v)) return false;
   if (!bwd && ((uintptr_t)p.out & 7)) return false;
@@ -507,7 +513,7 @@ static int pick_waves(int BH, int tiles) {
 }
 static int fill(MhaParams& p, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo, float scale,
                 float dropout_p, uint32_t seed, const uint32_t* counter, const char* who) {
-  TD_REQUIRE(hd == HD, "%s: head dim %d unsupported (only 32)", who, hd);
+  TD_REQUIRE(hd == 32 || hd == 64, "%s: head dim %d unsupported (32: TubeDETR's transformer, 64: RoBERTa)", who, hd);
   TD_REQUIRE(Lk >= 1 && Lk <= 64 * KJ, "%s: Lk=%d out of range (1..%d)", who, Lk, 64 * KJ);
   TD_REQUIRE(B >= 1 && H >= 1 && Lq >= 1, "%s: bad sizes", who);
   TD_REQUIRE((double)B * H * Lq * Lk < 4294967295.0, "%s: probs tensor too large for the dropout index", who);
@@ -528,12 +534,11 @@ static int fill(MhaParams& p, int B, int H, int Lq, int Lk, int hd, int ldq, int
 static void mha_allow_big_lds() {
   static const bool done = [] {
     const int big = 160 * 1024;
-    (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+#define TD_BIG(K) (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, big)
+    TD_BIG((mha_fwd_kernel<u16, 32>)); TD_BIG((mha_fwd_kernel<float, 32>)); TD_BIG((mha_fwd_kernel<u16, 64>)); TD_BIG((mha_fwd_kernel<float, 64>));
+    TD_BIG((mha_bwd_dq_kernel<u16, 32>)); TD_BIG((mha_bwd_dq_kernel<float, 32>)); TD_BIG((mha_bwd_dq_kernel<u16, 64>)); TD_BIG((mha_bwd_dq_kernel<float, 64>));
+    TD_BIG((mha_bwd_dkv_kernel<u16, 32>)); TD_BIG((mha_bwd_dkv_kernel<float, 32>)); TD_BIG((mha_bwd_dkv_kernel<u16, 64>)); TD_BIG((mha_bwd_dkv_kernel<float, 64>));
+#undef TD_BIG
     return true;
   }();
   (void)done;
@@ -553,18 +558,21 @@ extern "C" int td_mha_fwd(const void* q, const void* k, const void* v, const uin
   if (rc) return rc;
   p.q = q; p.k = k; p.v = v; p.kpm = key_pad; p.out = out; p.probs = probs;
   hipStream_t st = (hipStream_t)stream;
-  size_t lds = (size_t)(2 * Lk * 33 + 4 * Lk) * sizeof(float);
+  size_t lds = (size_t)(2 * Lk * (hd + 1) + 4 * Lk) * sizeof(float);
+  TD_REQUIRE(lds <= 160 * 1024, "td_mha_fwd: Lk too large for LDS");
   dim3 grid(B * H, (Lq + QT - 1) / QT);
   mha_allow_big_lds();
-  if (mfma_path_ok(p, dtype, false)) {
+  if (mfma_path_ok(p, dtype, false, hd)) {
     const int qt = cdiv(Lq, 16), nw = pick_waves(B * H, qt);
     dim3 g2(B * H, cdiv(qt, nw));
     if (Lk <= 64) mha_fwd_mfma_kernel<4><<<g2, 64 * nw, 0, st>>>(p);
     else if (Lk <= 128) mha_fwd_mfma_kernel<8><<<g2, 64 * nw, 0, st>>>(p);
     else if (Lk <= 160) mha_fwd_mfma_kernel<10><<<g2, 64 * nw, 0, st>>>(p);
     else mha_fwd_mfma_kernel<16><<<g2, 64 * nw, 0, st>>>(p);
-  } else if (dtype == TD_BF16) mha_fwd_kernel<u16><<<grid, 256, lds, st>>>(p);
-  else if (dtype == TD_F32) mha_fwd_kernel<float><<<grid, 256, lds, st>>>(p);
+  } else if (dtype == TD_BF16 && hd == 32) mha_fwd_kernel<u16, 32><<<grid, 256, lds, st>>>(p);
+  else if (dtype == TD_BF16) mha_fwd_kernel<u16, 64><<<grid, 256, lds, st>>>(p);
+  else if (dtype == TD_F32 && hd == 32) mha_fwd_kernel<float, 32><<<grid, 256, lds, st>>>(p);
+  else if (dtype == TD_F32) mha_fwd_kernel<float, 64><<<grid, 256, lds, st>>>(p);
   else TD_REQUIRE(false, "td_mha_fwd: bad dtype");
   rc = check_launch("td_mha_fwd");
   if (rc) return rc;
@@ -588,12 +596,12 @@ extern "C" int td_mha_bwd(const void* q, const void* k, const void* v, const voi
   p.q = q; p.k = k; p.v = v; p.dout = dout; p.probs = (float*)probs; p.dwavg = dwavg;
   p.dq = dq; p.dk = dk; p.dv = dv; p.ds_ws = ds_ws;
   hipStream_t st = (hipStream_t)stream;
-  size_t ldsA = (size_t)(2 * Lk * 33 + 4 * Lk) * sizeof(float);
-  size_t ldsB = (size_t)(2 * Lq * HD) * sizeof(float);
+  size_t ldsA = (size_t)(2 * Lk * (hd + 1) + 4 * Lk) * sizeof(float);
+  size_t ldsB = (size_t)(2 * Lq * hd) * sizeof(float);
   TD_REQUIRE(ldsA <= 160 * 1024 && ldsB <= 160 * 1024, "td_mha_bwd: Lq/Lk too large for LDS");
   dim3 gridA(B * H, (Lq + QT - 1) / QT), gridB(B * H, (Lk + 63) / 64);
   mha_allow_big_lds();
-  if (mfma_path_ok(p, dtype, true)) {
+  if (mfma_path_ok(p, dtype, true, hd)) {
     const int qt = cdiv(Lq, 16), nwq = pick_waves(B * H, qt);
     dim3 gA(B * H, cdiv(qt, nwq));
     if (Lk <= 64) mha_bwd_dq_mfma_kernel<4><<<gA, 64 * nwq, 0, st>>>(p);
@@ -603,12 +611,18 @@ extern "C" int td_mha_bwd(const void* q, const void* k, const void* v, const voi
     const int ktl = cdiv(Lk, 16), nwk = pick_waves(B * H, ktl);
     const int QS = cdiv(Lq, 32) * 32 + 8;
     mha_bwd_dkv_mfma_kernel<<<dim3(B * H, cdiv(ktl, nwk)), 64 * nwk, (size_t)2 * 32 * QS * sizeof(u16), st>>>(p);
+  } else if (dtype == TD_BF16 && hd == 32) {
+    mha_bwd_dq_kernel<u16, 32><<<gridA, 256, ldsA, st>>>(p);
+    mha_bwd_dkv_kernel<u16, 32><<<gridB, 256, ldsB, st>>>(p);
   } else if (dtype == TD_BF16) {
-    mha_bwd_dq_kernel<u16><<<gridA, 256, ldsA, st>>>(p);
-    mha_bwd_dkv_kernel<u16><<<gridB, 256, ldsB, st>>>(p);
+    mha_bwd_dq_kernel<u16, 64><<<gridA, 256, ldsA, st>>>(p);
+    mha_bwd_dkv_kernel<u16, 64><<<gridB, 256, ldsB, st>>>(p);
+  } else if (dtype == TD_F32 && hd == 32) {
+    mha_bwd_dq_kernel<float, 32><<<gridA, 256, ldsA, st>>>(p);
+    mha_bwd_dkv_kernel<float, 32><<<gridB, 256, ldsB, st>>>(p);
   } else if (dtype == TD_F32) {
-    mha_bwd_dq_kernel<float><<<gridA, 256, ldsA, st>>>(p);
-    mha_bwd_dkv_kernel<float><<<gridB, 256, ldsB, st>>>(p);
+    mha_bwd_dq_kernel<float, 64><<<gridA, 256, ldsA, st>>>(p);
+    mha_bwd_dkv_kernel<float, 64><<<gridB, 256, ldsB, st>>>(p);
   } else TD_REQUIRE(false, "td_mha_bwd: bad dtype");
   return check_launch("td_mha_bwd");
 }

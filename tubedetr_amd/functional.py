@@ -474,6 +474,35 @@ class MHAFn(Function):
         return (d_q_in, d_k_in, d_v_in, dW_in, db_in, dW_out, db_out) + (None,) * 10
 
 
+class AttnCoreFn(Function):
+    """softmax(scale q k^T + key padding) v on already projected q, k, v rows ([B*L, E] each, heads in column blocks of
+    E // H = 32 or 64) - the attention core alone, for encoders that own their projections (RoBERTa: separate query / key /
+    value Linear modules).  Probability dropout inside the kernel; no layout change, no copies."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_pad, B, Lq, Lk, H, p_drop, seed):
+        E = q.shape[1]
+        scale = 1.0 / math.sqrt(E // H)
+        q3, k3, v3 = q.view(B, Lq, E), k.view(B, Lk, E), v.view(B, Lk, E)
+        out, probs, _ = ops.mha_fwd(q3, k3, v3, key_pad, H, scale, need_wavg=False, dropout_p=p_drop, seed=seed)
+        ctx.save_for_backward(q3, k3, v3, probs)
+        ctx.cfg = (B, Lq, Lk, H, E, scale, p_drop, seed)
+        return out.view(B * Lq, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q3, k3, v3, probs = ctx.saved_tensors
+        B, Lq, Lk, H, E, scale, p_drop, seed = ctx.cfg
+        dq, dk, dv = torch.empty_like(q3), torch.empty_like(k3), torch.empty_like(v3)
+        ops.mha_bwd(q3, k3, v3, dout.contiguous().view(B, Lq, E), probs, None, H, scale, dq, dk, dv, dropout_p=p_drop, seed=seed)
+        return dq.view(B * Lq, E), dk.view(B * Lk, E), dv.view(B * Lk, E), None, None, None, None, None, None, None
+
+
+def attention_core(q, k, v, key_pad, B, Lq, Lk, H, dropout_p=0.0, training=False):
+    p = dropout_p if training else 0.0
+    return AttnCoreFn.apply(q, k, v, key_pad, B, Lq, Lk, H, p, _seed() if p > 0 else 0)
+
+
 def multihead_attention(q_in, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_weights=False,
                         attn_dropout=0.0, out_dropout=0.0, training=False):
     pa = attn_dropout if training else 0.0

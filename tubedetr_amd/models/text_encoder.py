@@ -9,8 +9,8 @@ checkpoints and the optimizer's "text_encoder" parameter group are untouched) wi
   per layer    q / k / v projections, attention output projection (+dropout), intermediate (+GELU), output (+dropout):
                td_conv_gemm with fused bias / dropout epilogues; residual + LayerNorm: td_add_layernorm; GELU: td_gelu;
                the 72 weight / bias gradients join the transformer's deferred batched launch (functional._wgrad)
-  attention    12 heads x 64: ``F.scaled_dot_product_attention`` on the projected tensors (the in-house attention core
-               is specialised for TubeDETR's head dim 32)
+  attention    12 heads x 64 on the in-house attention core (td_mha_fwd / td_mha_bwd, head-dim-64 instance): the projected
+               rows are consumed where they lie (heads = column blocks), no transposes or copies
 
 fp32 compute dtype = exact-fp32 kernels (parity mode), bf16 = MFMA throughput mode.  The pooler is never evaluated
 (unused by the reference too: the reason it needs ``find_unused_parameters``).
@@ -20,8 +20,6 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
-
 from .. import functional as Fk
 
 
@@ -41,7 +39,7 @@ def run_roberta(hf, input_ids: torch.Tensor, attention_mask: Optional[torch.Tens
     H, nh = cfg.hidden_size, cfg.num_attention_heads
     hd = H // nh
     p_hid = float(cfg.hidden_dropout_prob)
-    p_att = float(cfg.attention_probs_dropout_prob) if training else 0.0
+    p_att = float(cfg.attention_probs_dropout_prob)
     if cfg.hidden_act != "gelu":
         raise NotImplementedError(f"hidden_act={cfg.hidden_act!r}: only RoBERTa's erf GELU is implemented")
     if no_padding:  # synthetic / unpadded captions: positions are padding_idx + 1 ..., known without looking at the ids
@@ -52,16 +50,15 @@ def run_roberta(hf, input_ids: torch.Tensor, attention_mask: Optional[torch.Tens
     rows = Fk.cast(x.reshape(B * L, H), compute_dtype)
     rows = Fk.add_layernorm(rows, None, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps)
     rows = Fk.dropout(rows, p_hid, training)
-    attn_mask = None
+    key_pad = None
     if attention_mask is not None and not no_padding:
-        attn_mask = attention_mask.bool()[:, None, None, :]  # [B, 1, 1, L]: True = attend
+        key_pad = attention_mask.ne(1)  # [B, L]: True = padded key, ignored
     for layer in hf.encoder.layer:
         sa, so = layer.attention.self, layer.attention.output
-        q = Fk.linear(rows, sa.query.weight, sa.query.bias).view(B, L, nh, hd).transpose(1, 2)
-        k = Fk.linear(rows, sa.key.weight, sa.key.bias).view(B, L, nh, hd).transpose(1, 2)
-        v = Fk.linear(rows, sa.value.weight, sa.value.bias).view(B, L, nh, hd).transpose(1, 2)
-        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, dropout_p=p_att)  # [B, nh, L, hd]
-        ctx = ctx.transpose(1, 2).reshape(B * L, H)
+        q = Fk.linear(rows, sa.query.weight, sa.query.bias)
+        k = Fk.linear(rows, sa.key.weight, sa.key.bias)
+        v = Fk.linear(rows, sa.value.weight, sa.value.bias)
+        ctx = Fk.attention_core(q, k, v, key_pad, B, L, L, nh, dropout_p=p_att, training=training)  # heads = column blocks of 64: no transposes
         a = Fk.linear(ctx, so.dense.weight, so.dense.bias, dropout_p=p_hid, training=training)
         rows = Fk.add_layernorm(a, rows, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps)
         h = Fk.gelu(Fk.linear(rows, layer.intermediate.dense.weight, layer.intermediate.dense.bias))
