@@ -76,6 +76,7 @@ def test_uint8_pipeline_equals_reference_format_step():
     assert abs(loss_a.item() - loss_b.item()) < 1e-4 * abs(loss_b.item())
     for key in ("pred_boxes", "pred_sted"):
         assert (out_a[key] - out_b[key]).abs().max().item() < 1e-4
+    scale = max(p.grad.norm().item() for p in params if p.grad is not None)  # numerically-zero gradients (softmax-invariant biases) are judged on the model's scale
     for p, a in zip(params, ga):
         if a is None:
             assert p.grad is None
@@ -83,4 +84,4 @@ def test_uint8_pipeline_equals_reference_format_step():
         # the two paths round the normalised pixels differently in the last bit ((x * (1/255) - m) * (1/s) vs (x / 255 - m) / s);
         # 104 convolutions and the min / max / sign kinks of the losses amplify that to ~1e-3 .. 1e-2 on individual gradient entries,
         # so the comparison is per parameter in norm (a wrong frame order or normalisation constant would be O(1))
-        assert (a - p.grad).norm().item() <= 2e-2 * p.grad.norm().item() + 1e-6
+        assert (a - p.grad).norm().item() <= 2e-2 * p.grad.norm().item() + 1e-5 * scale

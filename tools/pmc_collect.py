@@ -6,8 +6,10 @@
   mfma:       python tools/pmc_collect.py mfma <agg.csv> profiles/r02_pmc_mfma.json
               needs SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES and GRBM_GUI_ACTIVE in the aggregate (one rocprofv3 --pmc
               pass: SQ and GRBM counters come from different blocks, MI355X_MICROARCH.md "rocprofv3 PMC slots").
-              mfma_util of a kernel family = sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs):
-              the fraction of SIMD-cycles of the launches' wall time in which a matrix pipe was busy
+              mfma_util of a kernel family = sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs):
+              the fraction of SIMD-cycles of the launches' wall time in which a matrix pipe was busy.  rocprofv3 returns
+              GRBM_GUI_ACTIVE summed over the 8 XCDs' GRBM instances (measured: sum / kernel duration = 18 .. 20 cycles/ns
+              = 8 x ~2.4 GHz for every large kernel, `xcd_sum_check` in the output), hence the / 8
               (SQ_VALU_MFMA_BUSY_CYCLES counts per-SIMD busy cycles summed over the chip; MI355X_MICROARCH.md, per-instruction
               constants).  Families as in bench.py; plus north_star's group "decoder attention + its K/V projections".
 """
@@ -65,11 +67,13 @@ def mfma(src, dst, command=""):
         a[1] += float(r["sum"])
         a[2] += int(float(r.get("duration_ns") or 0))
     SIMDS = 256 * 4
-    res = {"_doc": "mfma_util = sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE * 1024 SIMDs) over the family's launches; "
-                   "cu_busy = sum SQ_BUSY_CU_CYCLES / (sum GRBM_GUI_ACTIVE * 256 CUs) where collected", "_command": command}
+    XCDS = 8  # GRBM_GUI_ACTIVE arrives summed over the XCDs
+    res = {"_doc": "mfma_util = sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) over the family's launches; "
+                   "cu_busy = sum SQ_BUSY_CU_CYCLES / (sum GRBM_GUI_ACTIVE / 8 * 256 CUs); gui_cycles_per_ns = sum GRBM_GUI_ACTIVE / "
+                   "summed kernel duration (19.2 = 8 XCDs x 2.4 GHz: the check that the counter is the XCD sum)", "_command": command}
 
     def util(names):
-        mf = ga = bc = 0.0
+        mf = ga = bc = dur = 0.0
         n = 0
         for f in names:
             c = per.get(f, {})
@@ -77,10 +81,11 @@ def mfma(src, dst, command=""):
             ga += c.get("GRBM_GUI_ACTIVE", [0, 0.0, 0])[1]
             bc += c.get("SQ_BUSY_CU_CYCLES", [0, 0.0, 0])[1]
             n += c.get("GRBM_GUI_ACTIVE", [0, 0.0, 0])[0]
+            dur += c.get("GRBM_GUI_ACTIVE", [0, 0.0, 0])[2]
         if ga <= 0:
             return None
-        return {"dispatches": n, "mfma_util": round(mf / (ga * SIMDS), 4), "cu_busy": round(bc / (ga * 256), 4) if bc else None,
-                "mfma_busy_cycles": mf, "gui_active_cycles": ga}
+        return {"dispatches": n, "mfma_util": round(mf / (ga / XCDS * SIMDS), 4), "cu_busy": round(bc / (ga / XCDS * 256), 4) if bc else None,
+                "mfma_busy_cycles": mf, "gui_active_cycles": ga, "gui_cycles_per_ns": round(ga / dur, 2) if dur else None}
 
     for f in sorted(per):
         u = util([f])

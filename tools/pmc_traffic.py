@@ -8,7 +8,7 @@ import csv, json, re, sys
 
 
 def family(name):
-    m = re.search(r"td::conv_gemm_kernel<([^,]+), (\d+), (\d+), (\d+), (true|false)>", name)
+    m = re.search(r"td::conv_gemm_kernel<([^,]+), (\d+), (\d+), (\d+), (true|false)", name)
     if m:
         return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, *, *>"  # stages and pointwise flag merged
     if "td::pw_resident_kernel" in name:
