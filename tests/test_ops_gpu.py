@@ -116,6 +116,36 @@ def test_conv_wgrad_batch_matches_autograd(dt):
     assert rel_err(dw, w.grad) < TOL[dt]
 
 
+def test_conv_wgrad_batch_wide_tiles():
+    """bf16 jobs with >= 4096 reduction rows and 128-multiple channel counts take the sixteen-wavefront wide-tile instance
+    (conv_wgrad_wide_batch_kernel): every tile class (256x256, 128x256, 256x128; 3x3 stride 1 / 2 and pointwise), split
+    (atomics) and un-split jobs, partial last k tile (K = 1152), ragged last stage, FrozenBN scale folding - in one
+    launch, next to a small job that stays on the 128x128 instance."""
+    from tubedetr_amd import ops
+
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(23)
+    cfgs = [(8, 128, 28, 27, 128, 3, 1, 1), (20, 256, 26, 25, 256, 3, 1, 1), (5, 1024, 30, 31, 256, 1, 1, 0), (16, 512, 30, 30, 128, 1, 1, 0),
+            (6, 128, 28, 28, 512, 1, 1, 0), (8, 128, 57, 57, 128, 3, 2, 1), (2, 64, 12, 12, 64, 1, 1, 0), (3, 512, 40, 40, 512, 3, 1, 1)]
+    jobs, refs = [], []
+    for i, (N, Ci, H, W, Co, R, st, pad) in enumerate(cfgs):
+        x = rnd((N, Ci, H, W), g, dt).to(dev())
+        Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+        gy = rnd((N, Co, Ho, Wo), g, dt).to(dev())
+        scale = (torch.rand(Co, generator=g) + 0.5).to(dev()) if i % 2 == 0 else None
+        ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, R, R), gy, stride=st, padding=pad)  # fp32 on the GPU, same bf16 values
+        refs.append(ref * (scale.view(-1, 1, 1, 1) if scale is not None else 1.0))
+        to_rows = lambda t_: t_.permute(0, 2, 3, 1).contiguous().to(dt)
+        jobs.append((to_rows(gy), to_rows(x), R, R, st, pad, scale, Ci))
+    outs = ops.conv_wgrad_batch(jobs)
+    for got, ref, cfg in zip(outs, refs, cfgs):
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) < TOL[dt], cfg
+    outs2 = ops.conv_wgrad_batch(jobs)  # stale outputs are overwritten, split jobs re-zeroed
+    for a, b in zip(outs, outs2):
+        assert rel_err(a, b) < 1e-5
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_frozen_bn_fold_and_mask_epilogues(dt):
     from tubedetr_amd import ops
@@ -226,6 +256,62 @@ def test_pointwise_persistent_instance_matches_tiled_math(cfg):
     if use_res:
         y2 = ops.linear_fwd(x, w, b, residual=res, relu=relu, mask_src=msk, out=res)
         assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("cfg", [(41000, 512, 256, True, False, True), (41003, 1024, 128, False, True, False), (61000, 2048, 512, True, True, False),
+                                 (41000, 576, 256, False, False, True)])
+def test_pointwise_256_row_tiles(cfg):
+    """bf16 pointwise layers with K >= 512 and enough rows take the eight-wavefront 256-row tile instance
+    (conv_gemm_big_kernel, both tile widths): all epilogues, ragged last M tile, in-place residual."""
+    from tubedetr_amd import ops
+
+    M, K, Nn, use_res, use_mask, relu = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(M, K, generator=g)).to(dev(), dt)
+    w = (torch.randn(Nn, K, generator=g) / math.sqrt(K)).to(dev(), dt)
+    b = torch.randn(Nn, generator=g).to(dev())
+    res = torch.randn(M, Nn, generator=g).to(dev(), dt) if use_res else None
+    msk = torch.randn(M, Nn, generator=g).to(dev(), dt) if use_mask else None
+    ref = x.float() @ w.float().t() + b
+    if use_res:
+        ref = ref + res.float()
+    if relu:
+        ref = F.relu(ref)
+    if use_mask:
+        ref = ref * (msk.float() > 0)
+    y = ops.linear_fwd(x, w, b, residual=res, relu=relu, mask_src=msk)
+    assert rel_err(y, ref) < TOL[dt]
+    if use_res:
+        y2 = ops.linear_fwd(x, w, b, residual=res, relu=relu, mask_src=msk, out=res)
+        assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("cfg", [(21, 64, 45, 44, 256, 1), (11, 128, 62, 61, 128, 1), (12, 128, 118, 117, 128, 2), (6, 256, 84, 83, 512, 1)])
+def test_conv3x3_256_row_tiles(cfg):
+    """3x3 layers large enough for the 256-row tile instance: forward (bias + ReLU, stride 1 and 2) and input gradient
+    (residual + ReLU-mask), image borders and a ragged last tile, against torch's fp32 convolution of the same bf16 values."""
+    from tubedetr_amd import ops
+
+    N, Ci, H, W, Co, st = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(43)
+    x = rnd((N, Ci, H, W), g, dt).to(dev())
+    w = rnd((Co, Ci, 3, 3), g, dt, 1.0 / math.sqrt(9 * Ci)).to(dev())
+    bias = torch.randn(Co, generator=g).to(dev())
+    ref = F.relu(F.conv2d(x, w, bias, stride=st, padding=1))
+    wf, wd, b_out, _ = ops.weight_prep(w, dt, bias=bias)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dt)
+    y = ops.conv_fwd(xd, wf, b_out, 3, 3, st, 1, relu=True)
+    assert rel_err(y.float().permute(0, 3, 1, 2), ref) < TOL[dt]
+    if st == 1:
+        gy = rnd(tuple(ref.shape), g, dt).to(dev())
+        r = rnd((N, Ci, H, W), g, dt).to(dev())
+        m = rnd((N, Ci, H, W), g, dt).to(dev())
+        dx_ref = (torch.nn.grad.conv2d_input((N, Ci, H, W), w, gy, padding=1) + r) * (m > 0)
+        to_rows = lambda t_: t_.permute(0, 2, 3, 1).contiguous().to(dt)
+        dx = ops.conv_dgrad(to_rows(gy), wd, (H, W), 3, 3, 1, 1, residual=to_rows(r), mask_src=to_rows(m))
+        assert rel_err(dx.float().permute(0, 3, 1, 2), dx_ref) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DT)

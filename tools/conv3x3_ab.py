@@ -40,3 +40,13 @@ for H, Cc, st in SHAPES:
         dx = torch.empty(frames, H, H, Cc, device=dev, dtype=torch.bfloat16)
         us = timeit(lambda: ops.conv_dgrad(gy, wd, (H, H), 3, 3, st, 1, mask_src=x, out=dx))
         print(f"dgrad N={frames} {H}x{H} C={Cc} s{st}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s")
+
+# pointwise layers with K >= 512 (conv1 of layer2..4 forward, conv3 input gradient): rows x K -> N
+for rows, K, Nn in [(frames * 484, 1024, 256), (frames * 121, 2048, 512), (frames * 1936, 512, 128), (frames * 484, 512, 256)]:
+    x = torch.randn(rows, K, device=dev, generator=g).bfloat16()
+    w = (torch.randn(Nn, K, device=dev, generator=g) * 0.02).bfloat16()
+    b = torch.randn(Nn, device=dev, generator=g)
+    y = torch.empty(rows, Nn, device=dev, dtype=torch.bfloat16)
+    us = timeit(lambda: ops.linear_fwd(x, w, b, relu=True, out=y))
+    by = (rows * K + Nn * K + rows * Nn) * 2
+    print(f"1x1   M={rows} K={K} N={Nn}: {us:8.1f} us  {2.0 * rows * K * Nn / us / 1e6:7.1f} TF/s  {by / us / 1e3:7.1f} GB/s")

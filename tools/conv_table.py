@@ -1,4 +1,5 @@
-"""Per-launch table of the MFMA kernels in one training step (in-library HIP-event timing): shape, ms, TFLOP/s, GB/s."""
+"""Per-launch table of the MFMA kernels in one training step (in-library HIP-event timing): shape, ms, TFLOP/s, GB/s.
+usage: conv_table.py [clips per step, default 4]   (family ids: include/tubedetr_hip.h TD_PROF_*)"""
 import os, sys, csv, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +15,8 @@ dev = torch.device("cuda:0")
 model, criterion, wd = build_model(tubedetr_amd.default_args(stride=k, compute_dtype=torch.bfloat16))
 model.to(dev).train()
 tok = BatchTokenizer(); model.transformer.tokenizer = tok
-b = make_batch(T, res, k, L, 1, dev); tok.batch = b
+clips = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+b = make_batch(T, res, k, L, 1, dev, clips=clips); tok.batch = b
 for _ in range(2):
     model.zero_grad(set_to_none=True); loss, *_ = forward_step(model, criterion, wd, b); loss.backward()
 torch.cuda.synchronize()
@@ -30,7 +32,7 @@ for r in rows:
 tot = sum(v[1] for v in agg.values())
 print(f"total MFMA-kernel ms/step {tot:.2f}")
 print("fam      M     N     K  R st md/sp  cnt   ms_tot  us_each   TF/s   GB/s(min)")
-for key, (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for key, (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('ROWS', '70'))]:
     fam, M, N, K, R, st, md = (int(x) for x in key)
     fl = 2.0 * M * N * K * cnt
     if fam == 2: byts = (M * N + M * K / (R * R if R > 1 else 1)) * 2 * cnt + N * K * 4 * cnt

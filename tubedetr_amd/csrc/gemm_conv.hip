@@ -497,6 +497,268 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
     }
   }
   TD_STAMP(5);
+#undef TD_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256-row tiles for the MFMA-bound layers (bf16; every 3x3 of layer2..4, the 1x1 layers with K >= 512), forward and
+// input gradient.  Why a second instance: a 128 x 128 x 64 tile moves 32 KiB HBM/L2 -> LDS per 512 MFMA cycles of the CU,
+// i.e. it needs the full 64 B/clk/CU of the vector-memory path to keep the matrix pipes busy, and measured it sits at a
+// third of both.  Here one workgroup of EIGHT wavefronts (two per SIMD, the only workgroup of its CU: 2 x 64 KiB stages)
+// owns a 256 x 256 (or 256 x 128) tile: the same DMA instruction count per wavefront and tile as before feeds twice the
+// MFMAs (32 B/clk/CU at peak), the activation rows of a 256-channel layer are read exactly once, and each wavefront's
+// 128 x 64 sub-tile needs 12 KiB of LDS fragment reads per 32 MFMAs instead of 16.  Accumulators: 128 VGPRs per lane.
+// The epilogue walks the wavefront's rows in chunks of 16: transposed through a private 4-KiB LDS region (no workgroup
+// barrier between chunks), residual / mask operands of chunk c+1 requested while chunk c is stored.
+// TU / pointwise addressing exactly as in conv_gemm_kernel.
+template <int BN, bool TU>
+__global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
+  using T = u16;
+  constexpr int ES = 2, BM = 256, BK = 64, NW = 8, VEC = 8;
+  constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);
+  constexpr int WGN = BN / 64, WGM = NW / WGN;
+  constexpr int WM = BM / WGM, WN = 64;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  __shared__ __attribute__((aligned(16))) char smem0[(BM + BN) * 128];
+  __shared__ __attribute__((aligned(16))) char smem1[(BM + BN) * 128];
+
+  const td_conv_desc& d = p.d;
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int NT = d.Nc / BN;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mt = (seq / NT) * 8 + xcd, nt = seq - (seq / NT) * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (m0 >= p.M) return;
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;
+  const int HoWo = d.Ho * d.Wo;
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  uint32_t a_off[AI];   // pointwise: byte offset of the row
+  int a_base[AI];       // TU: pixel index of tap (0, 0)
+  uint32_t a_mask[AI];  // TU: taps inside the image
+  const int RS = d.R * d.S;
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + (i * NW + wave) * 8 + lrow;
+    const bool ok = m < p.M;
+    if constexpr (!TU) {
+      a_off[i] = ok ? (uint32_t)m * (uint32_t)p.K * ES : OOB;
+    } else {
+      const int mm = ok ? m : 0;
+      const int n = mm / HoWo;
+      const int rem = mm - n * HoWo;
+      const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+      const int hb = d.mode == 0 ? ho * d.stride - d.pad : ho + d.pad;
+      const int wb = d.mode == 0 ? wo * d.stride - d.pad : wo + d.pad;
+      a_base[i] = n * d.Hs * d.Ws + hb * d.Ws + wb;
+      uint32_t msk = 0;
+      for (int r = 0; r < d.R; ++r) {
+        const int hs = d.mode == 0 ? hb + r : hb - r;
+        for (int sx = 0; sx < d.S; ++sx) {
+          const int ws = d.mode == 0 ? wb + sx : wb - sx;
+          const bool in = (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
+          msk |= (in ? 1u : 0u) << (r * d.S + sx);
+        }
+      }
+      a_mask[i] = ok ? msk : 0u;
+    }
+  }
+  uint32_t b_off[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) b_off[i] = (uint32_t)(n0 + (i * NW + wave) * 8 + lrow) * (uint32_t)p.K * ES;  // Nc % BN == 0: always inside
+  int kk = chunk * VEC;
+  int t_tap = 0, t_ks = 0, t_kc = 0, t_pix = 0;
+  const int lane_c = chunk * VEC;
+
+  auto issue_tile = [&](char* stage) {
+    char* stA = stage;
+    char* stB = stage + BM * 128;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      uint32_t off;
+      if constexpr (TU) {
+        const bool ok = (a_mask[i] >> (t_tap & 31)) & 1u;
+        off = ok ? (uint32_t)((a_base[i] + t_pix) * d.C + t_kc + lane_c) * ES : OOB;
+      } else {
+        off = a_off[i] != OOB ? a_off[i] + (uint32_t)kk * ES : OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stA + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const uint32_t off = b_off[i] + (uint32_t)kk * ES;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(stB + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
+    }
+    kk += BK;
+    if constexpr (TU) {
+      t_kc += BK;
+      if (t_kc >= d.C) {
+        t_kc = 0;
+        ++t_tap;
+        if (++t_ks == d.S) { t_ks = 0; t_pix += d.mode == 0 ? d.Ws - (d.S - 1) : -(d.Ws - (d.S - 1)); }
+        else t_pix += d.mode == 0 ? 1 : -1;
+      }
+    }
+  };
+
+  const int wy = wave / WGN, wx = wave - wy * WGN;
+  const int lr = lane & 15, lg = lane >> 4;
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // One K tile = 2 k-steps x (TM / 4) groups of 4 activation fragments x 4 weight fragments = 16 MFMAs per group.  The
+  // fragments of group g + 1 are requested before the MFMAs of group g are issued and the scheduler may not move
+  // anything across a group boundary: at most 2 x 16 + 2 x 16 fragment registers are live next to the 128
+  // accumulators (left to itself the scheduler hoists all 24 fragment reads of the tile and spills accumulators).
+  // The pipeline runs ACROSS tiles: the barrier that publishes tile kt + 1 sits before the LAST group of tile kt, and
+  // the first fragments of tile kt + 1 are requested right behind it, so their LDS latency and the barrier skew are
+  // covered by 16 MFMAs instead of idling the matrix pipe at every tile head (3250 -> cycles per tile measured with
+  // tools/stamp_big.py; the floor is 2 waves x 64 MFMAs x 16.5 = 2112).
+  constexpr int GPK = TM / 4, NG = 2 * GPK;
+  static_assert(NG % 2 == 0, "fragment double buffer parity");
+  uint4 wf[2][TN], af[2][4];
+  auto load_w = [&](const char* stage, int ks, uint4 (&dst)[TN]) {
+    const char* stB = stage + BM * 128;
+    const int cidx = ks * 4 + lg;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int row = wx * WN + i * 16 + lr;
+      dst[i] = *(const uint4*)(stB + row * 128 + ((cidx ^ (row & 7)) << 4));
+    }
+  };
+  auto load_a = [&](const char* stage, int g, uint4 (&dst)[4]) {
+    const int ks = g / GPK, jh = (g - ks * GPK) * 4;
+    const int cidx = ks * 4 + lg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wy * WM + (jh + j) * 16 + lr;
+      dst[j] = *(const uint4*)(stage + row * 128 + ((cidx ^ (row & 7)) << 4));
+    }
+  };
+  // tile in `cur` (its group-0 fragments already requested into wf[0] / af[0]); `nxt` receives tile kt + 1
+  auto tile_body = [&](char* cur, char* nxt, bool has_next) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g == 0 && has_next) issue_tile(nxt);  // every wavefront finished reading `nxt` (tile kt - 1) before the last barrier
+      if (g + 1 < NG) {
+        if ((g + 1) % GPK == 0) load_w(cur, (g + 1) / GPK, wf[((g + 1) / GPK) & 1]);
+        load_a(cur, g + 1, af[(g + 1) & 1]);
+      } else {
+        // own DMA of tile kt + 1 landed, own fragment reads of `cur` returned -> barrier -> both hold for every wavefront
+        // (the builtin, not inline asm: the compiler's own wait-count bookkeeping must see this wait, or it makes the
+        //  MFMAs below wait for the reads issued behind the barrier)
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        load_w(nxt, 0, wf[0]);  // after the last tile these read a stale stage: unused
+        load_a(nxt, 0, af[0]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int ks = g / GPK, jh = (g - ks * GPK) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) Mfma<T>::run(wf[ks & 1][i], af[g & 1][j], acc[i][jh + j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- epilogue bookkeeping: chunks of 16 rows, 8 lanes x 16 bytes per 64-channel row segment ----
+  constexpr int CR = 16, NCH = WM / CR, EPL = 8, LPR = WN / EPL, RPI = 64 / LPR, NIT = CR / RPI, CPRW = WN / 4;
+  const int cc = lane % LPR, rsub = lane / LPR;
+  const int n = n0 + wx * WN + cc * EPL;
+  uint32_t offs[2][NIT];  // element offsets (the host checks rows * ldc < 2^31)
+  bool live[2][NIT];
+  uint4 res[2][NIT], msk[2][NIT];
+  auto fetch_chunk = [&](int c, int b) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wy * WM + c * CR + it * RPI + rsub;
+      live[b][it] = m < p.M;
+      offs[b][it] = (uint32_t)min(m, p.M - 1) * (uint32_t)d.ldc + (uint32_t)n;
+      if (p.residual) res[b][it] = *(const uint4*)(p.residual + offs[b][it] * ES);
+      if (p.mask_src) msk[b][it] = *(const uint4*)(p.mask_src + offs[b][it] * ES);
+    }
+  };
+
+  const int nk = p.K / BK;
+#define TD_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+  TD_STAMP(0);
+  issue_tile(smem0);
+  __syncthreads();  // tile 0 landed
+  TD_STAMP(1);
+  load_w(smem0, 0, wf[0]);
+  load_a(smem0, 0, af[0]);
+#pragma unroll 1
+  for (int kt = 0; kt < nk; kt += 2) {
+    tile_body(smem0, smem1, kt + 1 < nk);
+    if (kt + 1 >= nk) break;
+    tile_body(smem1, smem0, kt + 2 < nk);
+  }
+  TD_STAMP(2);
+  fetch_chunk(0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every wavefront is done reading the stage buffers: they become the staging regions
+  TD_STAMP(3);
+  float* stg = (float*)((wave < 4 ? smem0 : smem1) + (wave & 3) * (CR * WN * 4));
+  const float alpha = p.alpha;
+  float bias[EPL];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) bias[r] = p.bias ? p.bias[n + r] : 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int b = c & 1;
+#pragma unroll
+    for (int jj = 0; jj < CR / 16; ++jj) {
+      const int row = jj * 16 + lr;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int cx = (i * 4 + lg) ^ (row & (CPRW - 1));
+        const f32x4 a = acc[i][c * (CR / 16) + jj];
+        *(float4*)(stg + row * WN + cx * 4) = make_float4(a[0] * alpha, a[1] * alpha, a[2] * alpha, a[3] * alpha);
+      }
+    }
+    if (c + 1 < NCH) fetch_chunk(c + 1, b ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + rsub;
+      const int sw = row & (CPRW - 1);
+      float v[EPL];
+#pragma unroll
+      for (int q = 0; q < EPL / 4; ++q) {
+        const float4 f = *(const float4*)(stg + row * WN + (((cc * (EPL / 4) + q) ^ sw) * 4));
+        v[4 * q + 0] = f.x + bias[4 * q + 0]; v[4 * q + 1] = f.y + bias[4 * q + 1];
+        v[4 * q + 2] = f.z + bias[4 * q + 2]; v[4 * q + 3] = f.w + bias[4 * q + 3];
+      }
+      if (p.residual) {
+        float r8[EPL];
+        unpack16<T>(res[b][it], r8);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] += r8[r];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.mask_src) {
+        float m8[EPL];
+        unpack16<T>(msk[b][it], m8);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
+      }
+      if (live[b][it]) *(uint4*)(p.out + offs[b][it] * ES) = pack16<T>(v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next chunk overwrites the region
+  }
+  TD_STAMP(5);
+#undef TD_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -677,6 +939,8 @@ struct WgradParams {
                  // 2: as 1 with plain stores (the job has a single split: nobody else touches the tile)
   int ci_real;   // input channels of the parameter (C may be padded)
   int tn, tk, first;  // batched launch: tile grid of this job and its first workgroup index
+  int cls;            // wide-tile instance (conv_wgrad_wide_batch_kernel): bit 0 = 256 output channels per tile (else 128),
+                      // bit 1 = 256 k columns per tile (else 128), bit 2 = pointwise
   unsigned long long* stamps;  // debug: 40 cycle stamps per workgroup (tools/stamp_wgrad.py)
 };
 
@@ -993,6 +1257,224 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_batch_kerne
   wgrad_body<T, NSTG, PW>(p, bx, by, local / p.tk, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide-tile weight gradients (bf16, batched launches, large M): the 128 x 128 instance above moves 32 KiB HBM/L2 -> LDS per
+// 128 MFMAs with ONE wavefront per SIMD - 0.17 of the MFMA peak measured over the trunk's 93 jobs.  Here a workgroup of
+// SIXTEEN wavefronts (four per SIMD: the LDS latency of one is covered by the MFMAs of the others, no fragment double
+// buffering, 128 registers each) owns a 256 (output channels) x 256 (k) tile of dW - or 128 x 256 / 256 x 128 for the
+// 128-wide layers - and walks its slice of the reduction in stages of 64 rows: 64 KiB per 512 MFMAs, the gradient rows of a
+// 256-channel layer read once per k tile.  LDS image: each 128-column sub-tile exactly as in the instance above
+// (reduction-major rows as they lie in HBM, swizzled 32-byte blocks, ds_read_b64_tr_b16 fragment reads); one DMA
+// instruction per wavefront, sub-tile and stage.  The barrier that publishes stage s + 1 sits between the fragment reads and
+// the MFMAs of the last k-step of stage s, so its skew is covered by 16 MFMAs per wavefront.  Output straight into the
+// parameter's [Nc][ci][R][S] layout with the FrozenBN scale folded (plain stores for unsplit jobs, fp32 atomics otherwise).
+// Nc and C are multiples of 128 (host-checked): a sub-tile is inside the matrix or outside as a whole and lies within ONE
+// filter tap - validity, tap and channel base are wave-uniform scalars, the lane only adds its column.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int GS, int XS, bool PW>
+__device__ __forceinline__ void wgrad_wide_body(const WgradParams& p, const int bx, const int by, const int bz, char* st0, char* st1) {
+  constexpr int ES = 2, MK = 64, ROWB = 256, SUB = MK * ROWB;  // one 128-column sub-tile = 16 KiB
+  constexpr int NW = 16;
+  constexpr int WVK = XS * 2, WVC = NW / WVK;  // wavefronts along k / along the output channels
+  constexpr int WCO = GS * 128 / WVC;
+  constexpr int FI = WCO / 16, FJ = 4;
+  static_assert(FI >= 1 && WCO <= 128, "wave tile");
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  const td_conv_desc& d = p.d;
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int co0 = bx * (GS * 128), kk0 = by * (XS * 128);
+  const int mbeg = bz * p.mper;
+  const int mend = min(p.M, mbeg + p.mper);
+  if (mbeg >= mend) return;
+  const int HoWo = d.Ho * d.Wo;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+
+  // DMA bookkeeping: this wavefront's instruction fills rows wave*4 + lane/16 of every sub-tile, LDS chunk lane%16
+  const int drow = wave * 4 + (lane >> 4);
+  const int c16 = lane & 15;
+  const int col = ((((c16 >> 1) ^ wg_swz<ES>(drow)) << 1) | (c16 & 1)) * 8;  // logical column of this lane's chunk
+  int mcur = mbeg + drow;
+  int rn = mcur / HoWo;
+  int rho = (mcur - rn * HoWo) / d.Wo;
+  int rwo = mcur - rn * HoWo - rho * d.Wo;
+  bool g_in[GS], x_in[XS];
+  int g_c0[GS], x_c0[XS], x_r[XS], x_s[XS];
+#pragma unroll
+  for (int s_ = 0; s_ < GS; ++s_) {
+    g_c0[s_] = co0 + s_ * 128;
+    g_in[s_] = g_c0[s_] < d.Nc;
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < XS; ++s_) {
+    const int kk = kk0 + s_ * 128;
+    x_in[s_] = kk < p.K;
+    x_r[s_] = 0; x_s[s_] = 0; x_c0[s_] = kk;
+    if (!PW && d.R * d.S > 1) {
+      const int tap = kk / d.C;
+      x_c0[s_] = kk - tap * d.C;
+      x_r[s_] = tap / d.S;
+      x_s[s_] = tap - x_r[s_] * d.S;
+    }
+  }
+  const int dN = MK / HoWo, dH = (MK - dN * HoWo) / d.Wo, dW = MK - dN * HoWo - dH * d.Wo;
+  auto issue_stage = [&](char* st) {
+    const int m = mcur;
+    const bool ok = m < mend;
+    const uint32_t grow = ((uint32_t)m * (uint32_t)p.ldg + (uint32_t)col) * ES;
+#pragma unroll
+    for (int s_ = 0; s_ < GS; ++s_) {
+      const uint32_t og = (ok && g_in[s_]) ? grow + (uint32_t)g_c0[s_] * ES : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(st + s_ * SUB + wave * 1024), 16, og, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < XS; ++s_) {
+      uint32_t ox;
+      if constexpr (PW) {
+        ox = (ok && x_in[s_]) ? ((uint32_t)m * (uint32_t)d.C + (uint32_t)(x_c0[s_] + col)) * ES : OOB;
+      } else {
+        const int hs = rho * d.stride - d.pad + x_r[s_], ws = rwo * d.stride - d.pad + x_s[s_];
+        const bool in = ok && x_in[s_] && (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
+        ox = in ? ((uint32_t)((rn * d.Hs + hs) * d.Ws + ws) * (uint32_t)d.C + (uint32_t)(x_c0[s_] + col)) * ES : OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st + (GS + s_) * SUB + wave * 1024), 16, ox, 0, 0, 0);
+    }
+    if constexpr (!PW) {
+      rwo += dW;
+      const int c1 = rwo >= d.Wo;
+      rwo -= c1 ? d.Wo : 0;
+      rho += dH + c1;
+      const int c2 = rho >= d.Ho;
+      rho -= c2 ? d.Ho : 0;
+      rn += dN + c2;
+    }
+    mcur += MK;
+  };
+
+  const int wyc = wave / WVK, wxk = wave - wyc * WVK;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int jrow = lr >> 2, q = lr & 3;
+  int f = jrow | ((lg & 1) << 2);  // = wg_swz(r0) = wg_swz(r1)
+  f32x4 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 gf[FI], xf[FJ];
+  auto frag = [&](const char* sub, int ks, int blk16) -> u32x4 {
+    const int r0 = ks * 32 + 8 * lg + jrow;
+    const int cb = ((blk16 ^ f) << 5) + q * 8;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sub + r0 * ROWB + cb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sub + (r0 + 4) * ROWB + cb));
+    const uint2 l2 = *(uint2*)&lo, h2 = *(uint2*)&hi;
+    return u32x4{l2.x, l2.y, h2.x, h2.y};
+  };
+  auto load_frags = [&](const char* st, int ks) {
+    const int xoff = wxk * 64, goff = wyc * WCO;  // both inside one sub-tile (WCO <= 64 or 128-aligned)
+    // the swizzle operand is laundered per call: the 2 x (FI + FJ) fragment addresses are then recomputed where they are
+    // used (an xor and a shift-add in the shadow of the MFMAs) instead of living in 16 registers across the loop
+    asm volatile("" : "+v"(f));
+#pragma unroll
+    for (int i = 0; i < FI; ++i) gf[i] = frag(st + ((goff + i * 16) / 128) * SUB, ks, ((goff + i * 16) % 128) / 16);
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) xf[j] = frag(st + (GS + xoff / 128) * SUB, ks, (xoff % 128) / 16 + j);
+  };
+  // The accumulator operand is TIED (inline asm "+v"): with the builtin the register allocator renames the accumulators
+  // through the two-stage loop body (destination != source C on most MFMAs), which doubles their footprint and spills.
+  // Hazards the compiler cannot see inside the asm: an accumulator is touched again 15 MFMAs (>= 240 cycles) later, and the
+  // epilogue below waits explicitly before its first VALU read.
+  auto mfmas = [&]() {
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(gf[i]), "v"(xf[j]));
+  };
+  auto stage_body = [&](char* cur, char* nxt) {
+    issue_stage(nxt);  // every wavefront finished reading `nxt` before the last barrier; past the slice: all-OOB, no traffic
+    load_frags(cur, 0);
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist the second k-step's reads: 2 x 32 fragment registers)
+    mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(cur, 1);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): own DMA of the next stage landed, own reads of `cur` returned
+    __builtin_amdgcn_s_barrier();
+    mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ONE loop over stage pairs and nothing else: an odd stage count is rounded up (rows past the slice are zero-filled
+  // without traffic).  A separate tail would bring register spills of the accumulators, and a spill store right behind an
+  // inline-asm MFMA lacks the MFMA -> VMEM wait states the compiler adds for MFMAs it knows about.
+  const int npair = ((mend - mbeg + MK - 1) / MK + 1) / 2;
+  issue_stage(st0);
+  __syncthreads();
+#pragma unroll 1
+  for (int it = 0; it < npair; ++it) {
+    stage_body(st0, st1);
+    stage_body(st1, st0);
+  }
+  // last MFMA results -> first read: 2 x 16 idle cycles, and every accumulator passes through an asm "modification" placed
+  // behind them, so no compiler-generated use (VALU read, spill store) of an accumulator can be scheduled before the wait
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) asm volatile("" : "+v"(acc[i][j]));
+  // D[i = co][j = kk]: lane holds co = base + 4*lg + rr, kk = base + lr
+  const int RS = d.R * d.S;
+#pragma unroll
+  for (int j = 0; j < FJ; ++j) {
+    const int kko = kk0 + wxk * 64 + j * 16 + lr;
+    if (kko >= p.K) continue;
+    int tap = 0, ci = kko;
+    if (!PW && RS > 1) {
+      tap = kko / d.C;
+      ci = kko - tap * d.C;
+    }
+    if (ci >= p.ci_real) continue;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int coo = co0 + wyc * WCO + i * 16 + 4 * lg + rr;
+        if (coo >= d.Nc) continue;
+        const float v = acc[i][j][rr] * (p.scale ? p.scale[coo] : 1.f);
+        float* dst = p.dw + ((size_t)coo * p.ci_real + ci) * RS + tap;
+        if (p.out_mode == 2) *dst = v;
+        else atomicAdd(dst, v);
+      }
+  }
+}
+
+__global__ __launch_bounds__(1024, 1) void conv_wgrad_wide_batch_kernel(const WgradParams* __restrict__ jobs, WgradXcdIndex xi) {
+  __shared__ __attribute__((aligned(16))) char wst0[65536];
+  __shared__ __attribute__((aligned(16))) char wst1[65536];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  if (slot >= xi.slots[xcd]) return;
+  int lo = xi.start[xcd], hi = xi.start[xcd + 1] - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first <= slot) lo = mid;
+    else hi = mid - 1;
+  }
+  const WgradParams p = jobs[lo];
+  int local = slot - p.first;
+  const int bx = local % p.tn;
+  local /= p.tn;
+  const int by = local % p.tk, bz = local / p.tk;
+  switch (p.cls) {
+    case 3: wgrad_wide_body<2, 2, false>(p, bx, by, bz, wst0, wst1); break;
+    case 7: wgrad_wide_body<2, 2, true>(p, bx, by, bz, wst0, wst1); break;
+    case 2: wgrad_wide_body<1, 2, false>(p, bx, by, bz, wst0, wst1); break;
+    case 6: wgrad_wide_body<1, 2, true>(p, bx, by, bz, wst0, wst1); break;
+    case 1: wgrad_wide_body<2, 1, false>(p, bx, by, bz, wst0, wst1); break;
+    default: wgrad_wide_body<2, 1, true>(p, bx, by, bz, wst0, wst1); break;
+  }
+}
+
 static int validate(const td_conv_desc* d, int dtype, const char* who) {
   const int vec = dtype == TD_BF16 ? 8 : 4;
   TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "%s: bad dtype %d", who, dtype);
@@ -1108,6 +1590,38 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   const int MT = cdiv(p.M, BMsel), NTl = cdiv(d->Nc, BNsel);
   dim3 grid(8 * cdiv(MT, 8) * NTl);
   const bool prof = prof_on();
+  const bool pw = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && p.d.out_sp == 1 && d->Hs == d->Ho && d->Ws == d->Wo;
+  // tap-uniform addressing (see conv_gemm_kernel): spatial convs whose channel count is a multiple of the K tile
+  static const int tu_on = [] { const char* e_ = getenv("TD_CONV_TAP_UNIFORM"); return e_ ? atoi(e_) : 1; }();
+  const int bk = dtype == TD_BF16 ? 64 : 32;
+  const bool tu = tu_on && !pw && d->R * d->S > 1 && d->R * d->S <= 32 && d->C % bk == 0 && p.d.out_sp == 1 && (d->mode == 0 || d->stride == 1);
+  {
+    // 256-row tiles (conv_gemm_big_kernel): MFMA-bound bf16 layers with enough workgroups to matter
+    static const int big_on = [] { const char* e_ = getenv("TD_CONV_BIG"); return e_ ? atoi(e_) : 1; }();
+    static const int big_min = [] { const char* e_ = getenv("TD_CONV_BIG_MIN_WG"); return e_ ? atoi(e_) : 160; }();
+    const int bnb = d->Nc % 256 == 0 ? 256 : 128;
+    const int wgs = cdiv(p.M, 256) * (d->Nc / bnb);
+    if (big_on && dtype == TD_BF16 && (pw || tu) && d->Nc % 128 == 0 && p.K % 64 == 0 && p.K >= 512 && d->ldc % 8 == 0 && !p.sigmoid &&
+        !p.drop_thresh && wgs >= big_min && (double)p.M * d->ldc < 2147483647.0) {
+      if (prof) {
+        prof_begin(TD_PROF_GEMM_256, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
+        double by = ((double)d->N * d->Hs * d->Ws * d->C + (double)d->Nc * p.K + (double)p.M * d->Nc) * 2.0;
+        if (p.residual) by += (double)p.M * d->Nc * 2.0;
+        if (p.mask_src) by += (double)p.M * d->Nc * 2.0;
+        prof_set_bytes(by);
+      }
+      dim3 gb(8 * cdiv(cdiv(p.M, 256), 8) * (d->Nc / bnb));
+      if (bnb == 256) {
+        if (tu) conv_gemm_big_kernel<256, true><<<gb, 512, 0, st>>>(p);
+        else conv_gemm_big_kernel<256, false><<<gb, 512, 0, st>>>(p);
+      } else {
+        if (tu) conv_gemm_big_kernel<128, true><<<gb, 512, 0, st>>>(p);
+        else conv_gemm_big_kernel<128, false><<<gb, 512, 0, st>>>(p);
+      }
+      if (prof) prof_end(st);
+      return check_launch("td_conv_gemm(256-row tiles)");
+    }
+  }
   if (prof) prof_begin(narrow ? TD_PROF_GEMM_128x64 : (small_m ? TD_PROF_GEMM_64x128 : TD_PROF_GEMM_128x128), dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
   if (prof) {
     // algorithmic HBM bytes: every operand / result tensor once (the gathered source counted as the tensor it is read from)
@@ -1118,11 +1632,6 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
     if (e && e->mask_src) by += rows_out * d->Nc * es;
     prof_set_bytes(by);
   }
-  const bool pw = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && p.d.out_sp == 1 && d->Hs == d->Ho && d->Ws == d->Wo;
-  // tap-uniform addressing (see conv_gemm_kernel): spatial convs whose channel count is a multiple of the K tile
-  static const int tu_on = [] { const char* e_ = getenv("TD_CONV_TAP_UNIFORM"); return e_ ? atoi(e_) : 1; }();
-  const int bk = dtype == TD_BF16 ? 64 : 32;
-  const bool tu = tu_on && !pw && d->R * d->S > 1 && d->R * d->S <= 32 && d->C % bk == 0 && p.d.out_sp == 1 && (d->mode == 0 || d->stride == 1);
 #define TD_LAUNCH(TT, BMv, BNv)                                                                   \
   do {                                                                                            \
     if (pw) conv_gemm_kernel<TT, BMv, BNv, 2, true><<<grid, 256, 0, st>>>(p);                    \
@@ -1245,7 +1754,7 @@ extern "C" int td_conv_wgrad_bias(const void* g, const void* src, float* dw, flo
 // The job table of a launch lives in caller-provided memory: the library writes it into `table_host` (page-locked),
 // enqueues ONE hipMemcpyAsync into `table_dev` on the caller's stream and launches; no allocation, no synchronisation.
 static size_t wg_table_half(int n_jobs) { return (((size_t)n_jobs * sizeof(WgradParams)) + 255) & ~(size_t)255; }
-extern "C" size_t td_conv_wgrad_batch_table_bytes(int n_jobs) { return n_jobs > 0 ? 2 * wg_table_half(n_jobs) : 0; }
+extern "C" size_t td_conv_wgrad_batch_table_bytes(int n_jobs) { return n_jobs > 0 ? 3 * wg_table_half(n_jobs) : 0; }  // general / pointwise / wide-tile tables
 
 extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev,
                                    size_t table_bytes, td_stream_t stream) {
@@ -1254,8 +1763,10 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
              "td_conv_wgrad_batch: job-table workspace missing or smaller than td_conv_wgrad_batch_table_bytes(%d)", n_jobs);
   const size_t half = wg_table_half(n_jobs);
   hipStream_t st = (hipStream_t)stream;
-  std::vector<WgradParams> tab[2];  // [0] general geometry, [1] pointwise
+  std::vector<WgradParams> tab[3];  // [0] general geometry, [1] pointwise, [2] wide tiles (conv_wgrad_wide_batch_kernel)
   double flops = 0, abytes = 0;
+  static const int wide_on = [] { const char* e = getenv("TD_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
+  static const int wide_min_m = [] { const char* e = getenv("TD_WGRAD_WIDE_MIN_M"); return e ? atoi(e) : 4096; }();
   for (int i = 0; i < n_jobs; ++i) {
     const td_wgrad_job& j = jobs[i];
     TD_REQUIRE(j.g && j.src && j.dW, "td_conv_wgrad_batch: job %d has a null pointer", i);
@@ -1277,7 +1788,16 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
       return TD_ERR_LAUNCH;
     }
     const bool pw = (j.d.R * j.d.S == 1) && j.d.stride == 1 && j.d.pad == 0;
-    tab[pw ? 1 : 0].push_back(p);
+    // wide tiles: bf16, many reduction rows, whole 128-column sub-tiles (see wgrad_wide_body), no fused bias gradient
+    const bool wide = wide_on && dtype == TD_BF16 && p.M >= wide_min_m && j.d.Nc % 128 == 0 && j.d.C % 128 == 0 && !j.dbias &&
+                      j.d.R * j.d.S <= 255 && (j.d.Nc % 256 == 0 || p.K >= 256);
+    if (wide) {
+      const int gs = j.d.Nc % 256 == 0 ? 2 : 1, xs = p.K >= 256 ? 2 : 1;
+      p.cls = (gs - 1) | ((xs - 1) << 1) | (pw ? 4 : 0);
+      p.tn = j.d.Nc / (gs * 128);
+      p.tk = cdiv(p.K, xs * 128);
+    }
+    tab[wide ? 2 : (pw ? 1 : 0)].push_back(p);
     flops += 2.0 * p.M * j.d.Nc * p.K;
     abytes += ((double)p.M * j.ldg + (double)j.d.N * j.d.Hs * j.d.Ws * j.d.C) * (dtype == TD_BF16 ? 2.0 : 4.0) + (double)j.d.Nc * j.ci_real * j.d.R * j.d.S * 4.0;
   }
@@ -1287,7 +1807,7 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
     prof_set_bytes(abytes);
   }
   const int nstg = wgrad_stages();
-  for (int pw = 0; pw < 2; ++pw) {
+  for (int pw = 0; pw < 3; ++pw) {
     std::vector<WgradParams>& t = tab[pw];
     if (t.empty()) continue;
     // one XCD per job, longest job first onto the least loaded XCD; inside an XCD the long work items come first so
@@ -1297,7 +1817,8 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
     std::vector<double> cost(nj);
     for (int i = 0; i < nj; ++i) {
       order[i] = i;
-      cost[i] = (double)t[i].tn * t[i].tk * t[i].first /*splits*/ * (double)t[i].mper * (pw ? 1.0 : 1.5);
+      cost[i] = (double)t[i].tn * t[i].tk * t[i].first /*splits*/ * (double)t[i].mper * ((pw == 1 || (t[i].cls & 4)) ? 1.0 : 1.5) *
+                (pw == 2 && (t[i].cls & 3) != 3 ? 0.6 : 1.0);  // half-size wide tiles: half the MFMAs, same DMA count
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1350,7 +1871,9 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
     if (pw) conv_wgrad_batch_kernel<TT, NS, true><<<grid, 256, 0, st>>>(dev, xi);            \
     else conv_wgrad_batch_kernel<TT, NS, false><<<grid, 256, 0, st>>>(dev, xi);              \
   } while (0)
-    if (nstg == 4) {
+    if (pw == 2) {
+      conv_wgrad_wide_batch_kernel<<<grid, 1024, 0, st>>>(dev, xi);
+    } else if (nstg == 4) {
       if (dtype == TD_BF16) TD_WGB_LAUNCH(u16, 4);
       else TD_WGB_LAUNCH(float, 4);
     } else {
