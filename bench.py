@@ -10,19 +10,20 @@ Workload at N=1: BASELINE.json configs[2] (the config the metric is quoted on): 
 L=30 text tokens, bf16 MFMA kernels with fp32 accumulation, random-init weights, train mode (dropout active),
 weights re-prepared every step (as after an optimizer step), all 125 trunk-forward frames of every clip executed
 (`--dedupe` skips the 25 slow frames inside the fast pass).  `--clips-per-gpu B` videos per GPU per step (the
-reference's --batch_size, main.py:63; 288 GB of HBM hold B = 4 clips = 50 GB of activations, and every latency-bound
-launch of the step - the 100-row decoder, RoBERTa on 30 tokens, the 12 100-row trunk backward - then does B times the
-work): `value` counts clips, not steps.  Inputs are generated on the device before the timed region.
+reference's --batch_size, main.py:63; default 8: 288 GB of HBM hold the 100 GB of activations of 8 clips, and every
+latency-bound launch of the step - the 100-row decoder, RoBERTa on 30 tokens, the 12 100-row trunk backward - then does B
+times the work; measured 42.9 / 55.8 / 67.6 / 73.0 clips/s at B = 1 / 2 / 4 / 8): `value` counts clips, not steps.  Inputs
+are generated on the device before the timed region.
 
-Execution: the step is captured once in HIP graph(s) and replayed (`--no-graph`: eager launches, host-bound).
-  N = 1 : one single-stream graph.
+Execution: the step is captured once in HIP graph(s) and replayed (`--no-graph`: eager launches; GPU-bound too from B = 4 on).
+  N = 1 : one graph, RoBERTa on a forked branch (its 120-row GEMMs overlap the trunk; `--no-text-stream`: linear graph).
   N > 1 : the step is cut at the ResNet trunk boundary (harness.backward_in_stages) and captured as TWO graphs; the
           all-reduce of the gradients that are final after the first one (heads, decoder, encoder, RoBERTa, input_proj:
           0.57 of 0.74 GB) is started between the two replays and overlaps the trunk backward, the trunk's own 0.17 GB
           follow (tubedetr_amd/distributed.py).  `--no-overlap`: one graph + one flat all-reduce after it; `--ddp`: torch
           DistributedDataParallel like main.py:372-376.
-At N=1 the measurement runs in a child process; if it dies the parent re-measures with eager launches, so a bench line
-is always produced; `attempts` in the JSON records what happened.
+At N=1 the measurement runs in a child process; if it dies the parent re-measures (linear graph, then eager launches), so
+a bench line is always produced; `attempts` in the JSON records what happened.
 
 Extra legs (rank 0, after the timed region, not part of `value`):
   roofline     : `--roofline-steps` more identical steps, launched eagerly, with HIP events recorded on the launch
@@ -61,7 +62,7 @@ PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 # algorithmic TFLOP per clip fwd+bwd
 ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
-DEFAULT_CLIPS_PER_GPU = 4
+DEFAULT_CLIPS_PER_GPU = 8
 PMC_TRAFFIC = "r02_pmc_traffic.json"
 PMC_MFMA = "r02_pmc_mfma.json"
 
@@ -185,8 +186,10 @@ def main():
     ap.add_argument("--no-tsa", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: run in eval mode")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--text-stream", action="store_true",
-                    help="graph mode: keep RoBERTa on its own stream (a forked graph branch: ~0.5 ms less GPU time per step but a 24 ms hipGraphLaunch)")
+    ap.add_argument("--text-stream", action="store_true", help="(default at N=1; accepted for older command lines)")
+    ap.add_argument("--no-text-stream", action="store_true",
+                    help="graph mode: capture RoBERTa on the main stream (a linear graph) instead of its own stream (a forked graph branch: "
+                         "its latency-bound 120-row GEMMs then overlap the trunk, ~2 ms per step at 4 clips; the default at N=1)")
     a = ap.parse_args()
 
     if os.environ.get("TD_EFENCE") == "1":  # diagnostic: electric-fence device allocator (tests/efence/), eager launches only
@@ -203,7 +206,7 @@ def main():
 
         argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]
         attempts = []
-        for extra in ([], [], ["--no-graph"]):
+        for extra in ([], ["--no-text-stream"], ["--no-graph"]):  # forked graph, linear graph, eager launches
             r = subprocess.run(argv + extra, stdout=subprocess.PIPE, text=True)
             line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
             attempts.append({"args": extra, "returncode": r.returncode})
@@ -214,8 +217,9 @@ def main():
                 return
             print(f"[bench] child {extra} failed with exit code {r.returncode}; retrying", file=sys.stderr, flush=True)
         raise SystemExit("bench: every attempt failed")
+    a.text_stream = a.graph and world == 1 and not a.force_ddp and not a.no_text_stream
     if a.graph and not a.text_stream:
-        os.environ.setdefault("TD_TEXT_STREAM", "0")  # single-stream capture: a linear graph launches in ~5 ms of host time
+        os.environ.setdefault("TD_TEXT_STREAM", "0")  # single-stream capture (the N > 1 staged two-graph mode is built on it)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
@@ -372,7 +376,7 @@ def main():
                     reducer.all_reduce()  # the only collective of the step, outside the graph
                 return static_loss
 
-            execution = "hip_graph" if not staged else "2 hip_graphs (cut at the trunk boundary, exchange overlapped)"
+            execution = ("hip_graph (text encoder on a forked branch)" if a.text_stream else "hip_graph (linear)") if not staged else "2 hip_graphs (cut at the trunk boundary, exchange overlapped)"
         except Exception as exc:  # capture not possible: measure the eager path
             ops_.set_dropout_counter(None)
             torch.cuda.synchronize()
@@ -420,7 +424,8 @@ def main():
             tname = "unsigned short" if cdt == torch.bfloat16 else "float"
             peak = PEAK_BF16_TFLOPS if cdt == torch.bfloat16 else 157.3
             fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128, *, *>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128, *, *>",
-                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, *, *>", 2: f"td::conv_wgrad_batch_kernel<{tname}>", 4: "td::pw_resident_kernel<*>"}  # * = all pipeline depths, pointwise and generic instances
+                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, *, *>", 2: "td::conv_wgrad_*batch_kernel", 4: "td::pw_resident_kernel<*>",
+                    5: "td::conv_gemm_big_kernel<*>"}  # * = all pipeline depths, pointwise and generic instances; 2 = wide-tile + 128x128 batched weight-gradient launches
             pmc, mfma = _load_profile_json(PMC_TRAFFIC), _load_profile_json(PMC_MFMA)
             # an (event, event) pair around nothing: what the bracketing itself adds to every launch (reported, NOT subtracted)
             cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
@@ -447,7 +452,7 @@ def main():
                            "traffic": traffic,
                            "traffic_source": (f"STATIC, not measured by this run: HBM bytes per launch from the committed rocprofv3 PMC passes of the same command "
                                               f"(FETCH_SIZE x2 + WRITE_SIZE, profiles/{PMC_TRAFFIC})") if traffic else None,
-                           "mfma_util": mu, "mfma_util_source": (f"STATIC: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), profiles/{PMC_MFMA}") if mu is not None else None,
+                           "mfma_util": mu, "mfma_util_source": (f"STATIC: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) over the family's launches, profiles/{PMC_MFMA}") if mu is not None else None,
                            "algorithmic_bytes_per_launch": round(by.value / n.value), "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfl, 2),
                            "launches_per_step": n.value // a.roofline_steps, "event_pair_overhead_us": round(ev_over_ms * 1e3, 2),
                            "avg_launch_us": round(ms.value * 1e3 / n.value, 2), "kernel_ms_per_step": round(ms.value / a.roofline_steps, 3),

@@ -50,3 +50,14 @@ for rows, K, Nn in [(frames * 484, 1024, 256), (frames * 121, 2048, 512), (frame
     us = timeit(lambda: ops.linear_fwd(x, w, b, relu=True, out=y))
     by = (rows * K + Nn * K + rows * Nn) * 2
     print(f"1x1   M={rows} K={K} N={Nn}: {us:8.1f} us  {2.0 * rows * K * Nn / us / 1e6:7.1f} TF/s  {by / us / 1e3:7.1f} GB/s")
+
+# persistent 1x1 instance (K <= 256): conv3 of a layer3 bottleneck with its residual, and the layer1 shape
+for rows, K, Nn in [(frames * 484, 256, 1024), (frames * 7744, 64, 256)]:
+    x = torch.randn(rows, K, device=dev, generator=g).bfloat16()
+    w = (torch.randn(Nn, K, device=dev, generator=g) * 0.02).bfloat16()
+    b = torch.randn(Nn, device=dev, generator=g)
+    r = torch.randn(rows, Nn, device=dev, generator=g).bfloat16()
+    y = torch.empty(rows, Nn, device=dev, dtype=torch.bfloat16)
+    us = timeit(lambda: ops.linear_fwd(x, w, b, residual=r, relu=True, out=y))
+    by = (rows * K + Nn * K + 2 * rows * Nn) * 2
+    print(f"1x1+res M={rows} K={K} N={Nn}: {us:8.1f} us  {by / us / 1e3:7.1f} GB/s")

@@ -13,6 +13,10 @@ def family(name):
         return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, *, *>"  # stages and pointwise flag merged
     if "td::pw_resident_kernel" in name:
         return "td::pw_resident_kernel<*>"
+    if "td::conv_gemm_big_kernel" in name:
+        return "td::conv_gemm_big_kernel<*>"
+    if "td::conv_wgrad_wide_batch_kernel" in name or "td::conv_wgrad_batch_kernel" in name:
+        return "td::conv_wgrad_*batch_kernel"
     m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)
     if m:
         return f"td::{m.group(1)}<{m.group(2)}>"

@@ -133,6 +133,29 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// 16-byte epilogue operand loads / result stores, non-temporal (TD_NT bit 0: loads, bit 1: stores; 0 = plain, for A/B builds):
+// these tensors are 0.1 - 1 GB streams that are touched once per launch; measured on the K >= 512 pointwise launches
+// -12 .. -18 %, on the persistent 1x1 instance 5.05 -> 5.41 TB/s.
+#ifndef TD_NT
+#define TD_NT 3
+#endif
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16(const char* p) {
+#if TD_NT & 1
+  const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *(const uint4*)p;
+#endif
+}
+__device__ __forceinline__ void st16(char* p, const uint4& v) {
+#if TD_NT & 2
+  __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, (u32x4_t*)p);
+#else
+  *(uint4*)p = v;
+#endif
+}
+
 // Main loop: operands go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB = 8 rows x 128 B per wave
 // instruction, no VGPR staging).  The LDS image is row-major with the 16-byte chunk index XOR-swizzled by
 // (row & 7): the DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE address and
@@ -374,8 +397,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
       }
       offs[it] = orow * d.ldc + n;
       if (vec_ok && live[it]) {
-        if (p.residual) res[it] = *(const uint4*)(p.residual + offs[it] * ES);
-        if (p.mask_src) msk[it] = *(const uint4*)(p.mask_src + offs[it] * ES);
+        if (p.residual) res[it] = ld16(p.residual + offs[it] * ES);
+        if (p.mask_src) msk[it] = ld16(p.mask_src + offs[it] * ES);
       }
     }
   };
@@ -482,7 +505,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
 #pragma unroll
         for (int r = 0; r < EPL; ++r) v[r] = dropout_keep(eff_seed, (uint32_t)(off + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
       }
-      *(uint4*)(p.out + off * ES) = pack16<T>(v);
+      st16(p.out + off * ES, pack16<T>(v));
     } else {
       const int cnt = min(EPL, d.Nc - n);
       for (int r = 0; r < cnt; ++r) {
@@ -682,8 +705,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
       const int m = m0 + wy * WM + c * CR + it * RPI + rsub;
       live[b][it] = m < p.M;
       offs[b][it] = (uint32_t)min(m, p.M - 1) * (uint32_t)d.ldc + (uint32_t)n;
-      if (p.residual) res[b][it] = *(const uint4*)(p.residual + offs[b][it] * ES);
-      if (p.mask_src) msk[b][it] = *(const uint4*)(p.mask_src + offs[b][it] * ES);
+      if (p.residual) res[b][it] = ld16(p.residual + offs[b][it] * ES);
+      if (p.mask_src) msk[b][it] = ld16(p.mask_src + offs[b][it] * ES);
     }
   };
 
@@ -753,7 +776,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
       }
-      if (live[b][it]) *(uint4*)(p.out + offs[b][it] * ES) = pack16<T>(v);
+      if (live[b][it]) st16(p.out + offs[b][it] * ES, pack16<T>(v));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next chunk overwrites the region
   }
@@ -833,8 +856,8 @@ __global__ __launch_bounds__(256, 2) void pw_resident_kernel(GemmParams p, int M
       const int m = mt * 64 + wy * WM + it * RPI + rsub;
       live[it] = m < p.M;
       offs[it] = (size_t)min(m, p.M - 1) * d.ldc + n;
-      if constexpr (RES) res[it] = *(const uint4*)(p.residual + offs[it] * ES);
-      if constexpr (MSK) msk[it] = *(const uint4*)(p.mask_src + offs[it] * ES);
+      if constexpr (RES) res[it] = ld16(p.residual + offs[it] * ES);
+      if constexpr (MSK) msk[it] = ld16(p.mask_src + offs[it] * ES);
     }
     // (2) next activation tile, then wait for the current one: only the loads issued in (1) and (2) may still be in
     //     flight (loads complete in order; stores of the previous tile can only make this wait stricter)
@@ -904,7 +927,7 @@ __global__ __launch_bounds__(256, 2) void pw_resident_kernel(GemmParams p, int M
 #pragma unroll
         for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
       }
-      if (live[it]) *(uint4*)(p.out + offs[it] * ES) = pack16<T>(v);
+      if (live[it]) st16(p.out + offs[it] * ES, pack16<T>(v));
     }
     // (4) staging reads done before the next step's DMA lands in this buffer
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
