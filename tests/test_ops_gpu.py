@@ -89,7 +89,7 @@ def test_conv_wgrad_batch_matches_autograd(dt):
     from tubedetr_amd import ops
 
     g = torch.Generator().manual_seed(21)
-    cfgs = CONVS + [(40, 64, 28, 28, 64, 1, 1, 0), (30, 64, 24, 24, 128, 3, 1, 1)]  # the last two are long enough to split
+    cfgs = CONVS + [(44, 64, 28, 28, 64, 1, 1, 0), (60, 64, 24, 24, 128, 3, 1, 1)]  # the last two are long enough to split (> 512 stages of 64 rows)
     jobs, refs = [], []
     for i, (N, Ci, H, W, Co, R, st, pad) in enumerate(cfgs):
         x = rnd((N, Ci, H, W), g, dt)
@@ -125,8 +125,9 @@ def test_conv_wgrad_batch_wide_tiles():
 
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(23)
-    cfgs = [(8, 128, 28, 27, 128, 3, 1, 1), (20, 256, 26, 25, 256, 3, 1, 1), (5, 1024, 30, 31, 256, 1, 1, 0), (16, 512, 30, 30, 128, 1, 1, 0),
-            (6, 128, 28, 28, 512, 1, 1, 0), (8, 128, 57, 57, 128, 3, 2, 1), (2, 64, 12, 12, 64, 1, 1, 0), (3, 512, 40, 40, 512, 3, 1, 1)]
+    cfgs = [(8, 128, 28, 27, 128, 3, 1, 1), (52, 256, 26, 25, 256, 3, 1, 1), (5, 1024, 30, 31, 256, 1, 1, 0), (40, 512, 30, 30, 128, 1, 1, 0),
+            (6, 128, 28, 28, 512, 1, 1, 0), (8, 128, 57, 57, 128, 3, 2, 1), (2, 64, 12, 12, 64, 1, 1, 0), (3, 512, 40, 40, 512, 3, 1, 1),
+            (50, 128, 28, 27, 128, 3, 1, 1)]  # M = 33 800 / 36 000 / 37 800 rows: split in two (atomics), the others unsplit
     jobs, refs = [], []
     for i, (N, Ci, H, W, Co, R, st, pad) in enumerate(cfgs):
         x = rnd((N, Ci, H, W), g, dt).to(dev())
