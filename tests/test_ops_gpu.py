@@ -334,11 +334,12 @@ def test_linear_sigmoid_alpha_dropout(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-def test_add_layernorm(dt):
+@pytest.mark.parametrize("shape", [(777, 256), (61, 768), (20011, 256), (33, 96)])  # vectorised bf16 instances (256 / 768 columns) and the generic one
+def test_add_layernorm(shape, dt):
     from tubedetr_amd import ops
 
     g = torch.Generator().manual_seed(6)
-    rows, cols = 777, 256
+    rows, cols = shape
     x, r = rnd((rows, cols), g, dt), rnd((rows, cols), g, dt)
     gamma, beta = torch.rand(cols, generator=g) + 0.5, torch.randn(cols, generator=g)
     sr = (x + r).requires_grad_(True)
