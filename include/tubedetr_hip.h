@@ -262,6 +262,21 @@ int td_mha_bwd(const void* q, const void* k, const void* v, const void* dout, co
                int ldv, int ldo, float scale, float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter,
                int dtype, td_stream_t stream);
 
+/* Lean form of the same attention core for callers that do not need the weights (the per-frame visual-text encoder,
+ * models/transformer.py:638-640: `weights` is dead there, SURVEY.md 8a'): nothing of size Lq x Lk is stored.  The forward
+ * writes two softmax statistics per (batch, head, query) into `stats` (td_mha_lean_stats_bytes(B, H, Lq) bytes: 4 floats per
+ * row); the backward recomputes the probabilities from q, k, key_pad and those statistics, takes sum_k P dP from dout . out
+ * (`out` = the forward's output), and uses the third float of each row as scratch.  bf16, hd = 32, Lk <= 256, Lq <= 448,
+ * 16-byte aligned rows; anything else returns TD_ERR_INVALID (use td_mha_fwd / td_mha_bwd).  Same dropout mask as td_mha_fwd. */
+size_t td_mha_lean_stats_bytes(int B, int H, int Lq);
+int td_mha_lean_fwd(const void* q, const void* k, const void* v, const uint8_t* key_pad, void* out, float* stats, int B, int H,
+                    int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo, float scale, float dropout_p,
+                    uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream);
+int td_mha_lean_bwd(const void* q, const void* k, const void* v, const uint8_t* key_pad, const void* out, const void* dout,
+                    float* stats, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk, int ldv,
+                    int ldo, float scale, float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype,
+                    td_stream_t stream);
+
 
 /* ---- optimizer-side tail of a training step over FLAT fp32 buffers -------------------------------
  * All trainable parameters of the model lie back to back in one buffer (`param`), their gradients in the same order in

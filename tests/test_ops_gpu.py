@@ -427,6 +427,51 @@ def test_mha_core_fwd_bwd(cfg, dt):
         assert rel_err(got, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("cfg", [(3, 8, 151, 151, True), (2, 8, 100, 100, False), (7, 8, 1, 151, True), (2, 8, 37, 70, True), (2, 8, 60, 250, True)])
+def test_mha_lean_matches_reference_and_probs_path(cfg):
+    """The no-weights ("lean") attention core: nothing of size Lq x Lk is stored, the backward recomputes the probabilities
+    from the row statistics.  Against an fp32 torch reference, and - with probability dropout on - against the probs-based
+    kernels of the same library on the same seed (same mask by construction)."""
+    from tubedetr_amd import ops
+
+    dt = torch.bfloat16
+    B, H, Lq, Lk, use_mask = cfg
+    E, hd = H * 32, 32
+    g = torch.Generator().manual_seed(19)
+    q, k, v = rnd((B, Lq, E), g, dt), rnd((B, Lk, E), g, dt), rnd((B, Lk, E), g, dt)
+    kpm = (torch.rand(B, Lk, generator=g) > 0.8) if use_mask else None
+    if kpm is not None:
+        kpm[:, 0] = False
+    scale = 1 / math.sqrt(hd)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (qr, kr, vr))
+    sc = (qh @ kh.transpose(-1, -2)) * scale
+    if kpm is not None:
+        sc = sc.masked_fill(kpm[:, None, None, :], float("-inf"))
+    out_ref = (sc.softmax(-1) @ vh).transpose(1, 2).reshape(B, Lq, E)
+    dout = rnd((B, Lq, E), g, dt)
+    (out_ref * dout).sum().backward()
+    qd, kd, vd = (t.to(dev(), dt) for t in (q, k, v))
+    kd_ = kpm.to(dev()) if kpm is not None else None
+    assert ops.mha_lean_ok(qd, kd, vd, H)
+    out, stats, kp = ops.mha_lean_fwd(qd, kd, vd, kd_, H, scale)
+    assert stats.shape == (B * H * Lq, 4)
+    assert rel_err(out, out_ref) < TOL[dt]
+    dq, dk, dv = ops.mha_lean_bwd(qd, kd, vd, kp, out, dout.to(dev(), dt), stats, H, scale, torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd))
+    for got, ref in ((dq, qr.grad), (dk, kr.grad), (dv, vr.grad)):
+        assert rel_err(got, ref) < TOL[dt]
+    # dropout on: lean == probs-based path of the same seed
+    p_drop, seed = 0.1, 1234
+    out_a, stats_a, kp = ops.mha_lean_fwd(qd, kd, vd, kd_, H, scale, dropout_p=p_drop, seed=seed)
+    out_b, probs_b, _ = ops.mha_fwd(qd, kd, vd, kd_, H, scale, dropout_p=p_drop, seed=seed)
+    assert torch.equal(out_a, out_b)
+    do = dout.to(dev(), dt)
+    ga = ops.mha_lean_bwd(qd, kd, vd, kp, out_a, do, stats_a, H, scale, torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd), dropout_p=p_drop, seed=seed)
+    gb = ops.mha_bwd(qd, kd, vd, do, probs_b, None, H, scale, torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd), dropout_p=p_drop, seed=seed)
+    for a, b in zip(ga, gb):
+        assert rel_err(a, b) < TOL[dt]
+
+
 @pytest.mark.parametrize("cfg", [(3, 8, 151, 151), (1, 8, 100, 100), (5, 8, 1, 151), (2, 8, 40, 200)])
 def test_mha_dropout_same_mask_in_both_dtypes(cfg):
     """The counter-based dropout mask is a function of (seed, element index) only: the exact-fp32 VALU kernels and the

@@ -11,7 +11,7 @@ import os
 import torch
 
 TD_F32, TD_BF16 = 0, 1
-EXPECTED_ABI = 3  # td_abi_version() of the library these signatures were written against
+EXPECTED_ABI = 4  # td_abi_version() of the library these signatures were written against
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtubedetr_hip.so")
 _lib = None
 
@@ -96,9 +96,12 @@ _SIGS = {
     "td_adamw_ema_step": [_P, _P, _P, _P, _P, _SZ, C.POINTER(OptimSegment), _I, _P, _P, _P, _F, _F, _F, _F, _F, _P],
     "td_mha_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
     "td_mha_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
+    "td_mha_lean_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
+    "td_mha_lean_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
 }
 _SIZE_SIGS = {
     "td_grad_norm_ws_bytes": [],
+    "td_mha_lean_stats_bytes": [_I, _I, _I],
     "td_conv_wgrad_batch_table_bytes": [_I],
     "td_resnet_bwd_table_bytes": [C.POINTER(C.c_int), _I],
     "td_resnet_fwd_ws_bytes": [_I, _I, _I, C.POINTER(C.c_int), _I, _I],

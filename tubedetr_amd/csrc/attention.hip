@@ -21,6 +21,7 @@ struct MhaParams {
   float* probs;
   const float* dwavg;
   float* ds_ws;
+  float* stats;  // lean path: [B*H][Lq][4] = (row max of the scaled masked scores, 1 / sum exp, delta = dO . O, unused)
   int B, H, Lq, Lk, ldq, ldk, ldv, ldo;
   float scale;
   uint32_t drop_thresh;
@@ -259,7 +260,9 @@ __device__ __forceinline__ void stage_transposed(u16* dst, int stride, const u16
   }
 }
 
-template <int NT>
+// LEAN: nothing of size Lq x Lk leaves the kernel - the probabilities are not stored (the backward recomputes them from
+// q, k and the two softmax statistics per row written to p.stats), for attention whose weights nobody reads (the encoder).
+template <int NT, bool LEAN = false>
 __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(MhaParams p) {
   constexpr int KP = NT * 16, VS = KP + 8;
   __shared__ __attribute__((aligned(16))) u16 sVt[32 * VS];
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(MhaParams p) {
   const float inv = 1.f / sum;
   const uint32_t seed = effective_seed(p.seed, p.seed_dev);
   const size_t prow = ((size_t)bh * Lq + qj) * Lk;
+  if (LEAN && qv && g == 0) *(float2*)(p.stats + ((size_t)bh * Lq + qj) * 4) = make_float2(mx, inv);
   f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int u = 0; u < NT / 2; ++u) {
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(MhaParams p) {
       for (int r = 0; r < 4; ++r) {
         const int key = (2 * u + hh) * 16 + 4 * g + r;
         float pr = s[2 * u + hh][r] * inv;
-        if (qv && key < Lk) p.probs[prow + key] = pr;
+        if (!LEAN && qv && key < Lk) p.probs[prow + key] = pr;
         if (p.drop_thresh) pr = dropout_keep(seed, (uint32_t)(prow + key), p.drop_thresh) ? pr * p.drop_scale : 0.f;
         bp[hh * 4 + r] = (__bf16)pr;
       }
@@ -494,6 +498,189 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(MhaParams p) {
   }
 }
 
+// ---- lean backward (no Lq x Lk tensor is read or written) ----------------------------------------------------------
+// kernel A: P recomputed from q, k and the row statistics; delta = sum_k P dP = dO . O (also under dropout: O = Pd V),
+// written to p.stats[..][2] for kernel B; dQ^T = K^T dS^T as in the probs-based kernel.
+template <int NT>
+__global__ __launch_bounds__(256) void mha_bwd_dq_lean_kernel(MhaParams p) {
+  constexpr int KP = NT * 16, VS = KP + 8;
+  __shared__ __attribute__((aligned(16))) u16 sKt[32 * VS];
+  __shared__ __attribute__((aligned(16))) float sBias[KP];
+  const int Lk = p.Lk, Lq = p.Lq, nthr = blockDim.x, nw = nthr >> 6;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const u16* Q = (const u16*)p.q;
+  const u16* K = (const u16*)p.k;
+  const u16* V = (const u16*)p.v;
+  const u16* DO = (const u16*)p.dout;
+  const u16* O = (const u16*)p.out;
+  const int qb = (blockIdx.y * nw + wave) * 16, qj = qb + li;
+  const bool qv = qj < Lq;
+  uint4 bdo = make_uint4(0, 0, 0, 0), bq = make_uint4(0, 0, 0, 0), bo = make_uint4(0, 0, 0, 0);
+  float2 st2 = make_float2(0.f, 0.f);
+  if (qv) {
+    bdo = ldg16(DO + (size_t)(b * Lq + qj) * p.ldo + h * HD + 8 * g);
+    bo = ldg16(O + (size_t)(b * Lq + qj) * p.ldo + h * HD + 8 * g);
+    bq = ldg16(Q + (size_t)(b * Lq + qj) * p.ldq + h * HD + 8 * g);
+    st2 = *(const float2*)(p.stats + ((size_t)bh * Lq + qj) * 4);
+  }
+  stage_transposed(sKt, VS, K + (size_t)b * Lk * p.ldk + h * HD, p.ldk, Lk, KP, t, nthr);
+  for (int key = t; key < KP; key += nthr) sBias[key] = (key < Lk && !(p.kpm && p.kpm[b * Lk + key])) ? 0.f : -INFINITY;
+  __syncthreads();
+  if (qb >= Lq) return;
+  // delta = dO . O over the 32 channels of this head: 8 per lane group, summed over the four groups
+  float delta = 0.f;
+  {
+    const u16* a = (const u16*)&bdo;
+    const u16* c = (const u16*)&bo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) delta += bf16_to_f32(a[i]) * bf16_to_f32(c[i]);
+  }
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+  if (qv && g == 0) p.stats[((size_t)bh * Lq + qj) * 4 + 2] = delta;
+  const uint32_t seed = effective_seed(p.seed, p.seed_dev);
+  const size_t prow = ((size_t)bh * Lq + qj) * Lk;
+  f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int u = 0; u < NT / 2; ++u) {
+    bf16x8 bs;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int tt = 2 * u + hh, key0 = tt * 16 + li;
+      uint4 ak = make_uint4(0, 0, 0, 0), av = make_uint4(0, 0, 0, 0);
+      if (key0 < Lk) {
+        ak = ldg16(K + (size_t)(b * Lk + key0) * p.ldk + h * HD + 8 * g);
+        av = ldg16(V + (size_t)(b * Lk + key0) * p.ldv + h * HD + 8 * g);
+      }
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 sc = mfma_bf16(ak, bq, z);   // S^T[key 4g+r][query li]
+      const f32x4 dp = mfma_bf16(av, bdo, z);  // dP^T
+      const float4 bias = *(const float4*)&sBias[tt * 16 + 4 * g];
+      const float bz[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = tt * 16 + 4 * g + r;
+        float ds = 0.f;
+        if (qv && key < Lk) {
+          const float pr = __expf(sc[r] * p.scale + bz[r] - st2.x) * st2.y;
+          float d = dp[r];
+          if (p.drop_thresh) d = dropout_keep(seed, (uint32_t)(prow + key), p.drop_thresh) ? d * p.drop_scale : 0.f;
+          ds = pr * (d - delta);
+        }
+        bs[hh * 4 + r] = (__bf16)ds;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      uint4 ak;
+      const uint2 lo = *(const uint2*)&sKt[(m * 16 + li) * VS + (2 * u) * 16 + 4 * g];
+      const uint2 hi = *(const uint2*)&sKt[(m * 16 + li) * VS + (2 * u + 1) * 16 + 4 * g];
+      ak.x = lo.x; ak.y = lo.y; ak.z = hi.x; ak.w = hi.y;
+      dq[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&ak, bs, dq[m], 0, 0, 0);
+    }
+  }
+  if (qv) {
+    u16* DQ = (u16*)p.dq + (size_t)(b * Lq + qj) * p.ldq + h * HD + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      bf16x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = (__bf16)(dq[m][r] * p.scale);
+      *(bf16x4*)(DQ + m * 16) = w;
+    }
+  }
+}
+
+// kernel B: one wavefront per 16-key tile, reduction over the queries in chunks of 32.  Per chunk the score and dP tiles
+// are recomputed as D[query][key] (A = 16 rows of q / dO, B = this tile's k / v rows, both straight 16-byte row loads),
+// which leaves every lane with 8 queries of its key column in the permuted order {qc+4g..+3, qc+16+4g..+3}; the second
+// products (dV^T = dO^T Pd, dK^T = Q^T dS) read their A operand from the transposed LDS copies in the same order.
+__global__ __launch_bounds__(256) void mha_bwd_dkv_lean_kernel(MhaParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Lk = p.Lk, Lq = p.Lq, nthr = blockDim.x, nw = nthr >> 6;
+  const int QP = cdiv(Lq, 32) * 32, QS = QP + 8;
+  u16* sQt = (u16*)sm;
+  u16* sOt = sQt + 32 * QS;
+  float4* sSt = (float4*)(sOt + 32 * QS);  // [QP] (max, 1/sum, delta, -)
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const u16* Q = (const u16*)p.q + (size_t)b * Lq * p.ldq + h * HD;
+  const u16* DO = (const u16*)p.dout + (size_t)b * Lq * p.ldo + h * HD;
+  stage_transposed(sQt, QS, Q, p.ldq, Lq, QP, t, nthr);
+  stage_transposed(sOt, QS, DO, p.ldo, Lq, QP, t, nthr);
+  for (int q = t; q < QP; q += nthr) sSt[q] = q < Lq ? *(const float4*)(p.stats + ((size_t)bh * Lq + q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int kt = blockIdx.y * nw + wave;
+  if (kt * 16 >= Lk) return;
+  const int key = kt * 16 + li;
+  const bool kv = key < Lk;
+  const float kbias = (kv && !(p.kpm && p.kpm[b * Lk + key])) ? 0.f : -INFINITY;
+  uint4 bk = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
+  if (kv) {
+    bk = ldg16((const u16*)p.k + (size_t)(b * Lk + key) * p.ldk + h * HD + 8 * g);
+    bv = ldg16((const u16*)p.v + (size_t)(b * Lk + key) * p.ldv + h * HD + 8 * g);
+  }
+  const uint32_t seed = effective_seed(p.seed, p.seed_dev);
+  f32x4 dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int qc = 0; qc < QP; qc += 32) {
+    bf16x8 bp, bs;
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) {
+      const int qrow = qc + tq * 16 + li;  // A-operand row of this lane
+      uint4 aq = make_uint4(0, 0, 0, 0), ado = make_uint4(0, 0, 0, 0);
+      if (qrow < Lq) {
+        aq = ldg16(Q + (size_t)qrow * p.ldq + 8 * g);
+        ado = ldg16(DO + (size_t)qrow * p.ldo + 8 * g);
+      }
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 sc = mfma_bf16(aq, bk, z);   // S[query 4g+r][key li]
+      const f32x4 dp = mfma_bf16(ado, bv, z);  // dP
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = qc + tq * 16 + 4 * g + r;
+        float pr = 0.f, ds = 0.f;
+        if (kv && qq < Lq) {
+          const float4 st = sSt[qq];
+          const float pv = __expf(sc[r] * p.scale + kbias - st.x) * st.y;
+          const size_t pi = ((size_t)bh * Lq + qq) * Lk + key;
+          const bool keep = !p.drop_thresh || dropout_keep(seed, (uint32_t)pi, p.drop_thresh);
+          pr = keep ? pv * p.drop_scale : 0.f;
+          const float d = keep ? dp[r] * p.drop_scale : 0.f;
+          ds = pv * (d - st.z);
+        }
+        bp[tq * 4 + r] = (__bf16)pr;
+        bs[tq * 4 + r] = (__bf16)ds;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      uint4 ao, aq;
+      const uint2 olo = *(const uint2*)&sOt[(m * 16 + li) * QS + qc + 4 * g], ohi = *(const uint2*)&sOt[(m * 16 + li) * QS + qc + 16 + 4 * g];
+      const uint2 qlo = *(const uint2*)&sQt[(m * 16 + li) * QS + qc + 4 * g], qhi = *(const uint2*)&sQt[(m * 16 + li) * QS + qc + 16 + 4 * g];
+      ao.x = olo.x; ao.y = olo.y; ao.z = ohi.x; ao.w = ohi.y;
+      aq.x = qlo.x; aq.y = qlo.y; aq.z = qhi.x; aq.w = qhi.y;
+      dv[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&ao, bp, dv[m], 0, 0, 0);
+      dk[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&aq, bs, dk[m], 0, 0, 0);
+    }
+  }
+  if (kv) {
+    u16* DK = (u16*)p.dk + (size_t)(b * Lk + key) * p.ldk + h * HD + 4 * g;
+    u16* DV = (u16*)p.dv + (size_t)(b * Lk + key) * p.ldv + h * HD + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      bf16x4 wk, wv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        wk[r] = (__bf16)(dk[m][r] * p.scale);
+        wv[r] = (__bf16)dv[m][r];
+      }
+      *(bf16x4*)(DK + m * 16) = wk;
+      *(bf16x4*)(DV + m * 16) = wv;
+    }
+  }
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool mfma_path_ok(const MhaParams& p, int dtype, bool bwd, int hd) {
   static const bool off = [] { const char* e = getenv("TD_MHA_VALU"); return e && e[0] == '1'; }();
@@ -625,4 +812,61 @@ extern "C" int td_mha_bwd(const void* q, const void* k, const void* v, const voi
     mha_bwd_dkv_kernel<float, 64><<<gridB, 256, ldsB, st>>>(p);
   } else TD_REQUIRE(false, "td_mha_bwd: bad dtype");
   return check_launch("td_mha_bwd");
+}
+
+// ---- lean entry points: bf16, head dim 32, Lk <= 256; no head-averaged weights (see include/tubedetr_hip.h) ----
+static int lean_check(const MhaParams& p, int dtype, int hd, const char* who) {
+  TD_REQUIRE(dtype == TD_BF16 && hd == HD && p.Lk <= 256 && p.Lq <= 448, "%s: the lean path takes bf16, head dim 32, Lk <= 256, Lq <= 448", who);
+  TD_REQUIRE(((p.ldq | p.ldk | p.ldv | p.ldo) & 7) == 0 && aligned16(p.q) && aligned16(p.k) && aligned16(p.v) && aligned16(p.out) && aligned16(p.stats),
+             "%s: rows must be 16-byte aligned", who);
+  return TD_OK;
+}
+
+extern "C" size_t td_mha_lean_stats_bytes(int B, int H, int Lq) { return (size_t)B * H * Lq * 4 * sizeof(float); }
+
+extern "C" int td_mha_lean_fwd(const void* q, const void* k, const void* v, const uint8_t* key_pad, void* out, float* stats, int B,
+                               int H, int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo, float scale, float dropout_p,
+                               uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream) {
+  TD_REQUIRE(q && k && v && out && stats, "td_mha_lean_fwd: null pointer");
+  MhaParams p;
+  memset(&p, 0, sizeof(p));
+  int rc = fill(p, B, H, Lq, Lk, hd == 32 ? hd : 32, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, dropout_counter, "td_mha_lean_fwd");
+  if (rc) return rc;
+  p.q = q; p.k = k; p.v = v; p.kpm = key_pad; p.out = out; p.stats = stats;
+  rc = lean_check(p, dtype, hd, "td_mha_lean_fwd");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int qt = cdiv(Lq, 16), nw = pick_waves(B * H, qt);
+  dim3 g2(B * H, cdiv(qt, nw));
+  if (Lk <= 64) mha_fwd_mfma_kernel<4, true><<<g2, 64 * nw, 0, st>>>(p);
+  else if (Lk <= 128) mha_fwd_mfma_kernel<8, true><<<g2, 64 * nw, 0, st>>>(p);
+  else if (Lk <= 160) mha_fwd_mfma_kernel<10, true><<<g2, 64 * nw, 0, st>>>(p);
+  else mha_fwd_mfma_kernel<16, true><<<g2, 64 * nw, 0, st>>>(p);
+  return check_launch("td_mha_lean_fwd");
+}
+
+extern "C" int td_mha_lean_bwd(const void* q, const void* k, const void* v, const uint8_t* key_pad, const void* out, const void* dout,
+                               float* stats, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk,
+                               int ldv, int ldo, float scale, float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter,
+                               int dtype, td_stream_t stream) {
+  TD_REQUIRE(q && k && v && out && dout && stats && dq && dk && dv, "td_mha_lean_bwd: null pointer");
+  MhaParams p;
+  memset(&p, 0, sizeof(p));
+  int rc = fill(p, B, H, Lq, Lk, hd == 32 ? hd : 32, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, dropout_counter, "td_mha_lean_bwd");
+  if (rc) return rc;
+  p.q = q; p.k = k; p.v = v; p.kpm = key_pad; p.out = (void*)out; p.dout = dout; p.stats = stats; p.dq = dq; p.dk = dk; p.dv = dv;
+  rc = lean_check(p, dtype, hd, "td_mha_lean_bwd");
+  if (rc) return rc;
+  TD_REQUIRE(aligned16(dout), "td_mha_lean_bwd: rows must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int qt = cdiv(Lq, 16), nwq = pick_waves(B * H, qt);
+  dim3 gA(B * H, cdiv(qt, nwq));
+  if (Lk <= 64) mha_bwd_dq_lean_kernel<4><<<gA, 64 * nwq, 0, st>>>(p);
+  else if (Lk <= 128) mha_bwd_dq_lean_kernel<8><<<gA, 64 * nwq, 0, st>>>(p);
+  else if (Lk <= 160) mha_bwd_dq_lean_kernel<10><<<gA, 64 * nwq, 0, st>>>(p);
+  else mha_bwd_dq_lean_kernel<16><<<gA, 64 * nwq, 0, st>>>(p);
+  const int ktl = cdiv(Lk, 16), nwk = pick_waves(B * H, ktl);
+  const int QP = cdiv(Lq, 32) * 32, QS = QP + 8;
+  mha_bwd_dkv_lean_kernel<<<dim3(B * H, cdiv(ktl, nwk)), 64 * nwk, (size_t)2 * 32 * QS * sizeof(u16) + (size_t)QP * sizeof(float4), st>>>(p);
+  return check_launch("td_mha_lean_bwd");
 }

@@ -420,10 +420,17 @@ class MHAFn(Function):
         wv_f, wv_d, _, _ = prepared(W_in[2 * E :], dt)
         v = ops.linear_fwd(v_in, wv_f, bi[2 * E :]).view(B, Lk, E)
         scale = 1.0 / math.sqrt(E // H)
-        ctxv, probs, wavg = ops.mha_fwd(q, k, v, key_pad, H, scale, need_wavg=need_w, dropout_p=p_attn, seed=seed_attn)
+        lean = not need_w and ops.mha_lean_ok(q, k, v, H)  # nobody reads the weights: nothing of size Lq x Lk is stored
+        if lean:
+            ctxv, probs, kp = ops.mha_lean_fwd(q, k, v, key_pad, H, scale, dropout_p=p_attn, seed=seed_attn)  # probs := row statistics
+            wavg = None
+        else:
+            ctxv, probs, wavg = ops.mha_fwd(q, k, v, key_pad, H, scale, need_wavg=need_w, dropout_p=p_attn, seed=seed_attn)
+            kp = None
         wo_f, wo_d, _, _ = prepared(W_out, dt)
         out = ops.linear_fwd(ctxv.view(B * Lq, E), wo_f, b_out.detach(), dropout_p=p_out, seed=seed_out)
         ctx.save_for_backward(q_in, k_in, v_in, q, k, v, probs, ctxv, wv_d, wo_d, *wd_list)
+        ctx.lean, ctx.kp = lean, kp
         ctx.cfg = (B, Lq, Lk, H, E, same_qk, scale, p_attn, seed_attn, p_out, seed_out)
         ctx.params = (W_in, b_in, W_out, b_out)
         return out, (wavg if need_w else None)
@@ -453,7 +460,10 @@ class MHAFn(Function):
             dk = torch.empty((B, Lk, E), dtype=dt, device=dev)
         dv = torch.empty((B, Lk, E), dtype=dt, device=dev)
         dwa = dwavg.contiguous().float() if dwavg is not None else None
-        ops.mha_bwd(q, k, v, dctx, probs, dwa, H, scale, dq, dk, dv, dropout_p=p_attn, seed=seed_attn)
+        if ctx.lean:
+            ops.mha_lean_bwd(q, k, v, ctx.kp, ctxv, dctx, probs, H, scale, dq, dk, dv, dropout_p=p_attn, seed=seed_attn)
+        else:
+            ops.mha_bwd(q, k, v, dctx, probs, dwa, H, scale, dq, dk, dv, dropout_p=p_attn, seed=seed_attn)
         dv2 = dv.view(B * Lk, E)
         _wgrad(dv2, v_in, defer, want_bias=True, out=dW_in[2 * E :], dbias=db_in[2 * E :])
         d_v_in = ops.linear_fwd(dv2, wv_d) if ctx.needs_input_grad[2] else None

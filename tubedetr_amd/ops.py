@@ -6,6 +6,8 @@ throughput mode).  There is no CPU path: CPU tensors raise.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Optional, Tuple
 
@@ -389,6 +391,44 @@ def mha_fwd(q: Tensor, k: Tensor, v: Tensor, key_pad: Optional[Tensor], H: int, 
                                 v.stride(1), E, scale, dropout_p, seed & 0xFFFFFFFF, _ctr() if dropout_p > 0 else None, dtype_code(q.dtype), stream_ptr()),
           "td_mha_fwd")
     return out, probs, wavg
+
+
+def mha_lean_ok(q: Tensor, k: Tensor, v: Tensor, H: int) -> bool:
+    """Can td_mha_lean_* take these projected rows?  (bf16, head dim 32, Lk <= 256, Lq <= 448, 16-byte aligned rows)"""
+    if os.environ.get("TD_MHA_LEAN", "1") == "0":
+        return False
+    E = q.shape[2]
+    return (q.dtype == torch.bfloat16 and E // H == 32 and k.shape[1] <= 256 and q.shape[1] <= 448
+            and all(t_.stride(1) % 8 == 0 and t_.data_ptr() % 16 == 0 for t_ in (q, k, v)))
+
+
+def mha_lean_fwd(q: Tensor, k: Tensor, v: Tensor, key_pad: Optional[Tensor], H: int, scale: float, *, dropout_p: float = 0.0, seed: int = 0):
+    """Attention core without the weights: -> (out [B,Lq,E], stats [B*H*Lq, 4] fp32, key_pad uint8 or None) - what
+    mha_lean_bwd needs besides q, k, v and the output."""
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    for t_ in (q, k, v):
+        assert t_.stride(2) == 1 and t_.stride(0) == t_.shape[1] * t_.stride(1)
+    out = torch.empty((B, Lq, E), dtype=q.dtype, device=q.device)
+    stats = torch.empty((B * H * Lq, 4), dtype=torch.float32, device=q.device)
+    kp = key_pad.to(torch.uint8).contiguous() if key_pad is not None else None
+    check(_hip.lib().td_mha_lean_fwd(ptr(q), ptr(k), ptr(v), ptr(kp), ptr(out), ptr(stats), B, H, Lq, Lk, E // H, q.stride(1), k.stride(1), v.stride(1), E,
+                                     scale, dropout_p, seed & 0xFFFFFFFF, _ctr() if dropout_p > 0 else None, dtype_code(q.dtype), stream_ptr()),
+          "td_mha_lean_fwd")
+    return out, stats, kp
+
+
+def mha_lean_bwd(q: Tensor, k: Tensor, v: Tensor, kp: Optional[Tensor], out: Tensor, dout: Tensor, stats: Tensor, H: int, scale: float,
+                 dq: Tensor, dk: Tensor, dv: Tensor, *, dropout_p: float = 0.0, seed: int = 0):
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    assert dout.is_contiguous() and out.is_contiguous()
+    for a, b in ((q, dq), (k, dk), (v, dv)):
+        assert a.stride() == b.stride() and a.shape == b.shape
+    check(_hip.lib().td_mha_lean_bwd(ptr(q), ptr(k), ptr(v), ptr(kp), ptr(out), ptr(dout), ptr(stats), ptr(dq), ptr(dk), ptr(dv), B, H, Lq, Lk, E // H,
+                                     q.stride(1), k.stride(1), v.stride(1), E, scale, dropout_p, seed & 0xFFFFFFFF, _ctr() if dropout_p > 0 else None,
+                                     dtype_code(q.dtype), stream_ptr()), "td_mha_lean_bwd")
+    return dq, dk, dv
 
 
 def mha_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, probs: Tensor, dwavg: Optional[Tensor], H: int, scale: float,
