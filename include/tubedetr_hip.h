@@ -75,6 +75,9 @@ typedef struct td_conv_desc {
   int ldc;    /* leading dimension (elements) of the output / residual / mask rows */
   int out_sp; /* 1 = dense rows; >1 = row (n,ho,wo) is written at (n, ho*out_sp, wo*out_sp) of an */
   int out_H, out_W; /*        [N][out_H][out_W][ldc] tensor (strided 1x1 dgrad scatter)           */
+  int aniso;            /* 1: `stride` / `pad` describe the vertical direction only, the horizontal one uses the two fields  */
+  int stride_w, pad_w;  /*    below (forward geometry only).  The pixel-pair form of the stem: a 7x7 stride-2 convolution of */
+                        /*    3-channel pixels = a 7x4 convolution, stride (2,1), pad (3,2), of 8-channel pixel PAIRS        */
 } td_conv_desc;
 
 /* Fused epilogue: v = acc (+ bias[n]) (+ residual[m][n]); relu; sigmoid; mask (v if mask_src>0 else 0);
@@ -137,7 +140,7 @@ int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, void* t
 /* Input frames of the trunk: one or more sources of NCHW frames - fp32 (the reference's normalised samples.tensors /
  * samples_fast.tensors, engine.py:55-57) or uint8 pixels (normalised here: (x/255 - mean[c]) * inv_std[c], the
  * datasets' T.Normalize done on the device, so the host sends a quarter of the bytes) - concatenated in order into one
- * NHWC T tensor with channels zero-padded to Cpad (8 bf16 / 4 fp32).  `index` (device int32[n], may be NULL) picks the
+ * NHWC T tensor with channels zero-padded to Cpad (8 or 4 for bf16, 4 for fp32).  `index` (device int32[n], may be NULL) picks the
  * source frame of every contributed frame: the slow clip is video[::k] of the SAME buffer as the fast frames
  * (datasets/vidstg.py:250-251) - no second copy of the pixels, no concatenation.  mean / inv_std: host arrays of C floats
  * or NULL (no normalisation). */
@@ -161,7 +164,13 @@ size_t td_resnet_fwd_ws_bytes(int N, int H, int W, const int* nblocks, int dtype
 int td_resnet_num_convs(const int* nblocks);
 int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const float* mean, const float* inv_std, int N, int H, int W,
                   const int* nblocks, const void* const* w_fwd, const float* const* bias, int save, void* ws, size_t ws_bytes,
-                  void** feat, int* feat_hw, int dtype, td_stream_t stream);
+                  void** feat, int* feat_hw, int stem_pairs, int dtype, td_stream_t stream);
+/* stem_pairs = 1 (bf16, even W): the stem runs in its pixel-pair form - the frames are laid down with 4 channels per
+ * pixel (3 + one zero), two horizontally adjacent pixels form one 8-channel element, and the 7x7 stride-2 convolution
+ * becomes a 7x4 convolution with stride (2, 1) and padding (3, 2) over them: K = 224 instead of 392 (3 channels padded to 8),
+ * half the input bytes.  w_fwd[0] must then be the [64][7][4][8] weight td_stem_pair_weights derives from the prepared
+ * [64][7][7][8] one. */
+int td_stem_pair_weights(const void* w_fwd_8, void* w_pairs, int Co, int dtype, td_stream_t stream);
 /* Backward through the stages >= first_train_stage (0..3; the reference trains layer2-4 = 1, backbone.py:82-89):
  * dfeat = gradient of *feat; fwd_ws = the save=1 workspace of the forward; dW[i] receives the gradient of conv i in
  * the parameter's own [Co][Ci][R][S] fp32 layout (FrozenBN scale un-folded); entries of frozen convs are ignored.

@@ -148,6 +148,49 @@ def test_conv_wgrad_batch_wide_tiles():
 
 
 @pytest.mark.parametrize("dt", DT)
+def test_anisotropic_stride_and_padding(dt):
+    """Forward geometry with different vertical / horizontal stride and padding (td_conv_desc.aniso), generic kernel path."""
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(51)
+    N, Ci, H, W, Co = 3, 8, 21, 17, 64
+    x = rnd((N, Ci, H, W), g, dt)
+    w = rnd((Co, Ci, 7, 4), g, dt, 0.1)
+    bias = torch.randn(Co, generator=g)
+    ref = F.relu(F.conv2d(x, w, bias, stride=(2, 1), padding=(3, 2)))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wf = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().to(dev(), dt)  # [Co][R][S][C], K contiguous
+    y = torch.empty((N, Ho, Wo, Co), dtype=dt, device=dev())
+    ops.conv_gemm_raw(nhwc(x, dt), wf, y, ops._desc(N, H, W, Ci, Ho, Wo, 7, 4, 2, 3, 0, Co, Co, stride_w=1, pad_w=2), ops._epi(bias.to(dev()), None, None, True))
+    assert rel_err(from_nhwc(y), ref) < TOL[dt]
+
+
+def test_stem_pixel_pair_form_equals_the_7x7_convolution():
+    """td_resnet_fwd's stem_pairs layout: 4-channel bf16 pixels taken two at a time + td_stem_pair_weights + a 7x4 stride-(2,1)
+    pad-(3,2) convolution == the 7x7 stride-2 pad-3 convolution of the 3-channel frames (bias + ReLU), incl. the image borders."""
+    import ctypes as C
+    from tubedetr_amd import _hip, ops
+
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(53)
+    N, H, W, Co = 3, 46, 60, 64
+    x = rnd((N, 3, H, W), g, dt)
+    w = rnd((Co, 3, 7, 7), g, dt, 0.1)
+    bias = torch.randn(Co, generator=g)
+    ref = F.relu(F.conv2d(x, w, bias, stride=2, padding=3))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wf8, _, b_out, _ = ops.weight_prep(w.to(dev()), dt, bias=bias.to(dev()), need_dgrad=False, cpad=8)
+    wp = torch.empty((Co, 7 * 4 * 8), dtype=dt, device=dev())
+    _hip.check(_hip.lib().td_stem_pair_weights(wf8.data_ptr(), wp.data_ptr(), Co, _hip.TD_BF16, _hip.stream_ptr()), "td_stem_pair_weights")
+    x4 = ops.nchw_to_nhwc(x.to(dev()), dt, 4)  # [N, H, W, 4] == [N, H, W/2, 8]
+    y = torch.empty((N, Ho, Wo, Co), dtype=dt, device=dev())
+    ops.conv_gemm_raw(x4.view(N, H, W // 2, 8), wp, y, ops._desc(N, H, W // 2, 8, Ho, Wo, 7, 4, 2, 3, 0, Co, Co, stride_w=1, pad_w=2), ops._epi(b_out, None, None, True))
+    assert rel_err(from_nhwc(y), ref) < TOL[dt]
+    y8 = ops.conv_fwd(ops.nchw_to_nhwc(x.to(dev()), dt, 8), wf8, b_out, 7, 7, 2, 3, relu=True)
+    assert rel_err(y, y8) < 4e-3  # same products, different summation order
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_frozen_bn_fold_and_mask_epilogues(dt):
     from tubedetr_amd import ops
 

@@ -17,7 +17,8 @@ _lib = None
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("N", "Hs", "Ws", "C", "Ho", "Wo", "R", "S", "stride", "pad", "mode", "Nc", "ldc", "out_sp", "out_H", "out_W")]
+    _fields_ = [(n, C.c_int) for n in ("N", "Hs", "Ws", "C", "Ho", "Wo", "R", "S", "stride", "pad", "mode", "Nc", "ldc", "out_sp", "out_H", "out_W",
+                                       "aniso", "stride_w", "pad_w")]
 
 
 class PrepItem(C.Structure):
@@ -70,7 +71,8 @@ _SIGS = {
     "td_conv_wgrad_batch": [C.POINTER(WgradJob), _I, _I, _P, _P, _SZ, _P],
     "td_resnet_num_convs": [C.POINTER(C.c_int)],
     "td_resnet_fwd": [C.POINTER(FrameSource), _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ,
-                      C.POINTER(_P), C.POINTER(C.c_int), _I, _P],
+                      C.POINTER(_P), C.POINTER(C.c_int), _I, _I, _P],
+    "td_stem_pair_weights": [_P, _P, _I, _I, _P],
     "td_frames_to_nhwc": [C.POINTER(FrameSource), _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P],
     "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _P, _P, _SZ, _I, _P],
     "td_weight_prep_batch": [_P, _I, _I, _I, _P],

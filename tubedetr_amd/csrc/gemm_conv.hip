@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm
       a_img[i] = n * d.Hs * d.Ws;
       if (d.mode == 0) {
         a_hb[i] = ho * d.stride - d.pad;
-        a_wb[i] = wo * d.stride - d.pad;
+        a_wb[i] = d.aniso ? wo * d.stride_w - d.pad_w : wo * d.stride - d.pad;  // (aniso: forward geometry of the generic path only)
       } else {
         a_hb[i] = ho + d.pad;
         a_wb[i] = wo + d.pad;
@@ -1505,6 +1505,7 @@ static int validate(const td_conv_desc* d, int dtype, const char* who) {
   TD_REQUIRE(d->N > 0 && d->Hs > 0 && d->Ws > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0 && d->stride > 0,
              "%s: bad geometry", who);
   TD_REQUIRE((double)d->N * d->Hs * d->Ws * d->C < 2147483647.0, "%s: source tensor exceeds 2^31 elements", who);
+  TD_REQUIRE(!d->aniso || (d->mode == 0 && d->stride_w >= 1 && d->pad_w >= 0 && d->out_sp <= 1), "%s: anisotropic stride / padding is a forward-only geometry", who);
   return TD_OK;
 }
 
@@ -1617,7 +1618,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   // tap-uniform addressing (see conv_gemm_kernel): spatial convs whose channel count is a multiple of the K tile
   static const int tu_on = [] { const char* e_ = getenv("TD_CONV_TAP_UNIFORM"); return e_ ? atoi(e_) : 1; }();
   const int bk = dtype == TD_BF16 ? 64 : 32;
-  const bool tu = tu_on && !pw && d->R * d->S > 1 && d->R * d->S <= 32 && d->C % bk == 0 && p.d.out_sp == 1 && (d->mode == 0 || d->stride == 1);
+  const bool tu = tu_on && !pw && !d->aniso && d->R * d->S > 1 && d->R * d->S <= 32 && d->C % bk == 0 && p.d.out_sp == 1 && (d->mode == 0 || d->stride == 1);
   {
     // 256-row tiles (conv_gemm_big_kernel): MFMA-bound bf16 layers with enough workgroups to matter
     static const int big_on = [] { const char* e_ = getenv("TD_CONV_BIG"); return e_ ? atoi(e_) : 1; }();
@@ -1693,7 +1694,7 @@ static int wgrad_fill(WgradParams& p, const void* g, const void* src, const td_c
   int rc = validate(d, dtype, who);
   if (rc) return rc;
   const int vec = dtype == TD_BF16 ? 8 : 4;
-  TD_REQUIRE(d->mode == 0, "%s: forward geometry expected", who);
+  TD_REQUIRE(d->mode == 0 && !d->aniso, "%s: isotropic forward geometry expected", who);
   TD_REQUIRE(d->Nc % vec == 0 && ldg % vec == 0, "%s: Nc=%d / ldg=%d must be multiples of %d", who, d->Nc, ldg, vec);
   memset(&p, 0, sizeof(p));
   p.g = (const char*)g;

@@ -183,8 +183,13 @@ __global__ __launch_bounds__(256) void frames_to_nhwc_kernel(const S* __restrict
     v[c] = 0.f;
     if (c < C) v[c] = ((float)x[(src * C + c) * hw + p] * nm.in_scale - nm.mean[c]) * nm.inv_std[c];
   }
-  if constexpr (sizeof(T) == 2) {
-    static_assert(CP == 8, "bf16 rows are padded to 8 channels");
+  if constexpr (sizeof(T) == 2 && CP == 4) {  // 4-channel bf16 pixels: the pixel-pair form of the stem (td_resnet_fwd stem_pairs)
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    ((uint2*)y)[idx] = o;
+  } else if constexpr (sizeof(T) == 2) {
+    static_assert(CP == 8, "bf16 rows are padded to 8 (or 4) channels");
     uint4 o;
     o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
     o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
@@ -277,8 +282,7 @@ extern "C" int td_frames_to_nhwc(const td_frame_source* srcs, int n_srcs, int C,
                                  const float* inv_std, void* y, int dtype, td_stream_t stream) {
   TD_REQUIRE(srcs && n_srcs >= 1 && y, "td_frames_to_nhwc: bad arguments");
   TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "td_frames_to_nhwc: bad dtype");
-  TD_REQUIRE(C >= 1 && C <= 4 && Cpad == (dtype == TD_BF16 ? 8 : 4), "td_frames_to_nhwc: C must be 1..4 and Cpad the vector width of the dtype (%d)",
-             dtype == TD_BF16 ? 8 : 4);
+  TD_REQUIRE(C >= 1 && C <= 4 && (Cpad == 4 || (Cpad == 8 && dtype == TD_BF16)), "td_frames_to_nhwc: C must be 1..4 and Cpad 4 (or 8 for bf16)");
   hipStream_t st = (hipStream_t)stream;
   const size_t es = dtype == TD_BF16 ? 2 : 4;
   size_t done = 0;
@@ -296,7 +300,10 @@ extern "C" int td_frames_to_nhwc(const td_frame_source* srcs, int n_srcs, int C,
     const size_t n = (size_t)f.n * H * W;
     char* out = (char*)y + done * (size_t)H * W * Cpad * es;
     const unsigned g = nblk(n);
-    if (dtype == TD_BF16) {
+    if (dtype == TD_BF16 && Cpad == 4) {
+      if (f.dtype == TD_U8) frames_to_nhwc_kernel<u16, uint8_t, 4><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
+      else frames_to_nhwc_kernel<u16, float, 4><<<g, 256, 0, st>>>((const float*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
+    } else if (dtype == TD_BF16) {
       if (f.dtype == TD_U8) frames_to_nhwc_kernel<u16, uint8_t, 8><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
       else frames_to_nhwc_kernel<u16, float, 8><<<g, 256, 0, st>>>((const float*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
     } else {
@@ -311,7 +318,7 @@ extern "C" int td_frames_to_nhwc(const td_frame_source* srcs, int n_srcs, int C,
 extern "C" int td_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype,
                                td_stream_t stream) {
   TD_REQUIRE(x && y && Cpad >= C, "td_nchw_to_nhwc: bad arguments");
-  if (C <= 4 && Cpad == (dtype == TD_BF16 ? 8 : 4)) {
+  if (C <= 4 && (Cpad == 4 || (Cpad == 8 && dtype == TD_BF16))) {
     td_frame_source f = {x, TD_F32, N, nullptr};
     return td_frames_to_nhwc(&f, 1, C, H, W, Cpad, nullptr, nullptr, y, dtype, stream);
   }
@@ -343,4 +350,26 @@ extern "C" int td_cast(const void* x, void* y, size_t n, int src_dtype, int dst_
   else if (src_dtype == TD_BF16 && dst_dtype == TD_BF16) cast_kernel<u16, u16><<<g, 256, 0, st>>>((const u16*)x, (u16*)y, n);
   else TD_REQUIRE(false, "td_cast: bad dtype");
   return check_launch("td_cast");
+}
+
+
+// Pixel-pair stem weights (td_resnet_fwd, stem_pairs): prepared [Co][7][7][8] (3 real channels, K contiguous) ->
+// [Co][7][4][8]: element (r, t, sub*4 + c) = w[r][s = 2t + sub - 1][c] for c < 3 and s >= 0, else 0.
+template <typename T>
+__global__ void stem_pair_weights_kernel(const T* __restrict__ w8, T* __restrict__ wp, int Co) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Co * 7 * 4 * 8) return;
+  const int j = idx & 7, t = (idx >> 3) & 3, r = (idx >> 5) % 7, co = idx / (7 * 32);
+  const int sub = j >> 2, c = j & 3, s_ = 2 * t + sub - 1;
+  T v = T(0);
+  if (s_ >= 0 && c < 3) v = w8[((co * 7 + r) * 7 + s_) * 8 + c];
+  wp[idx] = v;
+}
+
+extern "C" int td_stem_pair_weights(const void* w_fwd_8, void* w_pairs, int Co, int dtype, td_stream_t stream) {
+  TD_REQUIRE(w_fwd_8 && w_pairs && Co >= 1, "td_stem_pair_weights: bad arguments");
+  TD_REQUIRE(dtype == TD_BF16, "td_stem_pair_weights: the pixel-pair stem is a bf16 layout");
+  const int n = Co * 7 * 4 * 8;
+  stem_pair_weights_kernel<u16><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>((const u16*)w_fwd_8, (u16*)w_pairs, Co);
+  return check_launch("td_stem_pair_weights");
 }

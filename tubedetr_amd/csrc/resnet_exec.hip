@@ -137,7 +137,7 @@ extern "C" int td_resnet_num_convs(const int* nblocks) {
 
 extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const float* mean, const float* inv_std, int N, int H, int W,
                              const int* nblocks, const void* const* w_fwd, const float* const* bias, int save, void* ws,
-                             size_t ws_bytes, void** feat, int* feat_hw, int dtype, td_stream_t stream) {
+                             size_t ws_bytes, void** feat, int* feat_hw, int stem_pairs, int dtype, td_stream_t stream) {
   TD_REQUIRE(srcs && n_srcs >= 1 && nblocks && w_fwd && bias && ws && feat, "td_resnet_fwd: null pointer");
   TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "td_resnet_fwd: bad dtype");
   {
@@ -148,9 +148,23 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   Plan P = make_plan(N, H, W, nblocks, dtype, save);
   TD_REQUIRE(ws_bytes >= P.total, "td_resnet_fwd: workspace too small (%zu < %zu)", ws_bytes, P.total);
   char* base = (char*)ws;
-  int rc = td_frames_to_nhwc(srcs, n_srcs, 3, H, W, P.x.C, mean, inv_std, base + P.x.off, dtype, stream);
-  if (rc) return rc;
-  rc = run_conv(base, P.x, P.stem, N, P.convs[0], w_fwd[0], bias[0], nullptr, 1, dtype, stream);
+  int rc;
+  if (stem_pairs) {
+    // pixel-pair stem (see tubedetr_hip.h): 4-channel pixels in the first half of x's region = [H][W/2] elements of 8 channels
+    TD_REQUIRE(dtype == TD_BF16 && (W & 1) == 0, "td_resnet_fwd: the pixel-pair stem needs bf16 and an even frame width");
+    rc = td_frames_to_nhwc(srcs, n_srcs, 3, H, W, 4, mean, inv_std, base + P.x.off, dtype, stream);
+    if (rc) return rc;
+    td_conv_desc d = {N, H, W / 2, 8, P.stem.H, P.stem.W, 7, 4, 2, 3, 0, 64, 64, 1, 0, 0, 1, 1, 2};
+    td_epilogue e;
+    memset(&e, 0, sizeof(e));
+    e.bias = bias[0];
+    e.relu = 1;
+    rc = td_conv_gemm(base + P.x.off, w_fwd[0], base + P.stem.off, &d, &e, dtype, stream);
+  } else {
+    rc = td_frames_to_nhwc(srcs, n_srcs, 3, H, W, P.x.C, mean, inv_std, base + P.x.off, dtype, stream);
+    if (rc) return rc;
+    rc = run_conv(base, P.x, P.stem, N, P.convs[0], w_fwd[0], bias[0], nullptr, 1, dtype, stream);
+  }
   if (rc) return rc;
   rc = td_maxpool3x3s2(base + P.stem.off, base + P.pool.off, N, P.stem.H, P.stem.W, 64, dtype, stream);
   if (rc) return rc;

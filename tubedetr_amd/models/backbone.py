@@ -15,6 +15,8 @@ implicit-GEMM HIP kernels directly on NHWC activations:
 """
 from __future__ import annotations
 
+import os
+
 from collections import OrderedDict
 from typing import List
 
@@ -191,8 +193,15 @@ class ResNetTrunkFn(Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         feat_p = C.c_void_p()
         hw = (C.c_int * 3)()
-        _hip.check(L.td_resnet_fwd(srcs, len(x.parts), mean, inv_std, N, H, W, nb, _ptr_array([p[0] for p in preps]), _ptr_array([p[2] for p in preps]),
-                                   save, ws.data_ptr(), nbytes, C.byref(feat_p), hw, code, _hip.stream_ptr()), "td_resnet_fwd")
+        w_ptrs = [p[0] for p in preps]
+        # pixel-pair stem (include/tubedetr_hip.h): bf16, even width, frozen stem (its weight gradient would need the 8-channel frames)
+        pairs = dt == torch.bfloat16 and W % 2 == 0 and not convs[0][0].weight.requires_grad and os.environ.get("TD_STEM_PAIRS", "1") != "0"
+        if pairs:
+            w_pairs = torch.empty((preps[0][0].shape[0], 7 * 4 * 8), dtype=dt, device=x.device)
+            _hip.check(L.td_stem_pair_weights(preps[0][0].data_ptr(), w_pairs.data_ptr(), w_pairs.shape[0], code, _hip.stream_ptr()), "td_stem_pair_weights")
+            w_ptrs = [w_pairs] + w_ptrs[1:]
+        _hip.check(L.td_resnet_fwd(srcs, len(x.parts), mean, inv_std, N, H, W, nb, _ptr_array(w_ptrs), _ptr_array([p[2] for p in preps]),
+                                   save, ws.data_ptr(), nbytes, C.byref(feat_p), hw, int(pairs), code, _hip.stream_ptr()), "td_resnet_fwd")
         off = feat_p.value - ws.data_ptr()
         n_el = N * hw[0] * hw[1] * hw[2]
         feat = ws[off : off + n_el * dt.itemsize].view(dt).view(N, hw[0], hw[1], hw[2])

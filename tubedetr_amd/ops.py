@@ -75,8 +75,11 @@ def conv_out(h: int, k: int, stride: int, pad: int) -> int:
     return (h + 2 * pad - k) // stride + 1
 
 
-def _desc(N, Hs, Ws, Cs, Ho, Wo, R, S, stride, pad, mode, Nc, ldc, out_sp=1, out_H=0, out_W=0) -> ConvDesc:
-    return ConvDesc(N, Hs, Ws, Cs, Ho, Wo, R, S, stride, pad, mode, Nc, ldc, out_sp, out_H, out_W)
+def _desc(N, Hs, Ws, Cs, Ho, Wo, R, S, stride, pad, mode, Nc, ldc, out_sp=1, out_H=0, out_W=0, stride_w=None, pad_w=None) -> ConvDesc:
+    if stride_w is None and pad_w is None:
+        return ConvDesc(N, Hs, Ws, Cs, Ho, Wo, R, S, stride, pad, mode, Nc, ldc, out_sp, out_H, out_W)
+    return ConvDesc(N, Hs, Ws, Cs, Ho, Wo, R, S, stride, pad, mode, Nc, ldc, out_sp, out_H, out_W, 1, stride if stride_w is None else stride_w,
+                    pad if pad_w is None else pad_w)  # (stride, pad) vertical, (stride_w, pad_w) horizontal: forward geometry only
 
 
 _DROPOUT_COUNTER = [None]  # device uint32/int32 tensor or None
