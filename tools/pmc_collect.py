@@ -99,7 +99,7 @@ def mfma(src, dst, command=""):
     # kernels are separable by name; the K/V projections run on the shared GEMM kernel, so the group is reported as the
     # attention kernels alone and as attention + the 64x128 GEMM family that carries the projections (an upper bound on
     # the group's launches: the family also holds the encoder / decoder linears).
-    att = [f for f in per if "mha_" in f and "mfma" in f]
+    att = [f for f in per if "mha_" in f and ("mfma" in f or "lean" in f)]  # MFMA attention kernels (probs-based and lean)
     g = util(att)
     if g:
         res["decoder_attention_group"] = {"attention_kernels": g, "target": 0.40,
