@@ -206,7 +206,7 @@ def main():
 
         argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]
         attempts = []
-        for extra in ([], ["--no-text-stream"], ["--no-graph"]):  # forked graph, linear graph, eager launches
+        for extra in ([], ["--no-text-stream"], ["--no-graph"], ["--no-graph", "--clips-per-gpu", "4"]):  # forked graph, linear graph, eager launches, half the batch
             r = subprocess.run(argv + extra, stdout=subprocess.PIPE, text=True)
             line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
             attempts.append({"args": extra, "returncode": r.returncode})
@@ -480,7 +480,8 @@ def main():
         step_tflop = ALGO_TFLOP_PER_CLIP.get(a.workload)
         out = {
             "metric": ("training clips/sec (fwd+bwd) at T=100 k=4 res=352, 1/2/4/8 MI355X" if a.workload == "cfg3" else "training clips/sec (fwd+bwd)"), "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "clips_per_step_per_gpu": B, "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "clips_per_step_per_gpu": B, "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2),
+            "peak_hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "execution": execution,
             "gradient_exchange": (None if not distributed else ("torch DDP (find_unused_parameters)" if a.ddp else
