@@ -484,6 +484,147 @@ class MHAFn(Function):
         return (d_q_in, d_k_in, d_v_in, dW_in, db_in, dW_out, db_out) + (None,) * 10
 
 
+class _CrossKVShared:
+    """Side channel between CrossKVFn and the six cross-attention nodes that consume its output: the key / value gradients of
+    all layers land in ONE [rows, layers * E] buffer each (every layer's attention backward writes its own column block),
+    so the engine has nothing to accumulate and the hoisted node turns them into d(memory) with one GEMM."""
+
+    def __init__(self, mem_k, mem_v, n_layers, E):
+        self.mem_k, self.mem_v, self.n_layers, self.E = mem_k, mem_v, n_layers, E
+        self.dK = self.dV = None
+        self.written = set()
+        self.wk_d = self.wv_d = None  # concatenated input-gradient weights [E, layers * E]
+
+    def grads(self, like):
+        if self.dK is None:
+            self.dK = torch.empty((self.mem_k.shape[0], self.n_layers * self.E), dtype=like.dtype, device=like.device)
+            self.dV = torch.empty_like(self.dK)
+        return self.dK, self.dV
+
+
+class CrossKVFn(Function):
+    """The key and value projections of ALL decoder layers' time-aligned cross-attention in two GEMMs (the memory is the same
+    for the six layers, transformer.py:734-740): K_all = mem_k [W_k,0 | ... | W_k,5]^T + b, V_all likewise, [rows, layers * E].
+    The parameters stay with their layers (each layer's node returns the gradient of its whole in_proj); this node only owns
+    d(mem_k), d(mem_v): one GEMM each over the column-concatenated gradients (K = layers * E) instead of 2 x layers GEMMs whose
+    results the autograd engine would sum with 2 x (layers - 1) elementwise launches."""
+
+    @staticmethod
+    def forward(ctx, mem_k, mem_v, shared, *w_and_b):
+        E, dt = shared.E, mem_k.dtype
+        Ws, bs = w_and_b[0::2], w_and_b[1::2]
+        kf, vf, kd, vd = [], [], [], []
+        for W in Ws:
+            f, d_, _, _ = prepared(W[E : 2 * E], dt)
+            kf.append(f); kd.append(d_)
+            f, d_, _, _ = prepared(W[2 * E :], dt)
+            vf.append(f); vd.append(d_)
+        bk = torch.cat([b.detach()[E : 2 * E] for b in bs])
+        bv = torch.cat([b.detach()[2 * E :] for b in bs])
+        K_all = ops.linear_fwd(mem_k, torch.cat(kf, dim=0), bk)
+        V_all = ops.linear_fwd(mem_v, torch.cat(vf, dim=0), bv)
+        shared.wk_d, shared.wv_d = torch.cat(kd, dim=1), torch.cat(vd, dim=1)
+        ctx.shared = shared
+        ctx.set_materialize_grads(False)
+        return K_all, V_all
+
+    @staticmethod
+    def backward(ctx, gK, gV):
+        sh = ctx.shared
+        assert gK is None and gV is None, "the consumers of CrossKVFn hand their gradients over through the shared buffers"
+        if sh.dK is None:
+            return (None,) * (3 + 2 * sh.n_layers)
+        for l in range(sh.n_layers):  # a layer outside the loss (never the case in training) contributes nothing
+            if l not in sh.written:
+                sh.dK[:, l * sh.E : (l + 1) * sh.E].zero_()
+                sh.dV[:, l * sh.E : (l + 1) * sh.E].zero_()
+        d_mem_k = ops.linear_fwd(sh.dK, sh.wk_d) if ctx.needs_input_grad[0] else None
+        d_mem_v = ops.linear_fwd(sh.dV, sh.wv_d) if ctx.needs_input_grad[1] else None
+        return (d_mem_k, d_mem_v, None) + (None,) * (2 * sh.n_layers)
+
+
+class MHAPreKVFn(Function):
+    """MHAFn for a layer whose key / value projections were hoisted into CrossKVFn: q projection, attention core on column
+    block ``layer`` of K_all / V_all (read where they lie: row stride layers * E), out projection.  Backward: the attention
+    backward writes dK / dV straight into the shared buffers; the gradient of the layer's whole packed in_proj (q, k and v
+    rows) is produced here, so the parameter has a single owner and its weight gradients stay deferrable."""
+
+    @staticmethod
+    def forward(ctx, q_in, K_all, V_all, W_in, b_in, W_out, b_out, key_pad, shared, layer, B, Lq, Lk, H, need_w, p_attn, seed_attn, p_out, seed_out):
+        _note_use(ctx.needs_input_grad[3], W_in, b_in, W_out, b_out)
+        E = q_in.shape[1]
+        dt = q_in.dtype
+        nl = shared.n_layers
+        wq_f, wq_d, _, _ = prepared(W_in[:E], dt)
+        q = ops.linear_fwd(q_in, wq_f, b_in.detach()[:E]).view(B, Lq, E)
+        k = K_all.view(B, Lk, nl * E)[..., layer * E : (layer + 1) * E]
+        v = V_all.view(B, Lk, nl * E)[..., layer * E : (layer + 1) * E]
+        scale = 1.0 / math.sqrt(E // H)
+        ctxv, probs, wavg = ops.mha_fwd(q, k, v, key_pad, H, scale, need_wavg=need_w, dropout_p=p_attn, seed=seed_attn)
+        wo_f, wo_d, _, _ = prepared(W_out, dt)
+        out = ops.linear_fwd(ctxv.view(B * Lq, E), wo_f, b_out.detach(), dropout_p=p_out, seed=seed_out)
+        ctx.save_for_backward(q_in, q, K_all, V_all, probs, ctxv, wq_d, wo_d)
+        ctx.cfg = (B, Lq, Lk, H, E, scale, p_attn, seed_attn, p_out, seed_out, layer)
+        ctx.params = (W_in, b_in, W_out, b_out)
+        ctx.shared = shared
+        return out, (wavg if need_w else None)
+
+    @staticmethod
+    def backward(ctx, dout, dwavg):
+        _arm()
+        q_in, q, K_all, V_all, probs, ctxv, wq_d, wo_d = ctx.saved_tensors
+        B, Lq, Lk, H, E, scale, p_attn, seed_attn, p_out, seed_out, layer = ctx.cfg
+        sh = ctx.shared
+        nl = sh.n_layers
+        dt, dev = q_in.dtype, q_in.device
+        defer = _can_defer(*ctx.params)
+        g = ops.dropout(dout.contiguous(), p_out, seed_out) if p_out > 0 else dout.contiguous()
+        if defer:
+            dW_in = torch.empty((3 * E, E), dtype=torch.float32, device=dev)
+            db_in = torch.empty(3 * E, dtype=torch.float32, device=dev)
+        else:
+            dW_in = ops.zeros_f32((3 * E, E), dev)
+            db_in = ops.zeros_f32(3 * E, dev)
+        dW_out, db_out = _wgrad(g, ctxv.view(B * Lq, E), defer, want_bias=True)
+        dctx = ops.linear_fwd(g, wo_d).view(B, Lq, E)
+        dq = torch.empty((B, Lq, E), dtype=dt, device=dev)
+        dK_all, dV_all = sh.grads(K_all)
+        cols = slice(layer * E, (layer + 1) * E)
+        k = K_all.view(B, Lk, nl * E)[..., cols]
+        v = V_all.view(B, Lk, nl * E)[..., cols]
+        dk = dK_all.view(B, Lk, nl * E)[..., cols]
+        dv = dV_all.view(B, Lk, nl * E)[..., cols]
+        dwa = dwavg.contiguous().float() if dwavg is not None else None
+        ops.mha_bwd(q, k, v, dctx, probs, dwa, H, scale, dq, dk, dv, dropout_p=p_attn, seed=seed_attn)
+        sh.written.add(layer)
+        dq2 = dq.view(B * Lq, E)
+        _wgrad(dq2, q_in, defer, want_bias=True, out=dW_in[:E], dbias=db_in[:E])
+        _wgrad(dK_all[:, cols], sh.mem_k, defer, want_bias=True, out=dW_in[E : 2 * E], dbias=db_in[E : 2 * E])
+        _wgrad(dV_all[:, cols], sh.mem_v, defer, want_bias=True, out=dW_in[2 * E :], dbias=db_in[2 * E :])
+        d_q_in = ops.linear_fwd(dq2, wq_d) if ctx.needs_input_grad[0] else None
+        return (d_q_in, None, None, dW_in, db_in, dW_out, db_out) + (None,) * 12
+
+
+def cross_kv(mem_k, mem_v, attn_modules):
+    """-> (K_all, V_all, shared) for ``multihead_attention_prekv``; attn_modules: the layers' cross-attention parameter holders."""
+    E = attn_modules[0].embed_dim
+    shared = _CrossKVShared(mem_k, mem_v, len(attn_modules), E)
+    flat = []
+    for m in attn_modules:
+        flat += [m.in_proj_weight, m.in_proj_bias]
+    K_all, V_all = CrossKVFn.apply(mem_k, mem_v, shared, *flat)
+    return K_all, V_all, shared
+
+
+def multihead_attention_prekv(q_in, kv, layer, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_weights=False, attn_dropout=0.0,
+                              out_dropout=0.0, training=False):
+    pa = attn_dropout if training else 0.0
+    po = out_dropout if training else 0.0
+    K_all, V_all, shared = kv
+    return MHAPreKVFn.apply(q_in, K_all, V_all, W_in, b_in, W_out, b_out, key_pad, shared, layer, B, Lq, Lk, H, need_weights,
+                            pa, _seed() if pa > 0 else 0, po, _seed() if po > 0 else 0)
+
+
 class AttnCoreFn(Function):
     """softmax(scale q k^T + key padding) v on already projected q, k, v rows ([B*L, E] each, heads in column blocks of
     E // H = 32 or 64) - the attention core alone, for encoders that own their projections (RoBERTa: separate query / key /

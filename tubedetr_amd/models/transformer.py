@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -42,6 +43,11 @@ class MultiheadAttention(nn.Module):
         self.out_proj = nn.Linear(embed_dim, embed_dim)  # holder only (weight, bias)
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def run_prekv(self, q_in, kv, layer, key_pad, B, Lq, Lk, need_weights, out_dropout, training):
+        """Keys / values already projected for all layers (functional.cross_kv): this layer reads column block ``layer``."""
+        return Fk.multihead_attention_prekv(q_in, kv, layer, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight, self.out_proj.bias, key_pad,
+                                            B, Lq, Lk, self.num_heads, need_weights, attn_dropout=self.dropout, out_dropout=out_dropout, training=training)
 
     def run(self, q_in, k_in, v_in, key_pad, B, Lq, Lk, need_weights, out_dropout, training):
         return Fk.multihead_attention(q_in, k_in, v_in, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight,
@@ -102,9 +108,9 @@ class TransformerDecoderLayer(nn.Module):
         self.p = dropout
         self.no_tsa = no_tsa
 
-    def forward(self, tgt, query_pos, mem_k, mem_v, query_mask, memory_mask, b: int, t: int, S: int):
+    def forward(self, tgt, query_pos, mem_k, mem_v, query_mask, memory_mask, b: int, t: int, S: int, kv=None, index: int = 0):
         """tgt/query_pos rows [b*t, d] (video-major frames); mem_k = memory+pos, mem_v = memory rows [b*t*S, d]
-        (transformer.py:684-751)."""
+        (transformer.py:684-751).  kv: the hoisted key / value projections of all layers (TransformerDecoder.forward)."""
         qk = Fk.AddFn.apply(tgt, query_pos)
         if self.no_tsa:  # every frame attends to itself only: sequence length 1 (transformer.py:701-711)
             a, w = self.self_attn.run(qk, None, tgt, None, b * t, 1, 1, True, self.p, self.training)
@@ -112,7 +118,10 @@ class TransformerDecoderLayer(nn.Module):
             a, w = self.self_attn.run(qk, None, tgt, query_mask, b, t, t, True, self.p, self.training)
         tgt = Fk.add_layernorm(a, tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         qc = Fk.AddFn.apply(tgt, query_pos)
-        a, cw = self.cross_attn_image.run(qc, mem_k, mem_v, memory_mask, b * t, 1, S, True, self.p, self.training)
+        if kv is not None:
+            a, cw = self.cross_attn_image.run_prekv(qc, kv, index, memory_mask, b * t, 1, S, True, self.p, self.training)
+        else:
+            a, cw = self.cross_attn_image.run(qc, mem_k, mem_v, memory_mask, b * t, 1, S, True, self.p, self.training)
         tgt = Fk.add_layernorm(a, tgt, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         f = Fk.ffn(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.p, self.training)
         tgt = Fk.add_layernorm(f, tgt, self.norm4.weight, self.norm4.bias, self.norm4.eps)
@@ -131,8 +140,10 @@ class TransformerDecoder(nn.Module):
     def forward(self, tgt, query_pos, mem_k, mem_v, query_mask, memory_mask, b, t, S):
         inter, ws, cws = [], [], []
         out = tgt
-        for layer in self.layers:
-            out, w, cw = layer(out, query_pos, mem_k, mem_v, query_mask, memory_mask, b, t, S)
+        # one key and one value projection GEMM for the six layers' shared memory (functional.CrossKVFn)
+        kv = Fk.cross_kv(mem_k, mem_v, [l.cross_attn_image for l in self.layers]) if os.environ.get("TD_KV_HOIST", "1") != "0" else None
+        for i, layer in enumerate(self.layers):
+            out, w, cw = layer(out, query_pos, mem_k, mem_v, query_mask, memory_mask, b, t, S, kv=kv, index=i)
             if self.return_intermediate:
                 inter.append(Fk.add_layernorm(out, None, self.norm.weight, self.norm.bias, self.norm.eps))
                 ws.append(w)

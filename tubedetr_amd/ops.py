@@ -236,10 +236,10 @@ def linear_wgrad_batch(jobs) -> None:
     for a, (g, x, dw_ptr, db_ptr) in zip(arr, jobs):
         M, K = x.shape
         Nn = g.shape[1]
-        assert g.shape[0] == M and g.is_contiguous() and x.is_contiguous() and g.dtype == x.dtype
+        assert g.shape[0] == M and g.stride(1) == 1 and x.is_contiguous() and g.dtype == x.dtype  # g: rows of stride ldg (a column block is fine)
         a.g, a.src, a.dW, a.scale, a.dbias = g.data_ptr(), x.data_ptr(), dw_ptr, None, db_ptr
         a.d = _desc(1, M, 1, K, M, 1, 1, 1, 1, 0, 0, Nn, Nn)
-        a.ldg, a.ci_real = Nn, K
+        a.ldg, a.ci_real = g.stride(0), K
     nbytes = _hip.lib().td_conv_wgrad_batch_table_bytes(len(jobs))
     dev = jobs[0][0].device
     th, td_, done = job_tables.take(nbytes, dev)
@@ -267,7 +267,8 @@ def linear_wgrad(g: Tensor, x: Tensor, *, out: Optional[Tensor] = None, splits: 
     d = _desc(1, M, 1, K, M, 1, 1, 1, 1, 0, 0, Nn, Nn)
     if dbias is not None:
         assert dbias.dtype == torch.float32 and dbias.numel() == Nn and dbias.is_contiguous()
-    check(_hip.lib().td_conv_wgrad_bias(ptr(g), ptr(x), ptr(dw), ptr(dbias), C.byref(d), g.shape[1], dtype_code(x.dtype), splits, stream_ptr()),
+    assert g.stride(1) == 1 and x.is_contiguous()  # g may be a column block of a wider row-major buffer (row stride = ldg)
+    check(_hip.lib().td_conv_wgrad_bias(ptr(g), ptr(x), ptr(dw), ptr(dbias), C.byref(d), g.stride(0), dtype_code(x.dtype), splits, stream_ptr()),
           "td_conv_wgrad")
     return dw
 
