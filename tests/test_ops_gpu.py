@@ -273,7 +273,7 @@ def test_linear_fwd_bwd(shape, dt):
 
 
 @pytest.mark.parametrize("cfg", [(20001, 256, 1024, True, False, True), (70000, 64, 256, True, False, True), (40010, 128, 512, True, True, False),
-                                 (33000, 192, 512, False, True, False), (140000, 256, 128, False, False, True)])
+                                 (33000, 192, 512, False, True, False), (140000, 256, 128, False, False, True), (30200, 256, 2048, False, False, True)])
 def test_pointwise_persistent_instance_matches_tiled_math(cfg):
     """Shapes large enough to take the persistent weight-stationary instance (bf16, K <= 256, many rows): bias, residual,
     ReLU and ReLU-mask epilogues, ragged last M tile, against an fp32 matmul of the same bf16 inputs."""

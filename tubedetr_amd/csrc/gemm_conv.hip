@@ -1572,7 +1572,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
     const bool pw0 = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && p.d.out_sp == 1 && d->Hs == d->Ho && d->Ws == d->Wo;
     const int NTp = d->Nc / 128, Pp = 2 * n_cu / 8;
     const bool shape_ok = pw0 && dtype == TD_BF16 && p.K % 64 == 0 && p.K <= 256 && d->Nc % 128 == 0 &&
-                          (NTp == 1 || NTp == 2 || NTp == 4 || NTp == 8) && Pp >= NTp && d->ldc % 8 == 0 && !p.sigmoid &&
+                          (NTp == 1 || NTp == 2 || NTp == 4 || NTp == 8 || NTp == 16) && Pp >= NTp && d->ldc % 8 == 0 && !p.sigmoid &&
                           !p.drop_thresh && p.alpha == 1.f && n_cu % 8 == 0;
     const int MTp = cdiv(p.M, 64);
     const int groups = shape_ok ? 8 * (Pp / NTp) : 1;
