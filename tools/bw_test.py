@@ -17,3 +17,7 @@ af = torch.randn(n // 2, device=dev); cf = torch.empty_like(af)
 t = timeit(lambda: cf.copy_(af)); print(f"torch copy f32 (1R+1W, {2*af.numel()*4/1e6:.0f} MB): {t:.1f} us -> {2*af.numel()*4/t/1e6:.2f} TB/s")
 big = torch.randn(512 * 1024 * 1024 // 4, device=dev); bo = torch.empty_like(big)
 t = timeit(lambda: bo.copy_(big)); print(f"torch copy f32 512MB: {t:.1f} us -> {2*big.numel()*4/t/1e6:.2f} TB/s")
+t = timeit(lambda: big.sum()); print(f"torch sum f32 512MB (read only): {t:.1f} us -> {big.numel()*4/t/1e6:.2f} TB/s")
+t = timeit(lambda: bo.fill_(1.0)); print(f"torch fill f32 512MB (write only): {t:.1f} us -> {big.numel()*4/t/1e6:.2f} TB/s")
+huge = torch.empty(4 * 1024**3 // 2, dtype=torch.bfloat16, device=dev); ho = torch.empty_like(huge)
+t = timeit(lambda: ho.copy_(huge), 5); print(f"torch copy bf16 4GB: {t:.1f} us -> {2*huge.numel()*2/t/1e6:.2f} TB/s")
