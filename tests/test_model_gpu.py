@@ -172,11 +172,13 @@ def test_dedupe_slow_frames_is_exact():
         assert (a - b).abs().max() <= 1e-5 * max(1.0, b.abs().max().item())
 
 
-def test_hip_graph_replay_matches_eager_step():
+@pytest.mark.parametrize("text_stream", ["0", "1"])
+def test_hip_graph_replay_matches_eager_step(text_stream):
     """bench.py measures the step replayed from a HIP graph: the replay (static inputs, device-side dropout step
     counter, batched weight-gradient job table re-uploaded by a captured copy node, in-place weight re-preparation) must
-    produce the loss and the gradients of the same step launched eagerly.  Train mode, bf16; the dropout masks of
-    replay i are those of eager step i because both derive them from (seed drawn at capture/launch, step counter)."""
+    produce the loss and the gradients of the same step launched eagerly.  text_stream "1" = bench.py's default at N = 1
+    (RoBERTa forward and backward on their own stream: a forked branch of the graph), "0" = the single-stream graph the
+    staged N > 1 mode is built on."""
     import tubedetr_amd
     from oracle.weights import synthetic_batch
     from tubedetr_amd import ops as ops_
@@ -198,7 +200,7 @@ def test_hip_graph_replay_matches_eager_step():
         loss.backward()
         return loss
 
-    os.environ["TD_TEXT_STREAM"] = "0"  # single-stream capture, as bench.py does
+    os.environ["TD_TEXT_STREAM"] = text_stream
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
