@@ -945,6 +945,197 @@ __global__ __launch_bounds__(256, 2) void pw_resident_kernel(GemmParams p, int M
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two chained pointwise layers in one persistent launch: out1 = relu(x W1^T + b1 + residual) (the conv3 + identity of a
+// layer1 bottleneck: K1 = 64 -> N1 = 256) and out2 = relu(out1 W2^T + b2) (conv1 of the NEXT bottleneck: 256 -> 64 / 128).
+// Both are HBM-bound and out1 (4 GB at 8 clips) is their dominant stream: run apart, the second layer reads all of it
+// again.  Here a workgroup owns whole rows (64 per step, all 256 channels), keeps both weight matrices as MFMA fragments in
+// registers, writes the out1 tile to HBM AND (as bf16, chunk-swizzled) to LDS, and multiplies it by W2 from there - the
+// second layer costs its 64 / 128-channel output and 32 MFMAs per wavefront and step, no input traffic.
+struct ChainParams {
+  const char* x;       // [M][64] bf16
+  const char* w1;      // [256][64] bf16 (FrozenBN folded)
+  const float* b1;
+  const char* res;     // [M][256] bf16
+  char* out1;          // [M][256] bf16
+  const char* w2;      // [N2][256] bf16
+  const float* b2;
+  char* out2;          // [M][N2] bf16
+  int M;
+  uint32_t x_bytes;
+};
+
+template <int N2T>  // second layer: 64 * N2T output channels, 16 * N2T per wavefront
+__global__ __launch_bounds__(256, 2) void pw_chain_kernel(ChainParams p, int MT) {
+  using T = u16;
+  constexpr int ES = 2, K1 = 64, N1 = 256, N2 = 64 * N2T;
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  constexpr int TM = 4, TN = 4;                       // first layer, per wavefront: 64 rows x 64 channels
+  constexpr int EPL = 8, LPR = 64 / EPL, RPI = 64 / LPR, NIT = 64 / RPI, CPRW = 16;  // 8 lanes per 64-channel row segment, 8 rows per instruction
+  __shared__ __attribute__((aligned(16))) char sA0[8192];
+  __shared__ __attribute__((aligned(16))) char sA1[8192];
+  __shared__ __attribute__((aligned(16))) float sStg[4][32 * 64];   // per wavefront: 32 rows x 64 channels fp32, chunk-swizzled
+  __shared__ __attribute__((aligned(16))) char sT[64 * 512];        // out1 tile, bf16 [64][256], 16-byte chunks swizzled by (row & 7)
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  auto issue_A = [&](char* buf, int mt) {  // 64 rows x 128 B: two DMA instructions per wavefront
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mt * 64 + (i * 4 + wave) * 8 + lrow;
+      const uint32_t off = (mt < MT && m < p.M) ? ((uint32_t)m * K1 + (uint32_t)(chunk * 8)) * ES : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(buf + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  const int lr = lane & 15, lg = lane >> 4;
+  const int cc = lane % LPR, rsub = lane / LPR;
+  const int n1 = wave * 64 + cc * EPL;  // first output channel of this lane's 16-byte segment
+  float bias1[EPL];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) bias1[r] = p.b1 ? p.b1[n1 + r] : 0.f;
+  // both weight matrices as MFMA A-operand fragments in registers for the whole launch
+  uint4 w1f[2][TN], w2f[8][N2T];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < TN; ++i) w1f[ks][i] = *(const uint4*)(p.w1 + ((size_t)(wave * 64 + i * 16 + lr) * K1 + ks * 32 + lg * 8) * ES);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int i = 0; i < N2T; ++i) w2f[ks][i] = *(const uint4*)(p.w2 + ((size_t)(wave * 16 * N2T + i * 16 + lr) * N1 + ks * 32 + lg * 8) * ES);
+  float bias2[N2T][4];
+#pragma unroll
+  for (int i = 0; i < N2T; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias2[i][r] = p.b2 ? p.b2[wave * 16 * N2T + i * 16 + 4 * lg + r] : 0.f;
+  const int G = gridDim.x;
+  int mt = blockIdx.x;
+  issue_A(sA0, mt);
+
+  auto step = [&](char* cur, char* nxt, int mt) {
+    const int m0 = mt * 64;
+    // (1) residual rows of this tile (clamped: every lane always issues, the wait count below is a constant)
+    uint32_t offs[NIT];
+    bool live[NIT];
+    uint4 res[NIT];  // rows 0..31 are requested here, rows 32..63 behind the first layer's MFMAs (register pressure)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + it * RPI + rsub;
+      live[it] = m < p.M;
+      offs[it] = (uint32_t)min(m, p.M - 1) * N1 + (uint32_t)n1;
+      if (it < NIT / 2) res[it] = ld16(p.res + (size_t)offs[it] * ES);
+    }
+    // (2) next activation tile, then wait for the current one (loads complete in order: only (1) and (2) may be in flight)
+    issue_A(nxt, mt + G);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NIT / 2) : "memory");
+    __builtin_amdgcn_s_barrier();
+    // (3) first layer: 64 rows x this wavefront's 64 channels
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cidx = ks * 4 + lg;
+      uint4 af[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int row = j * 16 + lr;
+        af[j] = *(const uint4*)(cur + row * 128 + ((cidx ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mfma<T>::run(w1f[ks][i], af[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int it = NIT / 2; it < NIT; ++it) res[it] = ld16(p.res + (size_t)offs[it] * ES);
+    // (4) epilogue of the first layer in two halves of 32 rows through this wavefront's private staging area
+    float* stg = sStg[wave];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int row = jj * 16 + lr;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int c = (i * 4 + lg) ^ (row & (CPRW - 1));
+          const f32x4 a = acc[i][2 * h + jj];
+          *(float4*)(stg + row * 64 + c * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < NIT / 2; ++q) {
+        const int it = h * (NIT / 2) + q;
+        const int row = q * RPI + rsub;  // row inside the half
+        const int sw = row & (CPRW - 1);
+        float v[EPL], r8[EPL];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float4 f = *(const float4*)(stg + row * 64 + (((cc * 2 + u) ^ sw) * 4));
+          v[4 * u + 0] = f.x + bias1[4 * u + 0]; v[4 * u + 1] = f.y + bias1[4 * u + 1];
+          v[4 * u + 2] = f.z + bias1[4 * u + 2]; v[4 * u + 3] = f.w + bias1[4 * u + 3];
+        }
+        unpack16<T>(res[it], r8);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r] + r8[r], 0.f);
+        const uint4 o = pack16<T>(v);
+        if (live[it]) st16(p.out1 + (size_t)offs[it] * ES, o);
+        const int trow = h * 32 + row;  // row inside the 64-row tile
+        *(uint4*)(sT + trow * 512 + (((wave * 8 + cc) ^ (trow & 7)) << 4)) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the second half overwrites the area
+    }
+    __builtin_amdgcn_s_barrier();  // the bf16 out1 tile is complete
+    // (5) second layer: 64 rows x 16 * N2T channels per wavefront, K = 256 from the LDS tile
+    f32x4 acc2[N2T][TM];
+#pragma unroll
+    for (int i = 0; i < N2T; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int cidx = ks * 4 + lg;
+      uint4 af[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int row = j * 16 + lr;
+        af[j] = *(const uint4*)(sT + row * 512 + ((cidx ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < N2T; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mfma<T>::run(w2f[ks][i], af[j], acc2[i][j]);
+    }
+    // lane: 4 consecutive channels of row j*16 + lr -> 8-byte stores
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + j * 16 + lr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < N2T; ++i) {
+        float v4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = fmaxf(acc2[i][j][r] + bias2[i][r], 0.f);
+        store4<T>(p.out2, (size_t)m * N2 + wave * 16 * N2T + i * 16 + 4 * lg, v4);
+      }
+    }
+    // the next step's barrier (2) also orders this step's LDS-tile reads before the next tile's writes
+  };
+
+  while (mt < MT) {
+    step(sA0, sA1, mt);
+    mt += G;
+    if (mt >= MT) break;
+    step(sA1, sA0, mt);
+    mt += G;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-OOB) prefetch must not outlive the workgroup's LDS
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: dW[co][kk] += sum_{m in split} g[m][co] * gather(src)[m][kk]
 // Both operands are reduction-major in memory ([m][channel]); LDS keeps them that way and the bf16
 // fragments are produced by the gfx950 transposing LDS read (ds_read_b64_tr_b16).
@@ -1914,4 +2105,32 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
   }
   if (prof) prof_end(st);
   return TD_OK;
+}
+
+extern "C" int td_pw_chain(const void* x, const void* w1, const float* bias1, const void* residual, void* out1, const void* w2,
+                           const float* bias2, void* out2, int M, int K1, int N1, int N2, int dtype, td_stream_t stream) {
+  TD_REQUIRE(x && w1 && residual && out1 && w2 && out2 && M >= 1, "td_pw_chain: bad arguments");
+  TD_REQUIRE(dtype == TD_BF16 && K1 == 64 && N1 == 256 && (N2 == 64 || N2 == 128), "td_pw_chain: bf16, 64 -> 256 -> 64 | 128 channels only");
+  TD_REQUIRE((double)M * N1 < 2147483647.0, "td_pw_chain: tensor exceeds 2^31 elements");
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+  }();
+  ChainParams p;
+  p.x = (const char*)x; p.w1 = (const char*)w1; p.b1 = bias1; p.res = (const char*)residual; p.out1 = (char*)out1;
+  p.w2 = (const char*)w2; p.b2 = bias2; p.out2 = (char*)out2; p.M = M;
+  p.x_bytes = (uint32_t)((size_t)M * K1 * 2);
+  const int MT = cdiv(M, 64);
+  hipStream_t st = (hipStream_t)stream;
+  const bool prof = prof_on();
+  if (prof) {
+    prof_begin(TD_PROF_PW_RESIDENT, dtype, 2.0 * M * ((double)N1 * K1 + (double)N2 * N1), st, M, N1, K1, 1, 1, 0);
+    prof_set_bytes(((double)M * (K1 + 2.0 * N1 + N2) + (double)N1 * K1 + (double)N2 * N1) * 2.0);
+  }
+  dim3 grid(std::min(2 * n_cu, MT));
+  if (N2 == 64) pw_chain_kernel<1><<<grid, 256, 0, st>>>(p, MT);
+  else pw_chain_kernel<2><<<grid, 256, 0, st>>>(p, MT);
+  if (prof) prof_end(st);
+  return check_launch("td_pw_chain");
 }

@@ -168,14 +168,33 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   if (rc) return rc;
   rc = td_maxpool3x3s2(base + P.stem.off, base + P.pool.off, N, P.stem.H, P.stem.W, 64, dtype, stream);
   if (rc) return rc;
-  for (auto& b : P.blocks) {
+  // conv3 of a layer1 block + conv1 of the block behind it as ONE launch (td_pw_chain): 64 -> 256 -> 64 (| 128 into layer2)
+  static const int chain_on = [] { const char* e = getenv("TD_PW_CHAIN"); return e ? atoi(e) : 1; }();
+  bool conv1_done = false;  // this block's conv1 was produced by the previous block's chained launch
+  for (size_t bi = 0; bi < P.blocks.size(); ++bi) {
+    auto& b = P.blocks[bi];
     const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
-    if ((rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream))) return rc;
+    if (!conv1_done && (rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream))) return rc;
+    conv1_done = false;
     if ((rc = run_conv(base, b.h1, b.h2, N, P.convs[c2], w_fwd[c2], bias[c2], nullptr, 1, dtype, stream))) return rc;
     const void* idt = base + b.in.off;
     if (cd >= 0) {
       if ((rc = run_conv(base, b.in, b.idt, N, P.convs[cd], w_fwd[cd], bias[cd], nullptr, 0, dtype, stream))) return rc;
       idt = base + b.idt.off;
+    }
+    if (chain_on && dtype == TD_BF16 && bi + 1 < P.blocks.size()) {
+      auto& nb = P.blocks[bi + 1];
+      const ConvSpec &s3 = P.convs[c3], &s1 = P.convs[nb.conv[0]];
+      const long long rows = (long long)N * b.out.H * b.out.W;
+      const bool fits = s3.cin == 64 && s3.cout == 256 && s1.cin == 256 && s1.k == 1 && s1.stride == 1 && (s1.cout == 64 || (s1.cout == 128 && (chain_on & 2))) &&
+                        rows * 256 < 2147483647LL && nb.h1.off != b.h2.off && nb.h1.off != b.out.off && nb.h1.off != b.in.off && (cd < 0 || nb.h1.off != b.idt.off);
+      if (fits) {
+        if ((rc = td_pw_chain(base + b.h2.off, w_fwd[c3], bias[c3], idt, base + b.out.off, w_fwd[nb.conv[0]], bias[nb.conv[0]], base + nb.h1.off, (int)rows,
+                              64, 256, s1.cout, dtype, stream)))
+          return rc;
+        conv1_done = true;
+        continue;
+      }
     }
     if ((rc = run_conv(base, b.h2, b.out, N, P.convs[c3], w_fwd[c3], bias[c3], idt, 1, dtype, stream))) return rc;
   }
