@@ -994,15 +994,16 @@ __global__ __launch_bounds__(256, 2) void pw_chain_kernel(ChainParams p, int MT)
 #pragma unroll
   for (int r = 0; r < EPL; ++r) bias1[r] = p.b1 ? p.b1[n1 + r] : 0.f;
   // both weight matrices as MFMA A-operand fragments in registers for the whole launch
-  uint4 w1f[2][TN], w2f[8][N2T];
+  // (second layer: the first 16 channels of this wavefront stay in registers, a second 16-channel block - N2 = 128 - is
+  //  re-read from L2 in every step once the first layer's accumulators are gone: 64 more persistent registers would spill)
+  uint4 w1f[2][TN], w2f[8];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int i = 0; i < TN; ++i) w1f[ks][i] = *(const uint4*)(p.w1 + ((size_t)(wave * 64 + i * 16 + lr) * K1 + ks * 32 + lg * 8) * ES);
+  const char* w2row = p.w2 + ((size_t)(wave * 16 * N2T + lr) * N1 + lg * 8) * ES;
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-    for (int i = 0; i < N2T; ++i) w2f[ks][i] = *(const uint4*)(p.w2 + ((size_t)(wave * 16 * N2T + i * 16 + lr) * N1 + ks * 32 + lg * 8) * ES);
+  for (int ks = 0; ks < 8; ++ks) w2f[ks] = *(const uint4*)(w2row + (size_t)ks * 32 * ES);
   float bias2[N2T][4];
 #pragma unroll
   for (int i = 0; i < N2T; ++i)
@@ -1088,6 +1089,11 @@ __global__ __launch_bounds__(256, 2) void pw_chain_kernel(ChainParams p, int MT)
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the second half overwrites the area
     }
+    uint4 w2g[N2T > 1 ? 8 : 1];  // second 16-channel block of W2 (N2 = 128): requested before the barrier, used behind it
+    if constexpr (N2T > 1) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) w2g[ks] = *(const uint4*)(w2row + ((size_t)16 * N1 + (size_t)ks * 32) * ES);
+    }
     __builtin_amdgcn_s_barrier();  // the bf16 out1 tile is complete
     // (5) second layer: 64 rows x 16 * N2T channels per wavefront, K = 256 from the LDS tile
     f32x4 acc2[N2T][TM];
@@ -1105,9 +1111,11 @@ __global__ __launch_bounds__(256, 2) void pw_chain_kernel(ChainParams p, int MT)
         af[j] = *(const uint4*)(sT + row * 512 + ((cidx ^ (row & 7)) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < N2T; ++i)
+      for (int j = 0; j < TM; ++j) Mfma<T>::run(w2f[ks], af[j], acc2[0][j]);
+      if constexpr (N2T > 1) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) Mfma<T>::run(w2f[ks][i], af[j], acc2[i][j]);
+        for (int j = 0; j < TM; ++j) Mfma<T>::run(w2g[ks], af[j], acc2[1][j]);
+      }
     }
     // lane: 4 consecutive channels of row j*16 + lr -> 8-byte stores
 #pragma unroll

@@ -169,7 +169,7 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   rc = td_maxpool3x3s2(base + P.stem.off, base + P.pool.off, N, P.stem.H, P.stem.W, 64, dtype, stream);
   if (rc) return rc;
   // conv3 of a layer1 block + conv1 of the block behind it as ONE launch (td_pw_chain): 64 -> 256 -> 64 (| 128 into layer2)
-  static const int chain_on = [] { const char* e = getenv("TD_PW_CHAIN"); return e ? atoi(e) : 1; }();
+  static const int chain_on = [] { const char* e = getenv("TD_PW_CHAIN"); return e ? atoi(e) : 3; }();  // bit 0: inside layer1, bit 1: into layer2
   bool conv1_done = false;  // this block's conv1 was produced by the previous block's chained launch
   for (size_t bi = 0; bi < P.blocks.size(); ++bi) {
     auto& b = P.blocks[bi];
