@@ -830,7 +830,8 @@ extern "C" int td_mha_lean_fwd(const void* q, const void* k, const void* v, cons
   TD_REQUIRE(q && k && v && out && stats, "td_mha_lean_fwd: null pointer");
   MhaParams p;
   memset(&p, 0, sizeof(p));
-  int rc = fill(p, B, H, Lq, Lk, hd == 32 ? hd : 32, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, dropout_counter, "td_mha_lean_fwd");
+  TD_REQUIRE(hd == HD, "td_mha_lean_fwd: the lean path takes head dim 32 (got %d)", hd);
+  int rc = fill(p, B, H, Lq, Lk, hd, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, dropout_counter, "td_mha_lean_fwd");
   if (rc) return rc;
   p.q = q; p.k = k; p.v = v; p.kpm = key_pad; p.out = out; p.stats = stats;
   rc = lean_check(p, dtype, hd, "td_mha_lean_fwd");
@@ -852,7 +853,8 @@ extern "C" int td_mha_lean_bwd(const void* q, const void* k, const void* v, cons
   TD_REQUIRE(q && k && v && out && dout && stats && dq && dk && dv, "td_mha_lean_bwd: null pointer");
   MhaParams p;
   memset(&p, 0, sizeof(p));
-  int rc = fill(p, B, H, Lq, Lk, hd == 32 ? hd : 32, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, dropout_counter, "td_mha_lean_bwd");
+  TD_REQUIRE(hd == HD, "td_mha_lean_bwd: the lean path takes head dim 32 (got %d)", hd);
+  int rc = fill(p, B, H, Lq, Lk, hd, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, dropout_counter, "td_mha_lean_bwd");
   if (rc) return rc;
   p.q = q; p.k = k; p.v = v; p.kpm = key_pad; p.out = (void*)out; p.dout = dout; p.stats = stats; p.dq = dq; p.dk = dk; p.dv = dv;
   rc = lean_check(p, dtype, hd, "td_mha_lean_bwd");
