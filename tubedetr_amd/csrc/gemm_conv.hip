@@ -1887,7 +1887,8 @@ static int wgrad_stages() {
   return nstg;
 }
 
-// fills everything of p except the output fields; returns the split count through *splits_io
+// fills everything of p except the output fields; returns the split count through *splits_io.
+// auto_mode: 0 = single launch (about one workgroup per CU), > 0 = batched launch with work items of that many stages
 static int wgrad_fill(WgradParams& p, const void* g, const void* src, const td_conv_desc* d, int ldg, int dtype, int* splits_io,
                       int auto_mode, const char* who) {
   int rc = validate(d, dtype, who);
@@ -1928,8 +1929,9 @@ static int wgrad_fill(WgradParams& p, const void* g, const void* src, const td_c
       // fp32-atomic epilogue (65 536 atomics per 256 x 256 tile, 36-byte strided for the 3x3 layers: ~30 % of a 192-stage
       // item), an unsplit trunk leaves 3 000-stage items next to 190-stage ones: measured over the trunk's 93 jobs at 8 clips
       // 8.5 ms at 192 stages per item, 7.1 ms at 512 .. 1024, 10.4 ms unsplit.
-      static const int split_stages = [] { const char* e = getenv("TD_WGRAD_SPLIT_STAGES"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
-      splits = cdiv(p.M, split_stages * mk);
+      //   The length is chosen per launch (td_conv_wgrad_batch): total work / (3.4 items per CU), within 192 .. 2048 stages -
+      //   512 at 4 clips, ~1000 at 8 (in the network: 80.5 clips/s at 512, 81.1 at 1024); auto_mode carries it.
+      splits = cdiv(p.M, std::max(1, auto_mode) * mk);
     }
     if (splits < 1) splits = 1;
   }
@@ -1994,12 +1996,29 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
   double flops = 0, abytes = 0;
   static const int wide_on = [] { const char* e = getenv("TD_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
   static const int wide_min_m = [] { const char* e = getenv("TD_WGRAD_WIDE_MIN_M"); return e ? atoi(e) : 4096; }();
+  // stages (64 / 32 reduction rows) per work item: total work of the launch in 256 x 256 tile-stages / (3.4 items per CU)
+  int item_stages;
+  {
+    static const int fixed = [] { const char* e = getenv("TD_WGRAD_SPLIT_STAGES"); return e ? atoi(e) : 0; }();
+    static const int n_cu = [] {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      return cus;
+    }();
+    double units = 0;
+    const int mk = dtype == TD_BF16 ? 64 : 32;
+    for (int i = 0; i < n_jobs; ++i) {
+      const td_conv_desc& d = jobs[i].d;
+      units += (double)cdiv(d.Nc, 128) * cdiv(d.R * d.S * d.C, 128) / 4.0 * cdiv(d.N * d.Ho * d.Wo, mk);
+    }
+    item_stages = fixed > 0 ? fixed : (int)std::min(2048.0, std::max(192.0, units / (3.4 * n_cu)));
+  }
   for (int i = 0; i < n_jobs; ++i) {
     const td_wgrad_job& j = jobs[i];
     TD_REQUIRE(j.g && j.src && j.dW, "td_conv_wgrad_batch: job %d has a null pointer", i);
     WgradParams p;
     int splits = 0;
-    int rc = wgrad_fill(p, j.g, j.src, &j.d, j.ldg, dtype, &splits, 1, "td_conv_wgrad_batch");
+    int rc = wgrad_fill(p, j.g, j.src, &j.d, j.ldg, dtype, &splits, item_stages, "td_conv_wgrad_batch");
     if (rc) return rc;
     TD_REQUIRE(j.ci_real >= 1 && j.ci_real <= j.d.C, "td_conv_wgrad_batch: job %d: ci_real=%d out of range", i, j.ci_real);
     p.dw = j.dW;
