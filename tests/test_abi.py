@@ -27,6 +27,43 @@ def test_header_symbols_exported():
     assert _hip.lib().td_abi_version() == _hip.EXPECTED_ABI
 
 
+def test_binding_argument_counts_and_struct_layouts_match_the_header():
+    """Every prototype of include/tubedetr_hip.h has as many parameters as the ctypes signature that calls it, and every
+    struct as many fields as its ctypes mirror (a changed signature must not survive in the binding of an old checkout)."""
+    from tubedetr_amd import _hip
+
+    src = open(os.path.join(ROOT, "include", "tubedetr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    flat = " ".join(src.split())
+    protos = dict()
+    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(td_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", flat):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    sigs = dict(_hip._SIGS)
+    sigs.update(_hip._SIZE_SIGS)
+    checked = 0
+    for name, argtypes in sigs.items():
+        assert name in protos, name
+        assert protos[name] == len(argtypes), f"{name}: header has {protos[name]} parameters, the binding passes {len(argtypes)}"
+        checked += 1
+    assert checked >= 40
+    structs = {m.group(2): m.group(1) for m in re.finditer(r"typedef struct \w+ \{(.*?)\} (td_\w+);", flat)}
+
+    def n_fields(body):
+        n = 0
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                n += decl.count(",") + 1
+        return n
+
+    mirrors = {"td_conv_desc": _hip.ConvDesc, "td_epilogue": _hip.Epilogue, "td_wgrad_job": _hip.WgradJob, "td_frame_source": _hip.FrameSource,
+               "td_prep_item": _hip.PrepItem, "td_optim_segment": _hip.OptimSegment}
+    for cname, cls in mirrors.items():
+        assert cname in structs, cname
+        assert n_fields(structs[cname]) == len(cls._fields_), f"{cname}: {n_fields(structs[cname])} fields in the header, {len(cls._fields_)} in the binding"
+
+
 def test_errors_are_reported_not_swallowed():
     """Invalid arguments return an error code + message (no launch is attempted)."""
     from tubedetr_amd import _hip
