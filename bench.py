@@ -34,7 +34,7 @@ Extra legs (rank 0, after the timed region, not part of `value`):
                  rocprofv3 PMC results committed under profiles/ (counters cannot be read from inside the timed process).
                  `roofline` is the family with the largest share of the step, the others follow in `other_mfma_kernels`.
   cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on the host cores on a bounded
-                 sample (a T=`--cpu-frames` clip of the same resolution, fwd+bwd, median of 3) and scaled to T=100.
+                 sample (a T=`--cpu-frames` clip of the same resolution, fwd+bwd, one warm-up + median of 3 passes) and scaled to T=100.
 """
 from __future__ import annotations
 
@@ -119,8 +119,8 @@ def cpu_model_name() -> str:
 
 
 def cpu_baseline(T_sample, res, k, L, T_full):
-    """Reference algorithm on the host cores (oracle port), fwd+bwd of a T_sample-frame clip (median of 3 after one warm-up
-    unless the budget runs out), scaled to T_full frames."""
+    """Reference algorithm on the host cores (oracle port), fwd+bwd of a T_sample-frame clip: one warm-up pass, then the
+    median of THREE measured passes (always three: the sample is sized so that they fit the budget), scaled to T_full frames."""
     from oracle.tubedetr_oracle import OracleConfig, train_step
     from oracle.weights import fill_state, state_spec, synthetic_batch
 
@@ -129,25 +129,22 @@ def cpu_baseline(T_sample, res, k, L, T_full):
     cfg = OracleConfig(stride=k)
     sd = fill_state(state_spec(cfg), 1, requires_grad=True)
     batch = synthetic_batch(T=T_sample, res=res, k=k, L=L, seed=5)
-    times, spent = [], 0.0
-    for it in range(4):  # pass 0 = warm-up (allocator, thread pool), then up to three measured passes within ~30 s
+    times = []
+    for it in range(4):  # pass 0 = warm-up (allocator, thread pool), passes 1-3 are measured
         for v in sd.values():
             v.grad = None
         t0 = time.time()
         loss, _, _, _ = train_step(sd, cfg, batch)
         loss.backward()
         dt = time.time() - t0
-        spent += dt
-        if it > 0 or spent > 15.0:
+        if it > 0:
             times.append(dt)
-        if spent > 30.0 and times:
-            break
     times.sort()
     med = times[len(times) // 2]
     per_clip = med * (T_full / T_sample)
     return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": cores, "cpu": cpu_model_name(), "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"fwd+bwd of a T={T_sample} clip (k={k}, res={res}, L={L}) by the CPU oracle, median {med:.1f}s of {len(times)} passes "
-                      f"({', '.join(f'{t_:.1f}' for t_ in times)}), scaled x{T_full}/{T_sample} to T={T_full}"}
+                      f"({', '.join(f'{t_:.1f}' for t_ in times)}) after one warm-up pass, scaled x{T_full}/{T_sample} to T={T_full}"}
 
 
 def _trace(msg):
@@ -171,7 +168,7 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=DEFAULT_CLIPS_PER_GPU, help="videos per GPU per step (the reference's --batch_size, main.py:63)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--roofline-steps", type=int, default=1)
-    ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-baseline sample clip (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU-baseline sample clip (0 = skip); 32 frames: ~6 s per pass, 4 passes")
     ap.add_argument("--keep-prepared-weights", action="store_true", help="diagnostic: reuse prepared bf16 weights across steps")
     ap.add_argument("--dedupe", action="store_true",
                     help="do not recompute the slow frames inside the fast pass (exact, slow = video[::k]); off by default so the timed step "

@@ -149,6 +149,9 @@ typedef struct td_frame_source {
   int dtype;        /* TD_F32 or TD_U8 */
   int n;            /* frames contributed */
   const int* index; /* device int32[n] or NULL (= 0..n-1) */
+  const int* valid_hw; /* device int32[n_src][2] = (rows, columns) of every SOURCE frame that hold pixels, or NULL (= H x W): a
+                        * ragged batch padded to a common H x W; pixels outside are written as exactly 0 (after normalisation), like
+                        * NestedTensor.from_tensor_list pads the normalised frames, util/misc.py:158-170 */
 } td_frame_source;
 int td_frames_to_nhwc(const td_frame_source* srcs, int n_srcs, int C, int H, int W, int Cpad, const float* mean,
                       const float* inv_std, void* y, int dtype, td_stream_t stream);

@@ -85,3 +85,52 @@ def test_uint8_pipeline_equals_reference_format_step():
         # 104 convolutions and the min / max / sign kinks of the losses amplify that to ~1e-3 .. 1e-2 on individual gradient entries,
         # so the comparison is per parameter in norm (a wrong frame order or normalisation constant would be O(1))
         assert (a - p.grad).norm().item() <= 2e-2 * p.grad.norm().item() + 1e-5 * scale
+
+
+def test_ragged_batch_padding_is_zero_after_normalisation():
+    """Videos of different H x W in one batch: the reference normalises FIRST and pads with zeros
+    (NestedTensor.from_tensor_list, util/misc.py:158-170), so padded pixels are exactly 0 in the trunk's input; the uint8
+    pipeline pads raw pixels and lets td_frames_to_nhwc zero the padded area through the per-frame extents."""
+    import ctypes as C
+
+    from tubedetr_amd import _hip
+    from tubedetr_amd.data import ClipPipeline
+    from tubedetr_amd.util.misc import NestedTensor
+
+    dev = torch.device("cuda:0")
+    k = 2
+    g = torch.Generator().manual_seed(4)
+    videos = [torch.randint(1, 256, (4, 3, 20, 32), generator=g, dtype=torch.uint8), torch.randint(1, 256, (6, 3, 28, 24), generator=g, dtype=torch.uint8)]
+    ids = torch.randint(3, 50000, (2, 5), generator=g)
+    att = torch.ones(2, 5, dtype=torch.long)
+    boxes = torch.rand(10, 4, generator=g)
+    pipe = ClipPipeline(dev, k)
+    batch = pipe.collect(pipe.stage(videos, ids, att, boxes, [[0, 3], [0, 5]]))
+    torch.cuda.synchronize()
+    mean = torch.tensor((0.485, 0.456, 0.406)).view(1, 3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225)).view(1, 3, 1, 1)
+    # the reference's collate: normalised clips (C, T, H, W), zero-padded
+    ref = NestedTensor.from_tensor_list([((v.float() / 255 - mean) / std).transpose(0, 1) for v in videos])
+    H, W = ref.tensors.shape[-2:]
+    assert (H, W) == (28, 32)
+    assert torch.equal(batch["fast_mask"].cpu(), ref.mask)
+    slow_ref = torch.cat([ref.tensors[0:4:k], ref.tensors[4:10:k]])
+    assert torch.equal(batch["frames_mask"].cpu(), torch.cat([ref.mask[0:4:k], ref.mask[4:10:k]]))
+    for name, want in (("frames_fast", ref.tensors), ("frames", slow_ref)):
+        fs = batch[name]
+        n = fs.n_frames
+        assert n == want.shape[0]
+        for dt, cpad, tol in ((torch.float32, 4, 3e-6), (torch.bfloat16, 8, 3e-2)):
+            out = torch.full((n, H, W, cpad), float("nan"), dtype=dt, device=dev)
+            srcs = (_hip.FrameSource * len(fs.parts))()
+            for s_, (t_, idx), vhw in zip(srcs, fs.parts, fs.valid):
+                assert vhw is not None
+                s_.data, s_.dtype, s_.n = t_.data_ptr(), _hip.TD_U8, (idx.numel() if idx is not None else t_.shape[0])
+                s_.index, s_.valid_hw = (idx.data_ptr() if idx is not None else None), vhw.data_ptr()
+            _hip.check(_hip.lib().td_frames_to_nhwc(srcs, len(fs.parts), 3, H, W, cpad, (C.c_float * 3)(0.485, 0.456, 0.406),
+                                                    (C.c_float * 3)(*[1 / s for s in (0.229, 0.224, 0.225)]), out.data_ptr(), _hip.dtype_code(dt),
+                                                    _hip.stream_ptr()), "td_frames_to_nhwc")
+            got = out[..., :3].float().cpu().permute(0, 3, 1, 2)
+            assert (got - want).abs().max().item() < tol
+            pad = (want == 0).all(1)  # padded pixels: exactly zero, not (0 - mean) / std
+            assert pad.any() and (got.permute(0, 2, 3, 1)[pad] == 0).all()

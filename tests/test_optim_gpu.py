@@ -72,3 +72,83 @@ def test_fused_clip_adamw_ema_matches_torch():
     assert opt.step_dev.item() == 3
     # the model still computes with the updated weights: parameters are views of the flat buffer
     assert p_new[names[0]].data_ptr() == opt.flat_p.data_ptr()
+
+
+def test_optimizer_checkpoint_is_torch_adamw_layout_and_ema_resumes():
+    """checkpoint["optimizer"] of the reference is a torch AdamW state_dict (main.py:681): a checkpoint written by the fused
+    optimizer loads into torch.optim.AdamW built like main.py:381-413 and continues identically, and the other way round;
+    the EMA buffer starts from ema_model's own (resumed) weights, not from the model's."""
+    import tubedetr_amd
+    from tubedetr_amd.models import build_model
+    from tubedetr_amd.optim import FusedAdamWEMA
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    model, _, _ = build_model(tubedetr_amd.default_args(stride=4, resnet_layers=(1, 1, 1, 1), enc_layers=1, dec_layers=1))
+    model.to(dev)
+    ref = copy.deepcopy(model)
+    ema = copy.deepcopy(model)
+    with torch.no_grad():
+        for p in ema.parameters():
+            p.add_(0.25)  # "loaded from checkpoint['model_ema']": differs from the model's weights
+    ema_before = {n: p.detach().clone() for n, p in ema.named_parameters()}
+
+    def torch_opt(m):
+        groups = [{"params": [p for n, p in m.named_parameters() if "backbone" not in n and "text_encoder" not in n and p.requires_grad]},
+                  {"params": [p for n, p in m.named_parameters() if "backbone" in n and p.requires_grad], "lr": 1e-5},
+                  {"params": [p for n, p in m.named_parameters() if "text_encoder" in n and p.requires_grad], "lr": 5e-5}]
+        return torch.optim.AdamW(groups, lr=5e-5, weight_decay=1e-4)
+
+    opt = FusedAdamWEMA(model, max_norm=0.0, ema_model=ema, ema_decay=0.9998)
+    for n, p in ema.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p, ema_before[n]), n  # not overwritten by the model's weights
+    opt_ref = torch_opt(ref)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    p_new, p_ref = dict(model.named_parameters()), dict(ref.named_parameters())
+    g = torch.Generator(device=dev).manual_seed(2)
+
+    def grads():
+        for n in names:
+            if "pooler" in n:
+                p_ref[n].grad = p_new[n].grad = None
+                continue
+            gr = torch.randn(p_ref[n].shape, generator=g, device=dev) * 1e-2
+            p_ref[n].grad, p_new[n].grad = gr.clone(), gr.clone()
+
+    for _ in range(2):
+        grads()
+        opt.step()
+        opt_ref.step()
+    sd_fused, sd_torch = opt.state_dict(), opt_ref.state_dict()
+    assert set(sd_fused) == {"state", "param_groups"}
+    assert [g_["params"] for g_ in sd_fused["param_groups"]] == [g_["params"] for g_ in sd_torch["param_groups"]]
+    assert set(sd_fused["param_groups"][0]) == set(sd_torch["param_groups"][0])
+    assert set(sd_fused["state"]) == set(sd_torch["state"])  # the pooler's entries are absent on both sides
+    for i, st in sd_torch["state"].items():
+        assert float(sd_fused["state"][i]["step"]) == float(st["step"]) == 2.0
+        for k_ in ("exp_avg", "exp_avg_sq"):
+            a, b_ = sd_fused["state"][i][k_], st[k_]
+            assert a.shape == b_.shape and (a - b_).abs().max().item() <= 1e-6 * max(1e-12, b_.abs().max().item()) + 1e-12, (i, k_)
+    # cross-load: fused checkpoint -> torch AdamW on a fresh copy, torch checkpoint -> fused on another; one more step each
+    m2, m3 = copy.deepcopy(ref), copy.deepcopy(ref)
+    o2 = torch_opt(m2)
+    o2.load_state_dict(sd_fused)
+    o3 = FusedAdamWEMA(m3, max_norm=0.0)
+    o3.load_state_dict(sd_torch)
+    assert o3.step_dev.item() == 2
+    grads()
+    p2, p3 = dict(m2.named_parameters()), dict(m3.named_parameters())
+    for n in names:
+        p2[n].grad = None if p_ref[n].grad is None else p_ref[n].grad.clone()
+        p3[n].grad = None if p_ref[n].grad is None else p_ref[n].grad.clone()
+    before = {n: p_ref[n].detach().clone() for n in names}
+    opt_ref.step()
+    o2.step()
+    o3.step()
+    torch.cuda.synchronize()
+    for n in names:
+        upd = (p_ref[n].detach() - before[n])
+        scale = upd.abs().max().clamp_min(1e-12)
+        assert ((p2[n].detach() - before[n] - upd).abs().max() / scale).item() < 1e-2, n
+        assert ((p3[n].detach() - before[n] - upd).abs().max() / scale).item() < 1e-2, n

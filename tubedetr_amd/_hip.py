@@ -11,7 +11,7 @@ import os
 import torch
 
 TD_F32, TD_BF16 = 0, 1
-EXPECTED_ABI = 4  # td_abi_version() of the library these signatures were written against
+EXPECTED_ABI = 5  # td_abi_version() of the library these signatures were written against
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtubedetr_hip.so")
 _lib = None
 
@@ -36,7 +36,7 @@ TD_U8 = 2
 
 class FrameSource(C.Structure):
     """td_frame_source."""
-    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int), ("n", C.c_int), ("index", C.c_void_p)]
+    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int), ("n", C.c_int), ("index", C.c_void_p), ("valid_hw", C.c_void_p)]
 
 
 class OptimSegment(C.Structure):

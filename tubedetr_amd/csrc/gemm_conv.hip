@@ -175,7 +175,8 @@ __device__ __forceinline__ void st16(char* p, const uint4& v) {
 // bounds tests.  Which taps fall inside the image is a per-row bit mask computed once per workgroup.  Forward geometry with
 // any stride, or input-gradient geometry with stride 1.
 template <typename T, int BM, int BN, int NST, bool PW, bool TU = false>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void conv_gemm_kernel(GemmParams p) {
+// (three 24-KiB stages of a 64 x 128 tile = 72 KiB: two workgroups per CU, so that is what the NST == 3 instances declare)
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) void conv_gemm_kernel(GemmParams p) {
   static_assert(!(PW && TU), "pointwise layers have no taps");
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;   // elements per 16-byte chunk

@@ -169,19 +169,26 @@ struct FrameNorm {
   float mean[4], inv_std[4], in_scale;
 };
 template <typename T, typename S, int CP>
-__global__ __launch_bounds__(256) void frames_to_nhwc_kernel(const S* __restrict__ x, const int* __restrict__ index, T* __restrict__ y, int n_frames,
-                                                             int C, int H, int W, FrameNorm nm) {
+__global__ __launch_bounds__(256) void frames_to_nhwc_kernel(const S* __restrict__ x, const int* __restrict__ index, const int* __restrict__ valid_hw,
+                                                             T* __restrict__ y, int n_frames, int C, int H, int W, FrameNorm nm) {
   const size_t hw = (size_t)H * W;
   const size_t n = (size_t)n_frames * hw;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   const size_t img = idx / hw, p = idx - img * hw;
   const size_t src = index ? (size_t)index[img] : img;
+  // pixels outside the frame's own extent (a batch of videos padded to a common H x W) are exactly 0 AFTER normalisation,
+  // like NestedTensor.from_tensor_list pads the already normalised frames (util/misc.py:158-170)
+  bool inside = true;
+  if (valid_hw) {
+    const int py = (int)(p / W), px = (int)(p - (size_t)py * W);
+    inside = py < valid_hw[2 * src] && px < valid_hw[2 * src + 1];
+  }
   float v[CP];
 #pragma unroll
   for (int c = 0; c < CP; ++c) {
     v[c] = 0.f;
-    if (c < C) v[c] = ((float)x[(src * C + c) * hw + p] * nm.in_scale - nm.mean[c]) * nm.inv_std[c];
+    if (c < C && inside) v[c] = ((float)x[(src * C + c) * hw + p] * nm.in_scale - nm.mean[c]) * nm.inv_std[c];
   }
   if constexpr (sizeof(T) == 2 && CP == 4) {  // 4-channel bf16 pixels: the pixel-pair form of the stem (td_resnet_fwd stem_pairs)
     uint2 o;
@@ -301,14 +308,14 @@ extern "C" int td_frames_to_nhwc(const td_frame_source* srcs, int n_srcs, int C,
     char* out = (char*)y + done * (size_t)H * W * Cpad * es;
     const unsigned g = nblk(n);
     if (dtype == TD_BF16 && Cpad == 4) {
-      if (f.dtype == TD_U8) frames_to_nhwc_kernel<u16, uint8_t, 4><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
-      else frames_to_nhwc_kernel<u16, float, 4><<<g, 256, 0, st>>>((const float*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
+      if (f.dtype == TD_U8) frames_to_nhwc_kernel<u16, uint8_t, 4><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, f.valid_hw, (u16*)out, f.n, C, H, W, nm);
+      else frames_to_nhwc_kernel<u16, float, 4><<<g, 256, 0, st>>>((const float*)f.data, f.index, f.valid_hw, (u16*)out, f.n, C, H, W, nm);
     } else if (dtype == TD_BF16) {
-      if (f.dtype == TD_U8) frames_to_nhwc_kernel<u16, uint8_t, 8><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
-      else frames_to_nhwc_kernel<u16, float, 8><<<g, 256, 0, st>>>((const float*)f.data, f.index, (u16*)out, f.n, C, H, W, nm);
+      if (f.dtype == TD_U8) frames_to_nhwc_kernel<u16, uint8_t, 8><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, f.valid_hw, (u16*)out, f.n, C, H, W, nm);
+      else frames_to_nhwc_kernel<u16, float, 8><<<g, 256, 0, st>>>((const float*)f.data, f.index, f.valid_hw, (u16*)out, f.n, C, H, W, nm);
     } else {
-      if (f.dtype == TD_U8) frames_to_nhwc_kernel<float, uint8_t, 4><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, (float*)out, f.n, C, H, W, nm);
-      else frames_to_nhwc_kernel<float, float, 4><<<g, 256, 0, st>>>((const float*)f.data, f.index, (float*)out, f.n, C, H, W, nm);
+      if (f.dtype == TD_U8) frames_to_nhwc_kernel<float, uint8_t, 4><<<g, 256, 0, st>>>((const uint8_t*)f.data, f.index, f.valid_hw, (float*)out, f.n, C, H, W, nm);
+      else frames_to_nhwc_kernel<float, float, 4><<<g, 256, 0, st>>>((const float*)f.data, f.index, f.valid_hw, (float*)out, f.n, C, H, W, nm);
     }
     done += f.n;
   }
@@ -319,7 +326,7 @@ extern "C" int td_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int
                                td_stream_t stream) {
   TD_REQUIRE(x && y && Cpad >= C, "td_nchw_to_nhwc: bad arguments");
   if (C <= 4 && (Cpad == 4 || (Cpad == 8 && dtype == TD_BF16))) {
-    td_frame_source f = {x, TD_F32, N, nullptr};
+    td_frame_source f = {x, TD_F32, N, nullptr, nullptr};
     return td_frames_to_nhwc(&f, 1, C, H, W, Cpad, nullptr, nullptr, y, dtype, stream);
   }
   size_t n = (size_t)N * H * W;

@@ -53,16 +53,18 @@ class ClipPipeline:
         off = 0
         ragged = any(v.shape[2] != H or v.shape[3] != W for v in videos)
         if ragged:
-            vid.zero_()
+            vid.zero_()  # raw 0 is NOT 0 after normalisation: the padded area is zeroed by the input kernel through `valid_hw`
             msk.fill_(True)
         else:
             msk.fill_(False)
+        valid_hw = []
         for v in videos:
             assert v.dtype == torch.uint8 and v.dim() == 4 and v.shape[1] == 3, "videos are uint8 (T, 3, H, W)"
             t, _, h, w = v.shape
             vid[off : off + t, :, :h, :w].copy_(v)
             if ragged:
                 msk[off : off + t, :h, :w] = False
+            valid_hw += [[h, w]] * t
             off += t
         k = self.stride
         slow_idx, base = [], 0
@@ -73,26 +75,31 @@ class ClipPipeline:
             vid_dev = vid.to(self.device, non_blocking=True)
             msk_dev = msk.to(self.device, non_blocking=True)
             idx_dev = torch.tensor(slow_idx, dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
+            # extent of every frame inside the padded H x W (None for a uniform batch): the reference pads the NORMALISED
+            # frames with zeros (NestedTensor.from_tensor_list, util/misc.py:158-170), so padded pixels must be 0 after the
+            # device-side normalisation, not (0 - mean) / std
+            vhw_dev = torch.tensor(valid_hw, dtype=torch.int32).pin_memory().to(self.device, non_blocking=True) if ragged else None
             ids_dev = input_ids.pin_memory().to(self.device, non_blocking=True)
             att_dev = attention_mask.pin_memory().to(self.device, non_blocking=True)
             box_dev = target_boxes.pin_memory().to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         slot[2] = ev
-        return {"event": ev, "video": vid_dev, "mask": msk_dev, "slow_index": idx_dev, "durations": durations, "input_ids": ids_dev,
+        return {"event": ev, "video": vid_dev, "mask": msk_dev, "slow_index": idx_dev, "valid_hw": vhw_dev, "durations": durations, "input_ids": ids_dev,
                 "attention_mask": att_dev, "target_boxes": box_dev, "inter_idx": [list(x) for x in inter_idx], "n_slow": len(slow_idx)}
 
     def collect(self, ticket: dict) -> dict:
         """Batch dict for ``harness.forward_step``; the current stream waits for the ticket's copies (no host sync)."""
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ticket["event"])
-        for k_ in ("video", "mask", "slow_index", "input_ids", "attention_mask", "target_boxes"):
-            ticket[k_].record_stream(cur)  # allocated on the copy stream, consumed on the compute stream
-        video, mask, idx = ticket["video"], ticket["mask"], ticket["slow_index"]
+        for k_ in ("video", "mask", "slow_index", "valid_hw", "input_ids", "attention_mask", "target_boxes"):
+            if ticket[k_] is not None:
+                ticket[k_].record_stream(cur)  # allocated on the copy stream, consumed on the compute stream
+        video, mask, idx, vhw = ticket["video"], ticket["mask"], ticket["slow_index"], ticket["valid_hw"]
         return {
-            "frames": FrameSources([(video, idx)]),          # slow clip: an index list over the same pixels
+            "frames": FrameSources([(video, idx)], [vhw]),   # slow clip: an index list over the same pixels
             "frames_mask": mask[idx.long()],
-            "frames_fast": video,                            # uint8; normalised by the trunk's input kernel
+            "frames_fast": FrameSources([(video, None)], [vhw]) if vhw is not None else video,  # uint8; normalised by the trunk's input kernel
             "fast_mask": mask,
             "durations": ticket["durations"],
             "input_ids": ticket["input_ids"],

@@ -80,13 +80,19 @@ class FlatGradAllReducer:
             torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        had = [g is not None for g in grads]
-        if self._global_used is not None and any(h and not u for h, u in zip(had, self._global_used)):
-            # a parameter no rank used when the usage map was exchanged now has a gradient here: ranks that still skip it
-            # would silently diverge, so the map is re-exchanged (every rank must see the same change: data-dependent
-            # parameter usage is not supported by the reference's model either)
-            self._global_used = None
-        self._had_grad = had
+        self._note_usage(range(len(self.params)), grads)
+
+    def _note_usage(self, sel, grads) -> None:
+        """Record which of the parameters ``sel`` had a local gradient.  A parameter no rank used when the usage map was
+        exchanged and that now has a gradient here invalidates the map: ranks that still skip it would silently diverge,
+        so it is re-exchanged (every rank must see the same change: data-dependent parameter usage is not supported by the
+        reference's model either)."""
+        if self._had_grad is None or len(self._had_grad) != len(self.params):
+            self._had_grad = [True] * len(self.params)
+        for i, g in zip(sel, grads):
+            self._had_grad[i] = g is not None
+            if g is not None and self._global_used is not None and not self._global_used[i]:
+                self._global_used = None
 
     def _sync_usage(self) -> None:
         """DDP(find_unused_parameters=True) hands every rank the reduced gradient of a parameter ANY rank used and leaves
@@ -132,10 +138,7 @@ class FlatGradAllReducer:
             torch._foreach_zero_(missing)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        if self._had_grad is None or len(self._had_grad) != len(self.params):
-            self._had_grad = [True] * len(self.params)
-        for i, g in zip(sel, grads):
-            self._had_grad[i] = g is not None
+        self._note_usage(sel, grads)  # (same invalidation rule as gather(): the staged / graph path must not keep a stale usage map)
 
     def exchange_stage(self, early: bool) -> None:
         """Start the all-reduce of one stage's runs WITHOUT waiting for it (async_op: the collective is ordered after the

@@ -67,7 +67,7 @@ def forward_step(model, criterion, weight_dict: Dict[str, float], batch: dict):
         # one launch for the keep-gather + all 24 losses, one multiply + sum for the weighted total (engine.py:83-126)
         core._last_stacked = None
         assert len(targets) == keep.numel()
-        loss_dict = criterion.forward_fused(st, keep, targets, batch["inter_idx"], time_mask)
+        loss_dict = criterion.forward_fused(st, keep, targets, batch["inter_idx"], time_mask, aux=bool(getattr(core, "aux_loss", True)))
         loss = (criterion.last_loss_matrix * criterion.weight_matrix(weight_dict, st["pred_boxes"].shape[0], dev)).sum()
         return loss, loss_dict, raw, memory_cache
     outputs["pred_boxes"] = outputs["pred_boxes"][keep]

@@ -176,11 +176,12 @@ class ResNetTrunkFn(Function):
         N, _, H, W = x.shape
         srcs = (_hip.FrameSource * len(x.parts))()
         keep_alive = []
-        for fs, (t, idx) in zip(srcs, x.parts):
+        for fs, (t, idx), vhw in zip(srcs, x.parts, x.valid):
             t = t.detach().contiguous()
             keep_alive.append(t)
             fs.data, fs.dtype = t.data_ptr(), (_hip.TD_U8 if t.dtype == torch.uint8 else _hip.TD_F32)
             fs.n, fs.index = (idx.numel() if idx is not None else t.shape[0]), (idx.data_ptr() if idx is not None else None)
+            fs.valid_hw = vhw.data_ptr() if vhw is not None else None
         mean = inv_std = None
         if x.dtype == torch.uint8:  # the datasets' T.Normalize, on the device
             mean = (C.c_float * 3)(*body.pixel_mean)

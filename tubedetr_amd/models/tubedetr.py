@@ -44,6 +44,10 @@ def _parts(x):
     return list(x.parts) if isinstance(x, FrameSources) else [(x, None)]
 
 
+def _valid(x):
+    return list(x.valid) if isinstance(x, FrameSources) else [None]
+
+
 def _one_tensor(x):
     """The single un-indexed tensor behind ``x`` (a frame tensor, or a FrameSources wrapping exactly one)."""
     if isinstance(x, FrameSources):
@@ -138,7 +142,7 @@ class TubeDETR(nn.Module):
             perm, inv = self._dedupe_index(durations, samples_fast.tensors.device)
             assert perm.numel() == samples_fast.tensors.shape[0] and n_slow == sum(math.ceil(d / k) for d in durations)
             # (the permutation is an index list handed to the trunk's input kernel: the pixels are not copied)
-            both = NestedTensor(FrameSources([(_one_tensor(samples_fast.tensors), perm)]), samples_fast.mask[perm])
+            both = NestedTensor(FrameSources([(_one_tensor(samples_fast.tensors), perm)], _valid(samples_fast.tensors)), samples_fast.mask[perm])
             features, pos_all = self.backbone(both, n_slow)
             src_all, mask_all = features[-1].decompose()
             src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow]]
@@ -147,7 +151,8 @@ class TubeDETR(nn.Module):
             # slow (grad) and fast (no_grad, tubedetr.py:128-129) frames share the trunk weights: one launch sequence over
             # both, with the slow frames first; only they are saved-for / reached-by backward.
             n_slow = samples.tensors.shape[0]
-            both = NestedTensor(FrameSources(_parts(samples.tensors) + _parts(samples_fast.tensors)), torch.cat([samples.mask, samples_fast.mask]))
+            both = NestedTensor(FrameSources(_parts(samples.tensors) + _parts(samples_fast.tensors), _valid(samples.tensors) + _valid(samples_fast.tensors)),
+                                torch.cat([samples.mask, samples_fast.mask]))
             features, pos_all = self.backbone(both, n_slow)
             src_all, mask_all = features[-1].decompose()
             src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow]]
@@ -389,10 +394,12 @@ class SetCriterion(nn.Module):
             m = self._pm_cache[key] = torch.tensor(rows, dtype=torch.float32).to(device)
         return m
 
-    def forward_fused(self, stacked, keep, tgt_boxes, inter_idx, time_mask):
+    def forward_fused(self, stacked, keep, tgt_boxes, inter_idx, time_mask, aux: bool = True):
         """Same 24 values as ``forward`` from the decoder's stacked outputs (boxes [layers, b*t, 4] of every frame + the
         keep indices, sted [layers, b, t, 2], weights [layers, b, t, t]) in ONE kernel launch.  Returns the reference's
-        loss dict; ``self.last_loss_matrix`` ([layers, 4], differentiable) holds the same numbers for a fused weighted sum."""
+        loss dict; ``self.last_loss_matrix`` ([layers, 4], differentiable) holds the same numbers for a fused weighted sum.
+        ``aux=False`` (a model built without --aux_loss): only the last layer's keys, like the reference's loop over
+        ``outputs["aux_outputs"]`` (tubedetr.py:434-458) that then never runs."""
         boxes = stacked["pred_boxes"]
         sted = stacked["pred_sted"] if "sted" in self.losses else None
         weights = stacked["weights"] if "guided_attn" in self.losses else None
@@ -410,7 +417,7 @@ class SetCriterion(nn.Module):
         L = CriterionFn.apply(boxes, sted, weights, tgt_boxes, keep, tm_u8, pm_u8, inter_dev, num_boxes, float(self.sigma))
         self.last_loss_matrix = L
         losses, self._fused_keys = {}, set()
-        for l in range(nl):
+        for l in (range(nl) if aux else (nl - 1,)):
             sfx = "" if l == nl - 1 else f"_{l}"
             for j, c in enumerate(LOSS_COLUMNS):
                 if (c in ("loss_bbox", "loss_giou") and "boxes" in self.losses) or (c == "loss_sted" and sted is not None) or (c == "loss_guided_attn" and weights is not None):

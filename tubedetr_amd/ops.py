@@ -232,6 +232,16 @@ def linear_wgrad_batch(jobs) -> None:
     (no zero-initialisation needed).  g and x must stay alive until the stream has passed the launch."""
     if not jobs:
         return
+    # one launch per (dtype, device): the table carries ONE element size (a mixed queue - an fp32 head next to bf16 layers,
+    # TD_HIP_ROBERTA=0 - would otherwise be read with the wrong one)
+    key0 = (jobs[0][0].dtype, jobs[0][0].device)
+    if any((j[0].dtype, j[0].device) != key0 for j in jobs):
+        groups: dict = {}
+        for j in jobs:
+            groups.setdefault((j[0].dtype, j[0].device), []).append(j)
+        for sub in groups.values():
+            linear_wgrad_batch(sub)
+        return
     arr = (_hip.WgradJob * len(jobs))()
     for a, (g, x, dw_ptr, db_ptr) in zip(arr, jobs):
         M, K = x.shape

@@ -94,10 +94,14 @@ class FusedAdamWEMA:
         self.ema = None
         self.ema_decay = float(ema_decay)
         if ema_model is not None:
-            self.ema = self.flat_p.clone()
+            # the EMA buffer starts from ema_model's OWN weights (a resumed run loads checkpoint["model_ema"] into it before the
+            # optimizer is built, main.py:562-568), not from the model's
+            self.ema = torch.empty_like(self.flat_p)
             ema_named = dict(ema_model.named_parameters())
             for nme, off_, p in zip(self.names, self.offsets, self.params):
-                ema_named[nme].data = self.ema[off_ : off_ + p.numel()].view_as(p)
+                v = self.ema[off_ : off_ + p.numel()].view_as(p)
+                v.copy_(ema_named[nme].data)
+                ema_named[nme].data = v
         self.reducer = reducer
         if reducer is not None:
             assert [id(p) for p in reducer.params] == [id(p) for p in self.params], "reducer and optimizer must hold the same parameters in the same order"
@@ -111,7 +115,12 @@ class FusedAdamWEMA:
         self.param_groups = [{"lr": lr, "params": [p for p, g in zip(self.params, self.group_of) if g == 0]},
                              {"lr": lr_backbone, "params": [p for p, g in zip(self.params, self.group_of) if g == 1]},
                              {"lr": text_encoder_lr, "params": [p for p, g in zip(self.params, self.group_of) if g == 2]}]
-        self._lr_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        # learning rates change every step under the warm-up schedules: the host runs ahead of the stream, so the pinned
+        # staging buffer of upload i must not be rewritten before its async copy has been consumed - a small ring, each slot
+        # guarded by the event recorded behind its copy
+        self._lr_host = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._lr_ev = [None] * 4
+        self._lr_slot = 0
         self._lr_dev = torch.zeros(4, dtype=torch.float32, device=dev)
         self._lr_last = None
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -153,8 +162,14 @@ class FusedAdamWEMA:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         lrs = tuple(float(g["lr"]) for g in self.param_groups)
         if lrs != self._lr_last:  # three scalars, uploaded only when adjust_learning_rate changed them
-            self._lr_host[:3] = torch.tensor(lrs)
-            self._lr_dev.copy_(self._lr_host, non_blocking=True)
+            i = self._lr_slot = (self._lr_slot + 1) % len(self._lr_host)
+            if self._lr_ev[i] is not None:
+                self._lr_ev[i].synchronize()  # the copy that last read this staging slot (4 uploads ago) has completed
+            self._lr_host[i][:3] = torch.tensor(lrs)
+            self._lr_dev.copy_(self._lr_host[i], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._lr_ev[i] = ev
             self._lr_last = lrs
         L = _hip.lib()
         st = _hip.stream_ptr()
@@ -166,16 +181,64 @@ class FusedAdamWEMA:
                                        self.eps, self.weight_decay, self.ema_decay, st), "td_adamw_ema_step")
         invalidate_prepared()  # the kernels changed the weights behind torch's version counters: prepared bf16 copies are stale
 
+    # ---- checkpointing: torch.optim.AdamW's own layout (what the reference stores in checkpoint["optimizer"], main.py:681) ----
+    def _torch_order(self) -> List[int]:
+        """torch numbers the parameters group by group (main.py:381-405: everything else, backbone, text encoder)."""
+        return [i for g in (0, 1, 2) for i, gg in enumerate(self.group_of) if gg == g]
+
     def state_dict(self):
-        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_dev, "ema": self.ema,
-                "lrs": [g["lr"] for g in self.param_groups], "names": self.names}
+        """{"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} exactly like
+        ``torch.optim.AdamW(param_dicts).state_dict()``: a checkpoint written here resumes in the reference and vice versa.
+        (The EMA weights are not optimizer state: they live in ``ema_model.state_dict()``, checkpoint["model_ema"].)"""
+        order = self._torch_order()
+        step = float(self.step_dev.item())
+        active = self._active if self._active is not None else [True] * len(self.params)
+        state = {}
+        for ti, pi in enumerate(order):
+            if step == 0 or not active[pi]:
+                continue  # torch creates a parameter's state at its first update
+            o, p = self.offsets[pi], self.params[pi]
+            state[ti] = {"step": torch.tensor(step, dtype=torch.float32),
+                         "exp_avg": self.exp_avg[o : o + p.numel()].view_as(p).clone(),
+                         "exp_avg_sq": self.exp_avg_sq[o : o + p.numel()].view_as(p).clone()}
+        defaults = dict(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1.0, betas=self.betas, eps=self.eps,
+                                          weight_decay=self.weight_decay).param_groups[0])  # this torch version's key set
+        defaults.pop("params")
+        groups, base = [], 0
+        for g in range(3):
+            cnt = sum(1 for x in self.group_of if x == g)
+            groups.append(dict(defaults, lr=float(self.param_groups[g]["lr"]), params=list(range(base, base + cnt))))
+            base += cnt
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        assert sd["names"] == self.names
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.step_dev.copy_(sd["step"])
-        if self.ema is not None and sd.get("ema") is not None:
-            self.ema.copy_(sd["ema"])
-        for g, lr in zip(self.param_groups, sd["lrs"]):
-            g["lr"] = lr
+        if "names" in sd and "exp_avg" in sd:  # flat format written by earlier versions of this class
+            assert sd["names"] == self.names
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.step_dev.copy_(sd["step"])
+            if self.ema is not None and sd.get("ema") is not None:
+                self.ema.copy_(sd["ema"])
+            for g, lr in zip(self.param_groups, sd["lrs"]):
+                g["lr"] = lr
+            return
+        order = self._torch_order()
+        groups = sd["param_groups"]
+        assert len(groups) == 3 and [len(g["params"]) for g in groups] == [sum(1 for x in self.group_of if x == g) for g in range(3)], \
+            "optimizer state does not match the model's three parameter groups (main.py:381-405)"
+        flat_ids = [i for g in groups for i in g["params"]]
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        step = 0.0
+        for ti, pi in zip(flat_ids, order):
+            st = sd["state"].get(ti)
+            if st is None:
+                continue
+            o, p = self.offsets[pi], self.params[pi]
+            self.exp_avg[o : o + p.numel()].view_as(p).copy_(st["exp_avg"])
+            self.exp_avg_sq[o : o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+            step = max(step, float(st["step"]))
+        self.step_dev.fill_(int(step))
+        for g, saved in zip(self.param_groups, groups):
+            g["lr"] = float(saved["lr"])
+        self._lr_last = None

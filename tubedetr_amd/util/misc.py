@@ -93,10 +93,18 @@ class FrameSources:
     of every contributed frame.  The slow clip and the fast frames of a step can then be two views of ONE buffer
     (slow = video[::k], datasets/vidstg.py:250-251) and uint8 pixels are normalised on the device
     (td_frames_to_nhwc) - no torch.cat / index copy of hundreds of MB of pixels, a quarter of the host-to-device bytes.
-    Quacks like the ``tensors`` field of a NestedTensor where the trunk needs it (shape, device, dtype, to)."""
+    Quacks like the ``tensors`` field of a NestedTensor where the trunk needs it (shape, device, dtype, to).
 
-    def __init__(self, parts):
+    ``valid`` (optional, one entry per part: device int32 ``(n_src, 2)`` or None): the (rows, columns) of every SOURCE frame
+    that hold pixels when videos of different sizes were padded to a common H x W as raw uint8; the input kernel writes
+    exactly 0 outside, which is what padding the already NORMALISED frames with zeros gives (util/misc.py:158-170)."""
+
+    def __init__(self, parts, valid=None):
         self.parts = [(t, (i.to(torch.int32).contiguous() if i is not None else None)) for t, i in parts]
+        self.valid = [None] * len(self.parts) if valid is None else [(v.to(torch.int32).contiguous() if v is not None else None) for v in valid]
+        assert len(self.valid) == len(self.parts)
+        for (t, _), v in zip(self.parts, self.valid):
+            assert v is None or tuple(v.shape) == (t.shape[0], 2), "valid: (rows, columns) per source frame"
         t0 = self.parts[0][0]
         assert all(t.dim() == 4 and t.shape[1:] == t0.shape[1:] and t.dtype == t0.dtype for t, _ in self.parts), "sources must share C, H, W and dtype"
         assert t0.dtype in (torch.float32, torch.uint8), "frames must be fp32 (normalised) or uint8 pixels"
@@ -118,10 +126,12 @@ class FrameSources:
         return self.parts[0][0].dtype
 
     def to(self, device, non_blocking: bool = False):
-        return FrameSources([(t.to(device, non_blocking=non_blocking), (i.to(device, non_blocking=non_blocking) if i is not None else None)) for t, i in self.parts])
+        return FrameSources([(t.to(device, non_blocking=non_blocking), (i.to(device, non_blocking=non_blocking) if i is not None else None)) for t, i in self.parts],
+                            [(v.to(device, non_blocking=non_blocking) if v is not None else None) for v in self.valid])
 
     def materialize(self) -> torch.Tensor:
-        """The concatenated (N, 3, H, W) tensor the sources describe (tests / fallbacks)."""
+        """The concatenated (N, 3, H, W) tensor the sources describe (tests / fallbacks); raw values - the zeroing of
+        the padded area described by ``valid`` happens where the pixels are normalised."""
         return torch.cat([(t[i.long()] if i is not None else t) for t, i in self.parts])
 
 
