@@ -1,0 +1,154 @@
+"""The bf16-only kernel instances that carry the benchmarked step, at EXACTLY the shapes bench.py launches them with
+(8 clips of cfg3 per step = a 1 000-frame trunk forward, a 200-frame trunk backward), each against a plain PyTorch fp32
+evaluation of the same op on the same bf16-rounded operands:
+
+  conv_gemm_big_kernel<256, true>   layer3 3x3        M = 484 000, N = 256, K = 2304      forward and input gradient
+  conv_gemm_big_kernel<256, false>  layer3 conv1      M = 484 000, N = 256, K = 1024
+  pw_resident_kernel                layer3 conv3      M = 484 000, N = 1024, K = 256      + residual + ReLU
+  pw_resident_kernel                layer1 conv3      M = 7 744 000, N = 256, K = 64      + residual + ReLU
+  pw_chain_kernel                   layer1 conv3 -> next conv1, M = 7 744 000
+  conv_wgrad_wide_batch_kernel      the trunk's batched weight-gradient table at 200 slow frames (one job per layer shape)
+
+The forward-type results are compared on sampled row ranges (first / middle / last rows of the launch: tile 0, an interior
+tile, the ragged last tile) - the reference of a whole 484 000 x 2304 launch would be another GEMM library's result, not
+a check; weight gradients are full reductions and are compared whole, against fp32 matmuls over the same rows.
+Tolerance: operands are identical bf16 values on both sides and both accumulate in fp32, so only the output rounding
+(bf16: 2^-8 relative) and the summation order differ: max |err| <= 1.2e-2 max |ref| (the module-wide bf16 bound)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1.2e-2
+FRAMES_FWD, FRAMES_BWD = 1000, 200  # 8 clips x (100 fast + 25 slow) frames forward, 8 x 25 slow frames backward
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double(), ref.detach().double()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def _rand(shape, g, scale=1.0, relu=False):
+    x = torch.randn(shape, generator=g, device=dev(), dtype=torch.float32) * scale
+    if relu:
+        x = x.relu()  # trunk activations are post-ReLU (half zeros): what the kernels see in the network
+    return x.to(torch.bfloat16)
+
+
+def _frames_sample(n):
+    return sorted({0, 1, n // 2, n - 2, n - 1})
+
+
+def test_layer3_conv3x3_forward_and_dgrad_at_bench_shape():
+    from tubedetr_amd import ops
+
+    g = torch.Generator(device=dev()).manual_seed(3)
+    N, H, W, C = FRAMES_FWD, 22, 22, 256
+    x = _rand((N, H, W, C), g, relu=True)
+    w = (torch.randn(C, C, 3, 3, generator=g, device=dev()) / math.sqrt(9 * C)).to(torch.bfloat16).float()
+    bias = torch.randn(C, generator=g, device=dev())
+    wf, wd, b_out, _ = ops.weight_prep(w, torch.bfloat16, bias=bias)
+    y = ops.conv_fwd(x, wf, b_out, 3, 3, 1, 1, relu=True)
+    assert y.shape == (N, H, W, C)
+    fr = _frames_sample(N)
+    xs = x[fr].float().permute(0, 3, 1, 2)
+    ref = F.relu(F.conv2d(xs, w, bias, padding=1)).permute(0, 2, 3, 1)
+    assert rel_err(y[fr].float(), ref) < TOL
+    # input gradient at the backward's shape (200 frames: 379 row tiles of 256 on 256 CUs), ReLU mask of the producing layer fused
+    Nb = FRAMES_BWD
+    gy = _rand((Nb, H, W, C), g)
+    act = _rand((Nb, H, W, C), g, relu=True)
+    dx = ops.conv_dgrad(gy, wd, (H, W), 3, 3, 1, 1, mask_src=act)
+    fr = _frames_sample(Nb)
+    gs = gy[fr].float().permute(0, 3, 1, 2)
+    ref = F.conv_transpose2d(gs, w, padding=1).permute(0, 2, 3, 1) * (act[fr].float() > 0)
+    assert rel_err(dx[fr].float(), ref) < TOL
+
+
+@pytest.mark.parametrize("shape", [("layer3.conv1 (256-row tiles)", 484000, 1024, 256, False), ("layer3.conv3 (persistent)", 484000, 256, 1024, True),
+                                   ("layer1.conv3 (persistent)", 7744000, 64, 256, True), ("layer2.conv1 (256-row tiles, 128 wide)", 1936000, 512, 128, False)])
+def test_pointwise_layers_at_bench_shape(shape):
+    from tubedetr_amd import ops
+
+    _, M, K, Nc, with_res = shape
+    g = torch.Generator(device=dev()).manual_seed(5)
+    x = _rand((M, K), g, relu=True)
+    w = (torch.randn(Nc, K, generator=g, device=dev()) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(Nc, generator=g, device=dev())
+    res = _rand((M, Nc), g, relu=True) if with_res else None
+    y = ops.linear_fwd(x, w, bias, residual=res, relu=True)
+    for a, b in ((0, 4096), (M // 2 - 1000, M // 2 + 3000), (M - 4096, M)):
+        ref = x[a:b].float() @ w.float().t() + bias
+        if res is not None:
+            ref = ref + res[a:b].float()
+        assert rel_err(y[a:b].float(), ref.relu()) < TOL, (shape[0], a)
+
+
+def test_layer1_chain_at_bench_shape():
+    from tubedetr_amd import ops
+
+    g = torch.Generator(device=dev()).manual_seed(7)
+    M = 7744000
+    x = _rand((M, 64), g, relu=True)
+    w1 = (torch.randn(256, 64, generator=g, device=dev()) / 8).to(torch.bfloat16)
+    w2 = (torch.randn(64, 256, generator=g, device=dev()) / 16).to(torch.bfloat16)
+    b1, b2 = torch.randn(256, generator=g, device=dev()), torch.randn(64, generator=g, device=dev())
+    res = _rand((M, 256), g, relu=True)
+    o1, o2 = ops.pw_chain(x, w1, b1, res, w2, b2)
+    for a, b in ((0, 4096), (M // 2, M // 2 + 4096), (M - 4000, M)):
+        r1 = (x[a:b].float() @ w1.float().t() + b1 + res[a:b].float()).relu()
+        assert rel_err(o1[a:b].float(), r1) < TOL
+        r2 = (o1[a:b].float() @ w2.float().t() + b2).relu()  # the second layer consumes the bf16-rounded first output
+        assert rel_err(o2[a:b].float(), r2) < TOL
+
+
+def _wgrad_ref(gy, x, R, stride, pad):
+    """dW [Co, Ci, R, R] = sum over output pixels of gy^T x(shifted): fp32 matmuls over the same rows (NHWC operands)."""
+    N, H, W, Ci = x.shape
+    _, Ho, Wo, Co = gy.shape
+    G = gy.float().reshape(-1, Co)
+    xp = F.pad(x.float(), (0, 0, pad, pad, pad, pad))
+    dW = torch.empty((Co, Ci, R, R), dtype=torch.float32, device=x.device)
+    for r in range(R):
+        for s in range(R):
+            xs = xp[:, r : r + (Ho - 1) * stride + 1 : stride, s : s + (Wo - 1) * stride + 1 : stride, :].reshape(-1, Ci)
+            dW[:, :, r, s] = G.t() @ xs
+    return dW
+
+
+def test_trunk_weight_gradient_table_at_bench_shape():
+    """One job per distinct layer shape of the trunk's backward at 200 slow frames of res 352 (layer2: 44 x 44, layer3: 22 x 22,
+    layer4: 11 x 11), all in ONE td_conv_wgrad_batch launch like td_resnet_bwd issues it (wide tiles, split and unsplit work
+    items, FrozenBN scale folded, parameter-layout output)."""
+    from tubedetr_amd import ops
+
+    g = torch.Generator(device=dev()).manual_seed(9)
+    Nb = FRAMES_BWD
+    # (Ci, H, W, Co, R, stride, pad)
+    shapes = [(256, 88, 88, 128, 1, 1, 0), (128, 88, 88, 128, 3, 2, 1), (128, 44, 44, 512, 1, 1, 0), (256, 88, 88, 512, 1, 2, 0),
+              (512, 44, 44, 128, 1, 1, 0), (128, 44, 44, 128, 3, 1, 1),
+              (512, 44, 44, 256, 1, 1, 0), (256, 44, 44, 256, 3, 2, 1), (256, 22, 22, 1024, 1, 1, 0), (512, 44, 44, 1024, 1, 2, 0),
+              (1024, 22, 22, 256, 1, 1, 0), (256, 22, 22, 256, 3, 1, 1),
+              (1024, 22, 22, 512, 1, 1, 0), (512, 22, 22, 512, 3, 2, 1), (512, 11, 11, 2048, 1, 1, 0), (1024, 22, 22, 2048, 1, 2, 0),
+              (2048, 11, 11, 512, 1, 1, 0), (512, 11, 11, 512, 3, 1, 1)]
+    jobs, keep = [], []
+    for i, (Ci, H, W, Co, R, st, pad) in enumerate(shapes):
+        Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+        x = _rand((Nb, H, W, Ci), g, relu=True)
+        gy = _rand((Nb, Ho, Wo, Co), g, scale=0.05)
+        scale = torch.rand(Co, generator=g, device=dev()) + 0.5
+        jobs.append((gy, x, R, R, st, pad, scale, Ci))
+        keep.append((gy, x, R, st, pad, scale))
+    outs = ops.conv_wgrad_batch(jobs)
+    torch.cuda.synchronize()
+    for got, (gy, x, R, st, pad, scale), shp in zip(outs, keep, shapes):
+        ref = _wgrad_ref(gy, x, R, st, pad) * scale.view(-1, 1, 1, 1)
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) < 2e-3, shp  # fp32 results of identical bf16 operands: only the summation order differs

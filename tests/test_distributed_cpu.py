@@ -199,9 +199,44 @@ def _flat_staged_overlap(rank, world):
         assert m.never.weight.grad is None
 
 
-@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce, _flat_rank_dependent_usage, _flat_staged_overlap])
+def _eval_collectives(rank, world):
+    """util/dist.py:34-122 of the reference: all_gather of picklable per-rank results of DIFFERENT sizes (the evaluators'
+    prediction dicts) and reduce_dict of the loss dict (sum / average, one collective, key order independent of the rank)."""
+    from tubedetr_amd.util.dist import all_gather, get_world_size, reduce_dict
+
+    assert get_world_size() == world
+    mine = {"rank": rank, "preds": {f"video_{rank}_{i}": {"sted": [i, i + rank + 1], "boxes": torch.arange(4.0 * (i + 1)).view(-1, 4) + rank} for i in range(3 + 5 * rank)},
+            "blob": "x" * (17 + 1000 * rank)}
+    got = all_gather(mine)
+    assert len(got) == world and [g["rank"] for g in got] == list(range(world))
+    for r, g in enumerate(got):
+        assert len(g["preds"]) == 3 + 5 * r and len(g["blob"]) == 17 + 1000 * r
+        assert g["preds"][f"video_{r}_2"]["sted"] == [2, 3 + r]
+        assert torch.equal(g["preds"][f"video_{r}_1"]["boxes"], torch.arange(8.0).view(-1, 4) + r)
+    # ranks insert the keys in different orders; values differ per rank
+    keys = ["loss_bbox", "loss_giou", "loss_sted", "loss_guided_attn_3"]
+    order = keys if rank == 0 else keys[::-1]
+    d = {k: torch.tensor(float(keys.index(k) + 1) * (rank + 1)) for k in order}
+    avg = reduce_dict(d, average=True)
+    tot = reduce_dict(d, average=False)
+    ranks_sum = sum(r + 1 for r in range(world))
+    for k in keys:
+        assert abs(tot[k].item() - (keys.index(k) + 1) * ranks_sum) < 1e-6
+        assert abs(avg[k].item() - (keys.index(k) + 1) * ranks_sum / world) < 1e-6
+    assert all(torch.equal(d[k], torch.tensor(float(keys.index(k) + 1) * (rank + 1))) for k in keys)  # inputs untouched
+
+
+@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce, _flat_rank_dependent_usage, _flat_staged_overlap,
+                                _eval_collectives])
 def test_world_size_2_gloo(fn):
     _run(fn)
+
+
+def test_eval_collectives_single_process():
+    from tubedetr_amd.util.dist import all_gather, reduce_dict
+
+    d = {"a": torch.tensor(1.0)}
+    assert all_gather({"x": 1}) == [{"x": 1}] and reduce_dict(d) is d  # world size 1: identity, like util/dist.py:44-45,108-109
 
 
 def test_bench_batches_are_sharded_by_rank():

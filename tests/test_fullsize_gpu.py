@@ -1,7 +1,7 @@
 """Parity at BASELINE.json's FULL sizes on a real MI355X (the shapes bench.py measures, not fixture sizes):
 
   cfg3  T=100 k=4 res=352 L=30  (headline)          cfg2  T=64 k=2 res=224 L=20, fast branch on
-  cfg5  cfg3 with --no_fast, and cfg3 with --no_tsa
+  cfg5  cfg3 with --no_fast, and cfg3 with --no_tsa   cfg1  T=8 k=5 res=224 L=20 (the reference's CPU-runnable case)
 
 (1) exact-fp32 mode of the HIP path against the CPU oracle's forward on the same seeded clip and weights: box / start-end
     logits and attention weights of all six decoder layers within 1e-3, attention argmax indices exact, the 24 losses.
@@ -10,6 +10,11 @@
     bound, the whole gradient's cosine >= 0.995 and length within 3 %, and for EVERY trainable parameter cosine >= 0.97 and
     norm within 15 % (measured worst cases recorded in the report; parameters whose gradient norm is below a quarter of the
     median one are judged on the absolute scale: error <= 5 % of the median norm).
+(3) exact-fp32 mode BACKWARD against the oracle's autograd at full size (cfg2, cfg1): every trainable parameter's gradient.
+(4) the BENCHMARKED batch: 8 clips per step at cfg3 (bench.py's default), fp32 forward against the oracle run per clip
+    (videos are independent: batch statistics do not exist in the model, FrozenBN), and the bf16 step at 8 clips - forward
+    and backward, the instances that carry the throughput number (256-row tiles, persistent / chained pointwise kernels,
+    wide-tile weight gradients, lean attention) - against the exact-fp32 mode run clip by clip.
 This exercises, under an oracle, exactly what `bench.py` launches: td_resnet_fwd over 125 frames with the save layout,
 the 93-job batched weight-gradient table, the persistent pointwise instance, M = 60 500-row tiles.
 A summary of every comparison is written to gpurun_out/fullsize_report.json.
@@ -25,6 +30,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOGIT_TOL = 1e-3
 FULL = {
+    "cfg1": dict(T=8, res=224, k=5, L=20, fast=True, no_tsa=False),  # BASELINE configs[0]: the reference's own CPU-runnable case (T not a multiple of k)
     "cfg3": dict(T=100, res=352, k=4, L=30, fast=True, no_tsa=False),
     "cfg2": dict(T=64, res=224, k=2, L=20, fast=True, no_tsa=False),
     "cfg5_no_fast": dict(T=100, res=352, k=4, L=30, fast=False, no_tsa=False),
@@ -51,21 +57,21 @@ def _cfg(c):
     return OracleConfig(stride=c["k"], fast=c["fast"], no_tsa=c["no_tsa"])
 
 
-def _inputs(c):
+def _inputs(c, seed=CLIP_SEED):
     from oracle.weights import fill_state, state_spec, synthetic_batch
 
     cfg = _cfg(c)
     sd = fill_state(state_spec(cfg), WEIGHT_SEED)
-    batch = synthetic_batch(T=c["T"], res=c["res"], k=c["k"], L=c["L"], seed=CLIP_SEED, fast=True)  # the dataset always yields the fast frames
+    batch = synthetic_batch(T=c["T"], res=c["res"], k=c["k"], L=c["L"], seed=seed, fast=True)  # the dataset always yields the fast frames
     return cfg, sd, batch
 
 
-def _oracle_forward(c):
+def _oracle_forward(c, seed=CLIP_SEED):
     """encode once per (clip, weights, fast) - --no_tsa only changes the decoder, so it shares cfg3's encode."""
     from oracle import tubedetr_oracle as O
 
-    cfg, sd, batch = _inputs(c)
-    key = (c["T"], c["res"], c["k"], c["L"], c["fast"])
+    cfg, sd, batch = _inputs(c, seed)
+    key = (c["T"], c["res"], c["k"], c["L"], c["fast"], seed)
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
     with torch.no_grad():
         if key not in _ORACLE_ENC:
@@ -199,4 +205,198 @@ def test_bf16_gradients_follow_fp32_mode_at_full_size(name):
     assert rec["global_cosine"] >= 0.995 and abs(rec["global_norm_ratio"] - 1.0) <= 0.03, rec
     bad = [(s[0], s[1], s[2], s[4]) for s in stats if (s[1] < 0.97 or abs(s[2]) > 0.15) and s[4] > 0.25 * med]
     bad += [(s[0], s[1], s[2], s[4]) for s in stats if s[4] <= 0.25 * med and s[3] * s[4] > 0.05 * med]
+    assert not bad, bad[:10]
+
+
+# ---- (3) full-size backward against the oracle's autograd ----------------------------------------------------------
+@pytest.mark.parametrize("name", ["cfg2", "cfg1"])
+def test_fp32_gradients_match_oracle_at_full_size(name):
+    """loss.backward() of the exact-fp32 HIP path against the CPU oracle's autograd on the same clip and weights, at a
+    BASELINE size: every trainable parameter's gradient (cosine and length), not a self-comparison."""
+    from oracle import tubedetr_oracle as O
+    from oracle.weights import fill_state, state_spec, is_trainable
+    from tubedetr_amd.harness import batch_to, forward_step
+
+    c = FULL[name]
+    cfg, _, batch = _inputs(c)
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
+    sd = fill_state(state_spec(cfg), WEIGHT_SEED, requires_grad=True)
+    loss_ref, _, _, _ = O.train_step(sd, cfg, batch)
+    loss_ref.backward()
+    model, criterion, weight_dict, Tok = _model(cfg, {k_: v.detach() for k_, v in sd.items()}, torch.float32)
+    model.transformer.tokenizer = Tok(batch["input_ids"], batch["attention_mask"])
+    loss, _, _, _ = forward_step(model, criterion, weight_dict, batch_to(batch, torch.device("cuda:0")))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * abs(loss_ref.item())
+    params = dict(model.named_parameters())
+    stats = []
+    ref_norms = [sd[k_].grad.double().norm().item() for k_ in sd if sd[k_].grad is not None]
+    top = max(ref_norms)
+    for k_, v in sd.items():
+        if k_ not in params or not params[k_].requires_grad:
+            continue
+        g_ref, g = v.grad, params[k_].grad
+        assert (g_ref is None) == (g is None), k_  # RoBERTa's pooler on both sides
+        if g_ref is None:
+            continue
+        assert is_trainable(k_), k_
+        a, b_ = g_ref.double().flatten(), g.double().cpu().flatten()
+        na, nb = a.norm().item(), b_.norm().item()
+        if na <= 1e-7 * top:  # numerically zero in fp32 (softmax-invariant key biases): no direction to compare
+            assert nb <= 1e-5 * top, (k_, na, nb)
+            continue
+        stats.append((k_, (a @ b_).item() / (na * nb + 1e-300), nb / na - 1.0, na))
+    stats.sort(key=lambda s_: s_[1])
+    rec = {"loss": loss.item(), "loss_oracle": loss_ref.item(), "checked_parameters": len(stats), "min_cosine": stats[0][1],
+           "max_abs_norm_ratio_err": max(abs(s_[2]) for s_ in stats),
+           "worst": [(s_[0], round(s_[1], 7), round(s_[2], 6), f"{s_[3]:.3e}") for s_ in stats[:6]]}
+    _report("fp32_grad_vs_oracle/" + name, rec)
+    assert len(stats) > 300
+    # two fp32 implementations of the same graph (different summation orders through ~130 layers, min / max / sign kinks in the
+    # losses): direction to 1e-3, length to 1 % for every parameter
+    bad = [s_ for s_ in stats if s_[1] < 0.999 or abs(s_[2]) > 1e-2]
+    assert not bad, bad[:10]
+
+
+# ---- (4) the benchmarked batch: 8 clips per step ----------------------------------------------------------------------
+BENCH_CLIPS = 8
+BENCH_SEEDS = [CLIP_SEED, CLIP_SEED + 1, CLIP_SEED + 2, CLIP_SEED + 3]
+BENCH_PATTERN = [0, 1, 2, 3, 3, 1, 0, 2]  # which distinct clip sits at each of the 8 batch positions (neighbours always differ)
+
+
+def _stitch(batches):
+    out = {}
+    for k_ in ("frames", "frames_mask", "frames_fast", "fast_mask", "input_ids", "attention_mask", "target_boxes"):
+        out[k_] = torch.cat([b_[k_] for b_ in batches])
+    out["durations"] = [d for b_ in batches for d in b_["durations"]]
+    out["inter_idx"] = [list(x) for b_ in batches for x in b_["inter_idx"]]
+    return out
+
+
+def _per_clip(x, n):
+    return x.reshape(n, x.shape[0] // n, *x.shape[1:])
+
+
+def test_bench_batch_fp32_forward_matches_oracle_per_clip():
+    """bench.py's workload (8 clips of cfg3 per step: a 1 000-frame trunk pass, M = 484 000 / 7 744 000-row GEMMs) in the
+    exact-fp32 mode against the oracle's forward of each clip."""
+    from tubedetr_amd.harness import batch_to, forward_step
+
+    c = FULL["cfg3"]
+    refs = [_oracle_forward(c, s_) for s_ in BENCH_SEEDS]
+    cfg, sd = refs[0][0], refs[0][1]
+    batch = _stitch([refs[i][2] for i in BENCH_PATTERN])
+    torch.cuda.empty_cache()
+    model, criterion, weight_dict, Tok = _model(cfg, sd, torch.float32)
+    model.transformer.tokenizer = Tok(batch["input_ids"], batch["attention_mask"])
+    with torch.no_grad():
+        _, ld, out, _ = forward_step(model, criterion, weight_dict, batch_to(batch, torch.device("cuda:0")))
+    torch.cuda.synchronize()
+    rec = {"clips": BENCH_CLIPS}
+    layers = out["aux_outputs"] + [out]
+    for key in ("pred_boxes", "pred_sted", "weights", "ca_weights"):
+        err, agree = 0.0, True
+        for l, a in enumerate(layers):
+            got = _per_clip(a[key].float().cpu(), BENCH_CLIPS)
+            for pos, ci in enumerate(BENCH_PATTERN):
+                o_ref = refs[ci][3]
+                b_ = (o_ref["aux_outputs"] + [o_ref])[l][key]
+                b_ = b_.reshape(got[pos].shape)
+                err = max(err, (got[pos] - b_).abs().max().item())
+                if key in ("weights", "ca_weights") and b_.shape[-1] > 1:
+                    top2 = b_.topk(2, dim=-1).values
+                    decided = (top2[..., 0] - top2[..., 1]) > 4e-5
+                    agree = agree and bool((got[pos].argmax(-1) == b_.argmax(-1))[decided].all())
+        rec["max_err_" + key] = err
+        assert err < LOGIT_TOL, (key, err)
+        assert agree, key
+    # every loss of the batch = mean of the per-clip losses (equal durations, every frame annotated)
+    worst = 0.0
+    for k_ in refs[0][4]:
+        want = sum(refs[ci][4][k_].item() for ci in BENCH_PATTERN) / BENCH_CLIPS
+        rel = abs(ld[k_].item() - want) / max(1.0, abs(want))
+        worst = max(worst, rel)
+        assert rel < 1e-3, (k_, ld[k_].item(), want)
+    rec["max_rel_err_losses"] = worst
+    _report("fp32_vs_oracle/cfg3_x8_clips", rec)
+
+
+def test_bench_batch_bf16_step_follows_fp32_per_clip():
+    """The benchmarked step itself - bf16, 8 clips, forward + backward - against the exact-fp32 mode run clip by clip (the
+    fp32 activations of 8 clips do not fit next to each other; the batch gradient is the mean of the per-clip gradients:
+    every loss is normalised by the batch's box / video count)."""
+    from tubedetr_amd.harness import batch_to, forward_step
+
+    c = FULL["cfg3"]
+    dev = torch.device("cuda:0")
+    singles = [_inputs(c, s_) for s_ in BENCH_SEEDS]
+    cfg, sd = singles[0][0], singles[0][1]
+    torch.cuda.empty_cache()
+    model, criterion, weight_dict, Tok = _model(cfg, sd, torch.float32)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    params = [p for p in model.parameters() if p.requires_grad]
+    weight = [BENCH_PATTERN.count(i) / BENCH_CLIPS for i in range(len(BENCH_SEEDS))]
+    g32 = [None] * len(params)
+    l32 = 0.0
+    logits32 = {}
+    for i, (_, _, b1) in enumerate(singles):
+        model.transformer.tokenizer = Tok(b1["input_ids"], b1["attention_mask"])
+        for p in params:
+            p.grad = None
+        loss, _, out, _ = forward_step(model, criterion, weight_dict, batch_to(b1, dev))
+        loss.backward()
+        l32 += weight[i] * loss.item()
+        logits32[i] = (out["pred_boxes"].float().clone(), out["pred_sted"].float().clone())
+        for j, p in enumerate(params):
+            if p.grad is not None:
+                g32[j] = p.grad.detach() * weight[i] if g32[j] is None else g32[j] + p.grad.detach() * weight[i]
+    for p in params:
+        p.grad = None
+    del loss, out
+    torch.cuda.empty_cache()
+    batch = _stitch([singles[i][2] for i in BENCH_PATTERN])
+    model.set_compute_dtype(torch.bfloat16)
+    model.transformer.tokenizer = Tok(batch["input_ids"], batch["attention_mask"])
+    loss, _, out, _ = forward_step(model, criterion, weight_dict, batch_to(batch, dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    l16 = loss.item()
+    g16 = [None if p.grad is None else p.grad.detach() for p in params]
+    box16, sted16 = _per_clip(out["pred_boxes"].float(), BENCH_CLIPS), _per_clip(out["pred_sted"].float(), BENCH_CLIPS)
+    rec = {"clips": BENCH_CLIPS, "loss_fp32_per_clip_mean": l32, "loss_bf16": l16, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+    rec["box_err"] = max((box16[pos] - logits32[ci][0].reshape(box16[pos].shape)).abs().max().item() for pos, ci in enumerate(BENCH_PATTERN))
+    rec["sted_err"] = max((sted16[pos] - logits32[ci][1].reshape(sted16[pos].shape)).abs().max().item() for pos, ci in enumerate(BENCH_PATTERN))
+    smax = max(v[1].abs().max().item() for v in logits32.values())
+    assert rec["box_err"] < 0.05 and rec["sted_err"] < 0.1 * max(1.0, smax), rec
+    assert abs(l16 - l32) < 0.02 * abs(l32), rec
+    norms = torch.stack([g.double().norm() for g in g32 if g is not None])
+    med, floor = norms.median().item(), 1e-6 * norms.max().item()
+    stats, dot, n32, n16 = [], 0.0, 0.0, 0.0
+    for n, a, b_ in zip(names, g32, g16):
+        assert (a is None) == (b_ is None), n
+        if a is None:
+            continue
+        assert torch.isfinite(b_).all(), n
+        ad, bd = a.double().flatten(), b_.double().flatten()
+        na, nb = ad.norm().item(), bd.norm().item()
+        dot += (ad @ bd).item()
+        n32 += na * na
+        n16 += nb * nb
+        if na <= floor:
+            continue
+        stats.append((n, (ad @ bd).item() / (na * nb + 1e-300), nb / na - 1.0, (ad - bd).norm().item() / na, na))
+    stats.sort(key=lambda s_: s_[1])
+    rec["checked_parameters"] = len(stats)
+    rec["global_cosine"] = dot / ((n32 ** 0.5) * (n16 ** 0.5))
+    rec["global_norm_ratio"] = (n16 / n32) ** 0.5
+    rec["min_cosine"] = stats[0][1]
+    rec["max_abs_norm_ratio_err"] = max(abs(s_[2]) for s_ in stats)
+    rec["worst_cosine"] = [(s_[0], round(s_[1], 5), round(s_[2], 4), f"{s_[4]:.3e}") for s_ in stats[:8]]
+    _report("bf16_vs_fp32/cfg3_x8_clips", rec)
+    assert len(stats) > 300
+    # same bounds as the one-clip comparison above (test_bf16_gradients_follow_fp32_mode_at_full_size)
+    assert rec["global_cosine"] >= 0.995 and abs(rec["global_norm_ratio"] - 1.0) <= 0.03, rec
+    bad = [(s_[0], s_[1], s_[2], s_[4]) for s_ in stats if (s_[1] < 0.97 or abs(s_[2]) > 0.15) and s_[4] > 0.25 * med]
+    bad += [(s_[0], s_[1], s_[2], s_[4]) for s_ in stats if s_[4] <= 0.25 * med and s_[3] * s_[4] > 0.05 * med]
     assert not bad, bad[:10]

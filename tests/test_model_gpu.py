@@ -238,3 +238,33 @@ def test_hip_graph_replay_matches_eager_step(text_stream):
         checked += 1
     assert not bad, bad[:12]
     assert checked > 300
+
+
+def test_no_grad_trunk_pass_is_chunked_identically(monkeypatch):
+    """A no-grad trunk pass over more frames than one 32-bit buffer descriptor can address (the 800 fast frames of an fp32
+    8-clip batch) is cut into chunks: same features as the single pass, for indexed / multi-part / uint8-with-extents sources."""
+    import tubedetr_amd
+    from tubedetr_amd.models import build_model
+    from tubedetr_amd.util.misc import FrameSources
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model, _, _ = build_model(tubedetr_amd.default_args(stride=2, resnet_layers=(1, 1, 1, 1), enc_layers=1, dec_layers=1))
+    model.to(dev).eval()
+    body = model.backbone[0].body
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(5, 3, 32, 48, generator=g).to(dev)
+    b = torch.randn(4, 3, 32, 48, generator=g).to(dev)
+    idx = torch.tensor([4, 0, 2], dtype=torch.int32, device=dev)
+    u8 = torch.randint(0, 256, (6, 3, 32, 48), generator=g, dtype=torch.uint8).to(dev)
+    vhw = torch.tensor([[32, 48], [20, 48], [32, 30], [32, 48], [16, 16], [32, 48]], dtype=torch.int32, device=dev)
+    cases = [FrameSources([(a, idx), (b, None)]), FrameSources([(u8, None)], [vhw]), FrameSources([(u8, torch.tensor([5, 1, 1, 4, 2], dtype=torch.int32, device=dev))], [vhw])]
+    for dt in (torch.float32, torch.bfloat16):
+        for fs in cases:
+            with torch.no_grad():
+                monkeypatch.delenv("TD_TRUNK_MAX_FRAMES", raising=False)
+                whole = body(fs, dt)
+                monkeypatch.setenv("TD_TRUNK_MAX_FRAMES", "2")
+                parts = body(fs, dt)
+            assert whole.shape == parts.shape == (fs.n_frames, 1, 2, 2048)
+            assert torch.equal(whole, parts)

@@ -174,14 +174,6 @@ class ResNetTrunkFn(Function):
             x = FrameSources([((x if x.dtype == torch.uint8 else x.float()).contiguous(), None)])
         assert len(x.shape) == 4 and x.shape[1] == 3, "frames must be (N,3,H,W)"
         N, _, H, W = x.shape
-        srcs = (_hip.FrameSource * len(x.parts))()
-        keep_alive = []
-        for fs, (t, idx), vhw in zip(srcs, x.parts, x.valid):
-            t = t.detach().contiguous()
-            keep_alive.append(t)
-            fs.data, fs.dtype = t.data_ptr(), (_hip.TD_U8 if t.dtype == torch.uint8 else _hip.TD_F32)
-            fs.n, fs.index = (idx.numel() if idx is not None else t.shape[0]), (idx.data_ptr() if idx is not None else None)
-            fs.valid_hw = vhw.data_ptr() if vhw is not None else None
         mean = inv_std = None
         if x.dtype == torch.uint8:  # the datasets' T.Normalize, on the device
             mean = (C.c_float * 3)(*body.pixel_mean)
@@ -190,10 +182,6 @@ class ResNetTrunkFn(Function):
         preps = [prepared(c.weight, dt, bn=bn.fold(), need_dgrad=c.weight.requires_grad, cpad=vec if i == 0 else None)
                  for i, (c, bn) in enumerate(convs)]
         nb = (C.c_int * 4)(*body.layers)
-        nbytes = L.td_resnet_fwd_ws_bytes(N, H, W, nb, code, save)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        feat_p = C.c_void_p()
-        hw = (C.c_int * 3)()
         w_ptrs = [p[0] for p in preps]
         # pixel-pair stem (include/tubedetr_hip.h): bf16, even width, frozen stem (its weight gradient would need the 8-channel frames)
         pairs = dt == torch.bfloat16 and W % 2 == 0 and not convs[0][0].weight.requires_grad and os.environ.get("TD_STEM_PAIRS", "1") != "0"
@@ -201,7 +189,58 @@ class ResNetTrunkFn(Function):
             w_pairs = torch.empty((preps[0][0].shape[0], 7 * 4 * 8), dtype=dt, device=x.device)
             _hip.check(L.td_stem_pair_weights(preps[0][0].data_ptr(), w_pairs.data_ptr(), w_pairs.shape[0], code, _hip.stream_ptr()), "td_stem_pair_weights")
             w_ptrs = [w_pairs] + w_ptrs[1:]
-        _hip.check(L.td_resnet_fwd(srcs, len(x.parts), mean, inv_std, N, H, W, nb, _ptr_array(w_ptrs), _ptr_array([p[2] for p in preps]),
+        keep_alive = [t.detach().contiguous() for t, _ in x.parts]
+
+        def sources(a: int, b: int):
+            """td_frame_source array describing frames [a, b) of the concatenated source list (pointer arithmetic only)."""
+            out, base = [], 0
+            for t, (_, idx), vhw in zip(keep_alive, x.parts, x.valid):
+                n_part = idx.numel() if idx is not None else t.shape[0]
+                lo, hi = max(a, base) - base, min(b, base + n_part) - base
+                base += n_part
+                if hi <= lo:
+                    continue
+                fs = _hip.FrameSource()
+                fs.dtype, fs.n = (_hip.TD_U8 if t.dtype == torch.uint8 else _hip.TD_F32), hi - lo
+                if idx is not None:  # the index list is cut, the pixels (and their per-source-frame extents) stay where they are
+                    fs.data, fs.index = t.data_ptr(), idx.data_ptr() + 4 * lo
+                    fs.valid_hw = vhw.data_ptr() if vhw is not None else None
+                else:
+                    fs.data, fs.index = t.data_ptr() + lo * t.stride(0) * t.element_size(), None
+                    fs.valid_hw = vhw.data_ptr() + 8 * lo if vhw is not None else None
+                out.append(fs)
+            arr = (_hip.FrameSource * len(out))(*out)
+            return arr, len(out)
+
+        # every activation of a pass is addressed through a 32-bit buffer descriptor: < 2^31 elements and < 4 GiB per tensor.
+        # The largest one has 16 * H * W elements per frame (stem output / layer1 output).  A no-grad pass over more frames than
+        # that (eval / the fast frames of a large fp32 batch) is cut into equal chunks; a pass that keeps its activations
+        # for backward is not (its backward walks ONE workspace): the C library reports the limit.
+        per_frame = 16 * H * W
+        n_max = max(1, int(min(2**31 - 1, (2**32 - 4096) // dt.itemsize) // per_frame))
+        n_max = int(os.environ.get("TD_TRUNK_MAX_FRAMES", n_max))  # (tests lower it to exercise the chunking on small frames)
+        n_chunks = 1 if save else -(-N // n_max)
+        if n_chunks > 1:
+            step_n = -(-N // n_chunks)
+            feats, hw = [], (C.c_int * 3)()
+            for a in range(0, N, step_n):
+                b = min(N, a + step_n)
+                srcs, n_srcs = sources(a, b)
+                nbytes = L.td_resnet_fwd_ws_bytes(b - a, H, W, nb, code, 0)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                feat_p = C.c_void_p()
+                _hip.check(L.td_resnet_fwd(srcs, n_srcs, mean, inv_std, b - a, H, W, nb, _ptr_array(w_ptrs), _ptr_array([p[2] for p in preps]),
+                                           0, ws.data_ptr(), nbytes, C.byref(feat_p), hw, int(pairs), code, _hip.stream_ptr()), "td_resnet_fwd")
+                off = feat_p.value - ws.data_ptr()
+                n_el = (b - a) * hw[0] * hw[1] * hw[2]
+                feats.append(ws[off : off + n_el * dt.itemsize].view(dt).view(b - a, hw[0], hw[1], hw[2]).clone())
+            return torch.cat(feats)
+        srcs, n_srcs = sources(0, N)
+        nbytes = L.td_resnet_fwd_ws_bytes(N, H, W, nb, code, save)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        feat_p = C.c_void_p()
+        hw = (C.c_int * 3)()
+        _hip.check(L.td_resnet_fwd(srcs, n_srcs, mean, inv_std, N, H, W, nb, _ptr_array(w_ptrs), _ptr_array([p[2] for p in preps]),
                                    save, ws.data_ptr(), nbytes, C.byref(feat_p), hw, int(pairs), code, _hip.stream_ptr()), "td_resnet_fwd")
         off = feat_p.value - ws.data_ptr()
         n_el = N * hw[0] * hw[1] * hw[2]
