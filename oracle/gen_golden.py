@@ -37,6 +37,17 @@ CASES = {
     "c_nofast_T6_res64_k2": (dict(T=6, res=64, k=2, L=4, seed=13, fast=False, pad_w=9), dict(stride=2, fast=False)),
     "d_notsa_T5_res64_k5": (dict(T=5, res=64, k=5, L=4, seed=14), dict(stride=5, no_tsa=True)),
 }
+# Ablation variants (SURVEY.md 8a': accepted flags outside the kernel scope).  The CPU oracle does not restate them - these
+# vectors pin the PRODUCT directly against the reference's own output: (synthetic_batch kwargs, OracleConfig overrides,
+# reference-argument overrides that OracleConfig has no field for).
+VARIANTS = {
+    "v_gating_T6_res64_k2": (dict(T=6, res=64, k=2, L=4, seed=21), dict(stride=2), dict(fast_mode="gating")),
+    "v_pool_T6_res64_k3": (dict(T=6, res=64, k=3, L=4, seed=22, pad_w=12), dict(stride=3), dict(fast_mode="pool")),
+    "v_transformer_T4_res64_k2": (dict(T=4, res=64, k=2, L=4, seed=23), dict(stride=2), dict(fast_mode="transformer")),
+    "v_noslow_T6_res64_k2": (dict(T=6, res=64, k=2, L=4, seed=24, text_pad=1), dict(stride=2), dict(fast_mode="noslow")),
+    "v_stride0_T5-3_res64": (dict(T=5, res=64, k=1, L=4, seed=25, fast=False, durations=[5, 3]), dict(stride=0, fast=False), dict()),
+    "v_learned_T6_res64_k2": (dict(T=6, res=64, k=2, L=4, seed=26), dict(stride=2), dict(learn_time_embed=True, position_embedding="learned")),
+}
 WEIGHT_SEED = 7
 
 
@@ -146,7 +157,13 @@ def install_stubs():
     return tok
 
 
-def ref_args(cfg):
+def ref_args(cfg, **extra):
+    a = _ref_args(cfg)
+    a.__dict__.update(extra)
+    return a
+
+
+def _ref_args(cfg):
     return types.SimpleNamespace(
         device="cpu", hidden_dim=cfg.hidden_dim, dropout=0.1, nheads=cfg.nheads, dim_feedforward=cfg.dim_feedforward,
         enc_layers=cfg.enc_layers, dec_layers=cfg.dec_layers, pass_pos_and_query=True, text_encoder_type="roberta-base",
@@ -165,19 +182,24 @@ def run_case(name, tok):
     from models import build_model
     from util.misc import NestedTensor
 
-    bkw, ckw = CASES[name]
+    variant = name in VARIANTS
+    bkw, ckw, extra = VARIANTS[name] if variant else (CASES[name] + ({},))
     cfg = OracleConfig(**ckw)
     batch = synthetic_batch(**bkw)
     torch.manual_seed(0)
-    model, criterion, weight_dict = build_model(ref_args(cfg))
-    spec = state_spec(cfg)
+    model, criterion, weight_dict = build_model(ref_args(cfg, **extra))
     ref_sd = model.state_dict()
-    assert list(ref_sd.keys()) == list(spec.keys()), "state-dict key order/names differ from oracle.weights.state_spec"
-    assert all(tuple(ref_sd[k].shape) == tuple(spec[k]) for k in spec)
+    if variant:  # the variant's own parameters (fast_encoder.layers.0..., time_embed.time_embed.weight, ...) are filled by the same pure function
+        spec = {k: tuple(v.shape) for k, v in ref_sd.items()}
+    else:
+        spec = state_spec(cfg)
+        assert list(ref_sd.keys()) == list(spec.keys()), "state-dict key order/names differ from oracle.weights.state_spec"
+        assert all(tuple(ref_sd[k].shape) == tuple(spec[k]) for k in spec)
     model.load_state_dict(fill_state(spec, WEIGHT_SEED), strict=True)
     trainable = {k for k, p in model.named_parameters() if p.requires_grad}
     unused = {k for k in trainable if "pooler" in k}
-    assert trainable == {k for k in spec if is_trainable(k)}, "freeze rule mismatch"
+    if not variant:
+        assert trainable == {k for k in spec if is_trainable(k)}, "freeze rule mismatch"
     model.eval()  # dropout off (parity mode); gradients still flow
 
     tok.ids, tok.att = batch["input_ids"], batch["attention_mask"]
@@ -190,7 +212,8 @@ def run_case(name, tok):
 
     res = {}
     for k in ("img_memory", "mask", "pos_embed", "query_embed", "query_mask", "text_memory", "text_memory_resized", "text_attention_mask"):
-        res["cache." + k] = cache[k].detach().numpy()
+        if cache[k] is not None:  # (stride 0: no time-query mask)
+            res["cache." + k] = cache[k].detach().numpy()
     layers = out["aux_outputs"] + [out]
     for key in ("pred_boxes", "pred_sted", "weights", "ca_weights"):
         res["out." + key] = np.stack([o[key].detach().numpy() for o in layers])
@@ -216,6 +239,8 @@ def run_case(name, tok):
     for k, p in model.named_parameters():
         if not p.requires_grad or k in unused:
             continue
+        if variant and p.grad is None:  # parameters a variant leaves out of its graph (noslow: the whole space-text encoder)
+            continue
         assert p.grad is not None, k
         names.append(k)
         norms.append(p.grad.double().norm().item())
@@ -227,6 +252,10 @@ def run_case(name, tok):
     res["grad.norms"] = np.array(norms)
     res["grad.heads"] = np.stack(heads)
     res["meta.n_state_keys"] = np.array(len(spec))
+    if variant:
+        res["meta.state_keys"] = np.array(list(spec.keys()))
+        res["meta.trainable"] = np.array(sorted(trainable))
+        res["meta.no_grad"] = np.array(sorted(k for k, p in model.named_parameters() if p.requires_grad and p.grad is None))
     res["meta.n_params"] = np.array(sum(p.numel() for p in model.parameters()))
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
@@ -235,7 +264,7 @@ def run_case(name, tok):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="*", default=list(CASES))
+    ap.add_argument("cases", nargs="*", default=list(CASES) + list(VARIANTS))
     a = ap.parse_args()
     sys.path.insert(0, os.path.dirname(HERE))
     tok = install_stubs()

@@ -36,9 +36,9 @@ def test_state_dict_matches_reference_layout(built):
 def test_flag_variants_build_like_the_reference():
     m, _, _ = build_model(tubedetr_amd.default_args(device="cpu", fast=False, no_tsa=True))
     assert not hasattr(m.transformer, "fast_encoder") and len(m.state_dict()) == 919
-    with pytest.raises(NotImplementedError):
-        build_model(tubedetr_amd.default_args(device="cpu", fast_mode="gating"))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
+        build_model(tubedetr_amd.default_args(device="cpu", fast_mode="no-such-mode"))
+    with pytest.raises(NotImplementedError):  # dilation / GroupNorm / timm backbones: other models, not flags of this one (SURVEY.md 8a')
         build_model(tubedetr_amd.default_args(device="cpu", dilation=True))
 
 
@@ -104,3 +104,29 @@ def test_text_encoder_is_not_silently_replaced(monkeypatch):
     with pytest.warns(UserWarning, match="RANDOM-INIT"):
         tok, enc = tr._load_text_encoder("roberta-base-that-does-not-exist")
     assert isinstance(tok, tr.HashTokenizer) and enc.config.hidden_size == 768
+
+
+def test_ablation_variants_keep_the_reference_parameter_names():
+    """--fast_mode / --learn_time_embed / --position_embedding learned / --stride 0 are accepted (SURVEY.md 8a') and build the
+    same state-dict keys, shapes and trainable set as the reference's modules (recorded by oracle/gen_golden.py VARIANTS)."""
+    import os
+
+    import numpy as np
+
+    import tubedetr_amd
+    from oracle.gen_golden import VARIANTS
+    from tubedetr_amd.models import build_model
+
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    for name, (_, ckw, extra) in VARIANTS.items():
+        gold = np.load(os.path.join(gold_dir, name + ".npz"))
+        model, _, _ = build_model(tubedetr_amd.default_args(device="cpu", **ckw, **extra))
+        assert list(model.state_dict().keys()) == [str(k) for k in gold["meta.state_keys"]], name
+        assert sorted(k for k, p in model.named_parameters() if p.requires_grad) == [str(k) for k in gold["meta.trainable"]], name
+        assert sum(p.numel() for p in model.parameters()) == int(gold["meta.n_params"]), name
+    # pass_pos_and_query=False: constructible like the reference; forward fails where the reference's does
+    model, _, _ = build_model(tubedetr_amd.default_args(device="cpu", pass_pos_and_query=False))
+    import pytest as _pytest
+
+    with _pytest.raises(TypeError):
+        model.transformer(encode_and_save=False)

@@ -28,6 +28,40 @@ class TimeEmbeddingSine(nn.Module):
         return self.te[:ln]
 
 
+class TimeEmbeddingLearned(nn.Module):
+    """--learn_time_embed (position_encoding.py:13-27): a learned table; an ablation outside the kernel scope (SURVEY.md
+    8a'), served by the embedding weight itself - stock PyTorch autograd reaches it through the query-position rows."""
+
+    def __init__(self, num_pos_feats: int = 200, d_model: int = 512):
+        super().__init__()
+        self.time_embed = nn.Embedding(num_pos_feats, d_model)
+        nn.init.uniform_(self.time_embed.weight)
+
+    def forward(self, ln: int) -> torch.Tensor:
+        return self.time_embed.weight[:ln].unsqueeze(1)
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """--position_embedding learned (position_encoding.py:96-131): row / column embedding tables, concatenated per pixel.
+    Ablation: stock PyTorch ops (their autograd trains the tables); the result enters the HIP encoder like the sine one."""
+
+    def __init__(self, num_pos_feats: int = 256):
+        super().__init__()
+        self.row_embed = nn.Embedding(50, num_pos_feats)
+        self.col_embed = nn.Embedding(50, num_pos_feats)
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+        self.compute_dtype = torch.float32
+
+    def forward(self, tensor_list) -> torch.Tensor:
+        n, h, w = tensor_list.mask.shape
+        dev = tensor_list.mask.device
+        x_emb = self.col_embed(torch.arange(w, device=dev))
+        y_emb = self.row_embed(torch.arange(h, device=dev))
+        pos = torch.cat([x_emb.unsqueeze(0).repeat(h, 1, 1), y_emb.unsqueeze(1).repeat(1, w, 1)], dim=-1)  # (h, w, C)
+        return pos.to(self.compute_dtype).unsqueeze(0).repeat(n, 1, 1, 1).permute(0, 3, 1, 2)  # (N, C, h, w), channels-last strides
+
+
 class PositionEmbeddingSine(nn.Module):
     """forward(NestedTensor) -> (N, 2*num_pos_feats, h, w) like the reference; ``compute_dtype`` selects the
     element type (set by the owning backbone).  Internally the kernel writes token-major [N, h*w, C]; the returned
@@ -56,4 +90,6 @@ def build_position_encoding(args):
     n_steps = args.hidden_dim // 2
     if args.position_embedding in ("v2", "sine"):
         return PositionEmbeddingSine(n_steps, normalize=True)
-    raise ValueError(f"not supported {args.position_embedding} (learned encodings are outside the HIP hot path)")
+    if args.position_embedding in ("v3", "learned"):
+        return PositionEmbeddingLearned(n_steps)
+    raise ValueError(f"not supported {args.position_embedding}")

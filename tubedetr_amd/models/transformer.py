@@ -27,9 +27,10 @@ from torch import Tensor, nn
 
 from .. import functional as Fk
 from ..util.misc import LRUCache
-from .position_encoding import TimeEmbeddingSine
+from .position_encoding import TimeEmbeddingLearned, TimeEmbeddingSine
 
-FAST_MODES_IN_HIP = ("",)
+FAST_MODES_IN_HIP = ("",)  # the default slow-fast aggregation; the ablation variants below run their aggregation on stock PyTorch ops
+FAST_MODES = ("", "gating", "transformer", "pool", "noslow")  # main.py --fast_mode choices (transformer.py:113-122)
 
 
 class MultiheadAttention(nn.Module):
@@ -224,12 +225,12 @@ class Transformer(nn.Module):
                  freeze_text_encoder=False, video_max_len=0, stride=0, no_tsa=False, return_weights=False, fast=False,
                  fast_mode="", learn_time_embed=False, rd_init_tsa=False, no_time_embed=False):
         super().__init__()
-        if not pass_pos_and_query:
-            raise NotImplementedError("pass_pos_and_query=False is an ablation outside the HIP hot path")
-        if learn_time_embed:
-            raise NotImplementedError("learned time embeddings are outside the HIP hot path")
-        if fast and fast_mode not in FAST_MODES_IN_HIP:
-            raise NotImplementedError(f"fast_mode={fast_mode!r}: only the default slow-fast aggregation is implemented in HIP")
+        if fast and fast_mode not in FAST_MODES:
+            raise ValueError(f"fast_mode={fast_mode!r}: expected one of {FAST_MODES}")
+        # Ablation flags (SURVEY.md 8a'): accepted like the reference's constructor does.  fast_mode variants, learned
+        # time embeddings and stride=0 run the step's kernels as usual and only their own extra arithmetic on stock
+        # PyTorch-ROCm ops (_aggregate_variant); pass_pos_and_query=False is stored and fails at forward(), where the
+        # reference itself fails (see forward).
         self.pass_pos_and_query = pass_pos_and_query
         enc_layer = TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation)
         self.encoder = TransformerEncoder(enc_layer, num_encoder_layers, None, return_weights=True)
@@ -241,12 +242,19 @@ class Transformer(nn.Module):
         self.learn_time_embed = learn_time_embed
         self.use_time_embed = not no_time_embed
         if self.use_time_embed:
-            self.time_embed = TimeEmbeddingSine(video_max_len, d_model)
+            self.time_embed = TimeEmbeddingLearned(video_max_len, d_model) if learn_time_embed else TimeEmbeddingSine(video_max_len, d_model)
         self.fast = fast
         self.fast_mode = fast_mode
-        if fast:
-            self.fast_encoder = nn.Linear(d_model, d_model)
-            self.fast_residual = nn.Linear(d_model, d_model)
+        if fast:  # transformer.py:110-122
+            if fast_mode == "gating":
+                self.fast_encoder = nn.Linear(d_model, d_model)
+            elif fast_mode == "transformer":
+                self.fast_encoder = TransformerEncoder(TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation), 1,
+                                                       nn.LayerNorm(d_model), return_weights=True)
+                self.fast_residual = nn.Linear(d_model, d_model)
+            else:
+                self.fast_encoder = nn.Linear(d_model, d_model)
+                self.fast_residual = nn.Linear(d_model, d_model)
         self.rd_init_tsa = rd_init_tsa
         self._reset_temporal_parameters()
         self.tokenizer, self.text_encoder = _load_text_encoder(text_encoder_type)
@@ -267,11 +275,15 @@ class Transformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def _reset_temporal_parameters(self):
+    def _reset_temporal_parameters(self):  # transformer.py:159-176
         for n, p in self.named_parameters():
+            if "fast_encoder" in n and self.fast_mode == "transformer":
+                nn.init.constant_(p, 1.0 if ("norm" in n and "weight" in n) else 0.0)
             if self.rd_init_tsa and "decoder" in n and "self_attn" in n and p.dim() > 1:
                 nn.init.xavier_uniform_(p)
             if "fast_residual" in n:
+                nn.init.constant_(p, 0)
+            if self.fast_mode == "gating" and "fast_encoder" in n:
                 nn.init.constant_(p, 0)
 
     # ---- helpers ----
@@ -280,7 +292,7 @@ class Transformer(nn.Module):
         key = (tuple(durations), n_clips_per_video, str(device))
         hit = self._idx_cache.get(key)
         if hit is None:
-            b, t, k = len(durations), max(durations), self.stride
+            b, t, k = len(durations), max(durations), (self.stride or 1)  # stride 0: every frame is its own clip
             vid = torch.arange(b)
             owner = (vid[:, None] * n_clips_per_video + torch.arange(t)[None, :] // k).reshape(-1)
             query_mask = torch.ones(b, t, dtype=torch.bool)
@@ -350,19 +362,22 @@ class Transformer(nn.Module):
     def forward(self, src=None, mask=None, query_embed=None, pos_embed=None, text=None, encode_and_save=True, durations=None,
                 tpad_mask_t=None, fast_src=None, img_memory=None, query_mask=None, text_memory=None, text_mask=None,
                 memory_mask=None):
+        if not self.pass_pos_and_query:
+            # the reference sets pos_embed = None in this mode (transformer.py:242-248) and then concatenates it with the text
+            # rows (:325, TypeError), and its decode branch adds to a `src` that is None (:463-469): the flag cannot complete a
+            # step there either, so the same failure class is raised here instead of silently running something else
+            raise TypeError("pass_pos_and_query=False: the reference's Transformer.forward fails in this mode (models/transformer.py:242-248 -> 325, 463-469)")
         if encode_and_save:
             return self._encode(src, mask, query_embed, pos_embed, text, durations, tpad_mask_t, fast_src)
         return self._decode(img_memory, mask, pos_embed, query_embed, query_mask)
 
     # ---- encode (transformer.py:195-460) ----
     def _encode(self, src, mask, query_embed, pos_embed, text, durations, tpad_mask_t, fast_src):
-        if not self.stride:
-            raise NotImplementedError("stride=0 (dense, no temporal sampling) is outside the HIP hot path")
         n, d, h, w = src.shape  # (n_clips_total, d, h, w) channels-last view of NHWC rows
         dev, dt = src.device, self.compute_dtype
         hw = h * w
         b, t = len(durations), max(durations)
-        n_clips = math.ceil(t / self.stride)
+        n_clips = math.ceil(t / self.stride) if self.stride else t  # stride 0 (dense ablation): one clip per frame, no replication
         assert n == b * n_clips, "every video of the batch must yield the same number of slow clips"
         src_bm = src.permute(0, 2, 3, 1).reshape(n, hw, d)  # zero-copy when src is channels-last
         pos_bm = pos_embed.permute(0, 2, 3, 1).reshape(n, hw, d)
@@ -377,7 +392,7 @@ class Transformer(nn.Module):
         q = query_embed[0].float()
         qpos_t = (q[None, :] + self.time_embed(t)[:, 0, :]) if self.use_time_embed else q[None, :].expand(t, -1)
         query_pos_bm = qpos_t[None].expand(b, t, d)  # fp32, autograd reaches query_embed.weight
-        query_mask = query_mask.clone()
+        query_mask = query_mask.clone() if self.stride else None  # transformer.py:225-238: no time-query mask without temporal sampling
 
         text_attention_mask_orig, text_resized, tokenized = self._encode_text(text, dev)  # [B,L], [B,L,d]
         L = text_resized.shape[1]
@@ -390,14 +405,26 @@ class Transformer(nn.Module):
         x = torch.cat([src_bm.to(dt), text_clip], dim=1)  # [n, S, d]
         pos_full = torch.cat([pos_bm.to(dt), torch.zeros(n, L, d, dtype=dt, device=dev)], dim=1)
         key_pad = torch.cat([mask.flatten(1), text_mask_clip], dim=1).to(torch.uint8)  # [n, S], 1 = ignore
-        mem = self.encoder(x.reshape(n * S, d), key_pad, pos_full.reshape(n * S, d), n, S).view(n, S, d)
+        if self.fast and self.fast_mode == "noslow":  # no space-text attention for this baseline (transformer.py:330-340)
+            mem = x
+        else:
+            mem = self.encoder(x.reshape(n * S, d), key_pad, pos_full.reshape(n * S, d), n, S).view(n, S, d)
 
-        # temporal replication (transformer.py:393-427): frame (i, j) <- clip i*n_clips + j//k
-        frames_mem = mem[owner]  # [b*t, S, d]
-        frames_pos = pos_full[owner]
-        frame_mask = torch.cat([tpad_mask_t.flatten(1), text_attention_mask_orig[vid_of_frame]], dim=1)  # [b*t, S]
-        frame_mask[:, 0] = False  # "avoid empty masks" (transformer.py:424)
-        if self.fast:  # transformer.py:373-375,387,441-445
+        if self.stride:
+            # temporal replication (transformer.py:393-427): frame (i, j) <- clip i*n_clips + j//k
+            frames_mem = mem[owner]  # [b*t, S, d]
+            frames_pos = pos_full[owner]
+            frame_mask = torch.cat([tpad_mask_t.flatten(1), text_attention_mask_orig[vid_of_frame]], dim=1)  # [b*t, S]
+            frame_mask[:, 0] = False  # "avoid empty masks" (transformer.py:424)
+        else:
+            frames_mem, frames_pos, frame_mask = mem, pos_full, key_pad.bool()
+        if self.fast and self.fast_mode not in FAST_MODES_IN_HIP:
+            if fast_src is None:
+                raise AttributeError("fast=True needs temporal sampling (stride > 0): the reference builds no fast_src without it (models/tubedetr.py:140-153)")
+            frames_mem = self._aggregate_variant(frames_mem, fast_src, tpad_mask_t, text_resized, vid_of_frame, b, t, hw, d)
+        elif self.fast:  # transformer.py:373-375,387,441-445
+            if fast_src is None:
+                raise AttributeError("fast=True needs temporal sampling (stride > 0): the reference builds no fast_src without it (models/tubedetr.py:140-153)")
             fs = fast_src.permute(0, 2, 3, 1).reshape(b * t * hw, d)
             fast_mem = Fk.linear(fs.to(dt), self.fast_encoder.weight, self.fast_encoder.bias).view(b * t, hw, d)
             vis = frames_mem[:, :hw].reshape(b * t * hw, d)
@@ -416,6 +443,41 @@ class Transformer(nn.Module):
             "query_embed": query_pos_bm.transpose(0, 1),  # (t, b, d)
             "query_mask": query_mask,
         }
+
+    def _aggregate_variant(self, frames_mem, fast_src, tpad_mask_t, text_resized, vid_of_frame, b, t, hw, d):
+        """--fast_mode gating | transformer | pool | noslow (transformer.py:341-387, 429-445): ablation variants outside the
+        kernel scope (SURVEY.md 8a').  The fast features enter as they do by default; the variant's own arithmetic - the
+        masked spatial pooling, the gate, the aggregation - runs on stock PyTorch-ROCm ops with their autograd; the
+        temporal transformer of the "transformer" variant is this package's encoder layer over the time axis."""
+        import torch.nn.functional as F
+
+        dt, mode = self.compute_dtype, self.fast_mode
+        fs = fast_src.permute(0, 2, 3, 1).reshape(b * t, hw, d).to(dt)
+        vis, txt = frames_mem[:, :hw], frames_mem[:, hw:]
+
+        def lin(x_, m_):
+            return F.linear(x_, m_.weight.to(x_.dtype), m_.bias.to(x_.dtype))
+
+        if mode == "transformer":  # sequences over time, one per (video, pixel): (b*t, hw, d) -> rows [(b, hw), t]
+            seq = fs.view(b, t, hw, d).permute(0, 2, 1, 3).reshape(b * hw * t, d).contiguous()
+            te = Fk.cast(self.time_embed(t)[:, 0, :].float(), dt)
+            pos = te[None].expand(b * hw, t, d).reshape(b * hw * t, d).contiguous()
+            y = self.fast_encoder(seq, None, pos, b * hw, t)
+            fast_mem = y.view(b, hw, t, d).permute(0, 2, 1, 3).reshape(b * t, hw, d)
+        elif mode == "pool":  # masked mean over the frame's pixels, then the linear layer, broadcast back
+            keep = (~tpad_mask_t.flatten(1))[:, :, None]
+            cnt = keep.float().sum(dim=1).clamp(min=1)
+            pooled = torch.div((fs * keep).sum(dim=1), cnt.to(fs.dtype))
+            fast_mem = lin(pooled, self.fast_encoder)[:, None, :].expand(b * t, hw, d)
+        else:
+            fast_mem = lin(fs, self.fast_encoder)
+        if mode == "noslow":
+            vis, txt = fast_mem, text_resized[vid_of_frame]
+        elif mode == "gating":
+            vis = vis + vis * torch.sigmoid(fast_mem)
+        else:
+            vis = vis + lin(vis + fast_mem, self.fast_residual)
+        return torch.cat([vis, txt], dim=1)
 
     @staticmethod
     def _repeat_tokenized(tokenized, vid_of_clip, clip_vid_list):

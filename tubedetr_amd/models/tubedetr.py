@@ -131,9 +131,32 @@ class TubeDETR(nn.Module):
         assert memory_cache is not None
         return self._decode(memory_cache)
 
+    def _encode_dense(self, samples, durations, captions):
+        """--stride 0 (models/tubedetr.py:140-153): no temporal sampling - every frame is encoded with the text, videos shorter
+        than the longest are padded in time with zero features / all-True masks.  An ablation outside the kernel scope
+        (SURVEY.md 8a'): the trunk, the encoder and the decoder run as usual, the temporal padding is stock PyTorch indexing."""
+        b, t = len(durations), max(durations)
+        features, pos = self.backbone(samples)
+        src, mask = features[-1].decompose()
+        src, pos_embed = self._project(src), pos[-1]
+        dev = src.device
+        dest = self._frame_index(durations, dev)
+        tpad_mask = mask.clone()
+        if dest.numel() != b * t:
+            def pad_time(x):  # (n, C, h, w) channels-last view -> (b*t, C, h, w), zero rows for the padded frames
+                rows = torch.zeros((b * t,) + tuple(x.permute(0, 2, 3, 1).shape[1:]), dtype=x.dtype, device=dev)
+                return rows.index_put((dest,), x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+
+            src, pos_embed = pad_time(src), pad_time(pos_embed)
+            tpad_mask = torch.ones((b * t,) + tuple(mask.shape[1:]), dtype=torch.bool, device=dev)
+            tpad_mask[dest] = mask
+        tpad_mask[:, 0, 0] = False  # avoid empty masks
+        return self.transformer(src, tpad_mask, self.query_embed.weight, pos_embed, captions, encode_and_save=True,
+                                durations=durations, tpad_mask_t=None, fast_src=None)
+
     def _encode(self, samples, durations, captions, samples_fast):
         if not self.stride:
-            raise NotImplementedError("stride=0 is outside the HIP hot path")
+            return self._encode_dense(samples, durations, captions)
         b, t, k = len(durations), max(durations), self.stride
         merged = self.fast and samples_fast is not None and torch.is_grad_enabled() and samples_fast.tensors.shape[1:] == samples.tensors.shape[1:]
         if merged and self.slow_frames_are_strided_fast and sum(durations) == samples_fast.tensors.shape[0]:
