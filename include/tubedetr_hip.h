@@ -101,6 +101,28 @@ typedef struct td_epilogue {
 int td_conv_gemm(const void* src, const void* wmat, void* out, const td_conv_desc* d, const td_epilogue* e,
                  int dtype, td_stream_t stream);
 
+/* Linear layer whose input rows are formed on the fly:
+ *   out[out_map[m]][n] = epilogue( sum_k X[m][k] * wmat[n][k] (+ residual[res_map[m]][n]) ),   X[m] = [ A1[a1_map[m]] | A2[a2_map[m]] ]
+ * (K1 columns from A1, K2 from A2; every map is a device int32[M] or NULL = identity; res_map NULL = the output row).
+ * With a shared weight (w_shared) the product is (A1 + A2) W^T: "src + pos" enters the Q / K projections as a second operand stream
+ * instead of a materialised sum (with_pos_embed + in_proj of nn.MultiheadAttention, models/transformer.py:637-640,
+ * 735-737), and the temporal replication of the clip memory to its frames (models/transformer.py:393-427) becomes a row
+ * index inside its consumers: the slow-fast aggregation (:441-445) reads the clip rows through a1_map / res_map and writes
+ * the frame rows through out_map.  a2 may be NULL (one source).  K1 must be a multiple of the K tile (64 bf16 / 32 fp32
+ * elements) when a2 is given; lda / ldc / ldr are row strides in elements (ldr <= 0: ldc). */
+typedef struct td_linear_ex_desc {
+  int M, N, K1, K2;
+  int lda1, lda2, ldc, ldr;
+  int w_shared;           /* 1: wmat is [N][K1] and multiplies both sources (K2 == K1): out = (A1 + A2) W^T, no [W | W] copy; 0: wmat is [N][K1 + K2] */
+  long long rows1, rows2; /* rows held by the A1 / A2 buffers (bounds of the gather) */
+  const int* a1_map;
+  const int* a2_map;
+  const int* out_map;
+  const int* res_map;
+} td_linear_ex_desc;
+int td_linear_ex(const void* a1, const void* a2, const void* wmat, void* out, const td_linear_ex_desc* x, const td_epilogue* e,
+                 int dtype, td_stream_t stream);
+
 /* dw[n][k] += sum_m g[m][n] * gather(src)[m][k]   (fp32 atomics, `splits` partitions of m).
  * Replaces: autograd weight gradients of Conv2d / Linear on the same call sites. */
 int td_conv_wgrad(const void* g, const void* src, float* dw, const td_conv_desc* d, int ldg, int dtype, int splits,
@@ -132,6 +154,8 @@ typedef struct td_wgrad_job {
   int ldg;
   int ci_real;        /* input channels of the parameter (d.C may be padded) */
   float* dbias;       /* optional [Nc] fp32: column sums of g (bias gradient of a Linear / Conv2d with bias), overwritten */
+  int accumulate;     /* 1: dW += (instead of =), run behind the overwriting jobs of the same call: the second operand stream of a
+                       * two-source layer (td_linear_ex: dW = g^T A1 + g^T A2, the positional operand of the Q / K projections); no dbias */
 } td_wgrad_job;
 size_t td_conv_wgrad_batch_table_bytes(int n_jobs);
 int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev, size_t table_bytes,
@@ -259,9 +283,23 @@ int td_dropout(const void* x, void* y, size_t n, float p, uint32_t seed, const u
                td_stream_t stream);
 
 /* PositionEmbeddingSine (models/position_encoding.py:71-94, normalize=True, scale=2pi) from a
- * (N,h,w) uint8 pad mask -> pos [N][h*w][2*npf] T  (token-major, the layout the encoder consumes). */
-int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, float temperature, int dtype,
+ * (N,h,w) uint8 pad mask -> pos [N][rows_per_image][2*npf] T  (token-major, the layout the encoder consumes).
+ * rows_per_image >= h*w (<= 0: h*w): the rows behind the h*w tokens are written as zeros - the positional operand of the
+ * text tokens the reference appends with torch.cat([pos_embed, zeros_like(text)]) (models/transformer.py:323-326). */
+int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, float temperature, int rows_per_image, int dtype,
                 td_stream_t stream);
+
+/* Row gather / scatter: dst[dst_map[i]][0:cols] = src[src_map[i]][0:cols] (+ add[i][0:cols]) for i < n_rows (maps: device
+ * int32[n_rows] or NULL = i).  The temporal replication of clip rows to frame rows (models/transformer.py:393-427: the text
+ * rows of every frame's memory; the whole memory under --no_fast) as ONE pass of 16-byte accesses instead of a Python loop
+ * of slice assignments; with `add` the same pass forms gathered + plain rows (the slow-fast mix, :441, re-formed in backward
+ * instead of stored).  ld_* = row strides in elements, cols a multiple of 8 (bf16) / 4 (fp32). */
+int td_rows_copy(const void* src, const int* src_map, const void* add, void* dst, const int* dst_map, int n_rows, int cols, int ld_src,
+                 int ld_add, int ld_dst, int dtype, td_stream_t stream);
+/* Segment sums over rows (the backward of that replication): out[r][0:cols] = sum_{j in [ptr[r], ptr[r+1])} in[idx[j]][0:cols], fp32
+ * accumulation, r < n_out (ptr: device int32[n_out + 1], idx: device int32[ptr[n_out]]). */
+int td_rows_segment_sum(const void* in, const int* idx, const int* ptr, void* out, int n_out, int cols, int ld_in, int ld_out, int dtype,
+                        td_stream_t stream);
 
 /* Multi-head attention core on already projected q,k,v (nn.MultiheadAttention internals,
  * models/transformer.py:613,638-640 encoder; 661,713-719 temporal self-attention; 662,734-740

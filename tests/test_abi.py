@@ -58,7 +58,7 @@ def test_binding_argument_counts_and_struct_layouts_match_the_header():
         return n
 
     mirrors = {"td_conv_desc": _hip.ConvDesc, "td_epilogue": _hip.Epilogue, "td_wgrad_job": _hip.WgradJob, "td_frame_source": _hip.FrameSource,
-               "td_prep_item": _hip.PrepItem, "td_optim_segment": _hip.OptimSegment}
+               "td_prep_item": _hip.PrepItem, "td_optim_segment": _hip.OptimSegment, "td_linear_ex_desc": _hip.LinearExDesc}
     for cname, cls in mirrors.items():
         assert cname in structs, cname
         assert n_fields(structs[cname]) == len(cls._fields_), f"{cname}: {n_fields(structs[cname])} fields in the header, {len(cls._fields_)} in the binding"

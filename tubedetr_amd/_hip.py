@@ -28,7 +28,7 @@ class PrepItem(C.Structure):
 
 class WgradJob(C.Structure):
     """td_wgrad_job (include/tubedetr_hip.h)."""
-    _fields_ = [("g", C.c_void_p), ("src", C.c_void_p), ("dW", C.c_void_p), ("scale", C.c_void_p), ("d", ConvDesc), ("ldg", C.c_int), ("ci_real", C.c_int), ("dbias", C.c_void_p)]
+    _fields_ = [("g", C.c_void_p), ("src", C.c_void_p), ("dW", C.c_void_p), ("scale", C.c_void_p), ("d", ConvDesc), ("ldg", C.c_int), ("ci_real", C.c_int), ("dbias", C.c_void_p), ("accumulate", C.c_int)]
 
 
 TD_U8 = 2
@@ -37,6 +37,12 @@ TD_U8 = 2
 class FrameSource(C.Structure):
     """td_frame_source."""
     _fields_ = [("data", C.c_void_p), ("dtype", C.c_int), ("n", C.c_int), ("index", C.c_void_p), ("valid_hw", C.c_void_p)]
+
+
+class LinearExDesc(C.Structure):
+    """td_linear_ex_desc."""
+    _fields_ = [(n, C.c_int) for n in ("M", "N", "K1", "K2", "lda1", "lda2", "ldc", "ldr", "w_shared")] + \
+               [("rows1", C.c_longlong), ("rows2", C.c_longlong)] + [(n, C.c_void_p) for n in ("a1_map", "a2_map", "out_map", "res_map")]
 
 
 class OptimSegment(C.Structure):
@@ -91,7 +97,10 @@ _SIGS = {
     "td_gelu_fwd": [_P, _P, _SZ, _I, _P],
     "td_gelu_bwd": [_P, _P, _P, _SZ, _I, _P],
     "td_dropout": [_P, _P, _SZ, _F, _U32, _P, _I, _P],
-    "td_pos_sine": [_P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "td_pos_sine": [_P, _P, _I, _I, _I, _I, _F, _I, _I, _P],
+    "td_linear_ex": [_P, _P, _P, _P, C.POINTER(LinearExDesc), C.POINTER(Epilogue), _I, _P],
+    "td_rows_copy": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "td_rows_segment_sum": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "td_criterion_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "td_criterion_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "td_sted_decode": [_P, _P, _I, _I, _P],

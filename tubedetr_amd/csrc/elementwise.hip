@@ -375,13 +375,21 @@ __global__ __launch_bounds__(256) void ew_kernel(const T* a, const T* b, T* y, s
   }
 }
 
-// one block per image; thread per (y,x) token, loops over channels
+// One workgroup per image.  Phase 1: the normalised cumulative coordinates of every token (position_encoding.py:71-83) into
+// LDS, the 1 / temperature^(2i/npf) table beside them.  Phase 2: one thread per 16-byte run of channels (8 bf16 / 4 fp32) ->
+// 16-byte stores over whole rows (the first version stored 2-byte elements at a 512-byte stride per thread: 19x the result's
+// bytes reached HBM).  `rows` >= h*w rows are written per image; the rows behind the h*w tokens are ZERO: the encoder's
+// positional operand covers the text tokens with zeros (transformer.py:323-326), produced here instead of a torch.cat.
 template <typename T>
-__global__ void pos_sine_kernel(const uint8_t* mask, T* pos, int h, int w, int npf, float temperature) {
+__global__ __launch_bounds__(256) void pos_sine_kernel(const uint8_t* mask, T* pos, int h, int w, int npf, float temperature, int rows) {
+  extern __shared__ float sh[];  // [h*w] y coordinate, [h*w] x coordinate, [npf] dim_t
   const int img = blockIdx.x;
-  const uint8_t* m = mask + (size_t)img * h * w;
+  const int hw = h * w;
+  const uint8_t* m = mask + (size_t)img * hw;
   const float two_pi = 6.283185307179586f;
-  for (int tkn = threadIdx.x; tkn < h * w; tkn += blockDim.x) {
+  float* dimt = sh + 2 * hw;
+  for (int i = threadIdx.x; i < npf; i += blockDim.x) dimt[i] = powf(temperature, (float)(2 * (i / 2)) / (float)npf);
+  for (int tkn = threadIdx.x; tkn < hw; tkn += blockDim.x) {
     const int y = tkn / w, x = tkn - y * w;
     float ye = 0.f, xe = 0.f, ylast = 0.f, xlast = 0.f;
     for (int yy = 0; yy < h; ++yy) {
@@ -394,15 +402,109 @@ __global__ void pos_sine_kernel(const uint8_t* mask, T* pos, int h, int w, int n
       xlast += nm;
       if (xx <= x) xe += nm;
     }
-    ye = ye / (ylast + 1e-6f) * two_pi;
-    xe = xe / (xlast + 1e-6f) * two_pi;
-    T* o = pos + ((size_t)img * h * w + tkn) * (2 * npf);
-    for (int i = 0; i < npf; ++i) {
-      float dim_t = powf(temperature, (float)(2 * (i / 2)) / (float)npf);
-      float vy = ye / dim_t, vx = xe / dim_t;
-      Elem<T>::store(o, i, (i & 1) ? cosf(vy) : sinf(vy));
-      Elem<T>::store(o, npf + i, (i & 1) ? cosf(vx) : sinf(vx));
+    sh[tkn] = ye / (ylast + 1e-6f) * two_pi;
+    sh[hw + tkn] = xe / (xlast + 1e-6f) * two_pi;
+  }
+  __syncthreads();
+  constexpr int EPL = 16 / sizeof(T);
+  const int C = 2 * npf, chunks = C / EPL;  // npf % EPL == 0 (host-checked): a run never straddles the y / x halves
+  char* base = (char*)pos + (size_t)img * rows * C * sizeof(T);
+  for (int idx = threadIdx.x; idx < rows * chunks; idx += blockDim.x) {
+    const int row = idx / chunks, c0 = (idx - row * chunks) * EPL;
+    float v[EPL];
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) v[r] = 0.f;
+    if (row < hw) {
+      const bool xhalf = c0 >= npf;
+      const float e = xhalf ? sh[hw + row] : sh[row];
+      const int i0 = xhalf ? c0 - npf : c0;
+#pragma unroll
+      for (int r = 0; r < EPL; ++r) {
+        const float val = e / dimt[i0 + r];
+        v[r] = ((i0 + r) & 1) ? cosf(val) : sinf(val);
+      }
     }
+    uint4 o;
+    if constexpr (sizeof(T) == 2) {
+      o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      o.z = (uint32_t)f32_to_bf16(v[4 % EPL]) | ((uint32_t)f32_to_bf16(v[5 % EPL]) << 16);
+      o.w = (uint32_t)f32_to_bf16(v[6 % EPL]) | ((uint32_t)f32_to_bf16(v[7 % EPL]) << 16);
+    } else {
+      o = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    }
+    *(uint4*)(base + ((size_t)row * C + c0) * sizeof(T)) = o;
+  }
+}
+
+// dst[dst_map[i]] = src[src_map[i]] (+ add[i]): one thread per 16-byte run of a row
+template <typename T>
+__global__ __launch_bounds__(256) void rows_copy_kernel(const char* __restrict__ src, const int* __restrict__ src_map, const char* __restrict__ add,
+                                                        char* __restrict__ dst, const int* __restrict__ dst_map, int n_rows, int chunks, int ld_src,
+                                                        int ld_add, int ld_dst) {
+  constexpr int EPL = 16 / sizeof(T);
+  const size_t total = (size_t)n_rows * chunks;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / chunks), c = (int)(idx - (size_t)i * chunks);
+    const size_t rs = src_map ? (size_t)src_map[i] : (size_t)i, rd = dst_map ? (size_t)dst_map[i] : (size_t)i;
+    uint4 v = *(const uint4*)(src + (rs * ld_src + (size_t)c * EPL) * sizeof(T));
+    if (add) {
+      const uint4 a = *(const uint4*)(add + ((size_t)i * ld_add + (size_t)c * EPL) * sizeof(T));
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t* pv = (const uint32_t*)&v;
+        const uint32_t* pa = (const uint32_t*)&a;
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(pv[q] << 16) + __uint_as_float(pa[q] << 16);
+          const float hi = __uint_as_float(pv[q] & 0xffff0000u) + __uint_as_float(pa[q] & 0xffff0000u);
+          o[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+        }
+        v = make_uint4(o[0], o[1], o[2], o[3]);
+      } else {
+        v = make_uint4(__float_as_uint(__uint_as_float(v.x) + __uint_as_float(a.x)), __float_as_uint(__uint_as_float(v.y) + __uint_as_float(a.y)),
+                       __float_as_uint(__uint_as_float(v.z) + __uint_as_float(a.z)), __float_as_uint(__uint_as_float(v.w) + __uint_as_float(a.w)));
+      }
+    }
+    *(uint4*)(dst + (rd * ld_dst + (size_t)c * EPL) * sizeof(T)) = v;
+  }
+}
+
+// out[r] = sum over its segment of input rows, fp32 accumulation: one thread per 16-byte run of an output row
+template <typename T>
+__global__ __launch_bounds__(256) void rows_segment_sum_kernel(const char* __restrict__ in, const int* __restrict__ idx, const int* __restrict__ ptr,
+                                                               char* __restrict__ out, int n_out, int chunks, int ld_in, int ld_out) {
+  constexpr int EPL = 16 / sizeof(T);
+  const size_t total = (size_t)n_out * chunks;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(t / chunks), c = (int)(t - (size_t)r * chunks);
+    float acc[EPL];
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) acc[q] = 0.f;
+    const int j0 = ptr[r], j1 = ptr[r + 1];
+    for (int j = j0; j < j1; ++j) {
+      const uint4 v = *(const uint4*)(in + ((size_t)idx[j] * ld_in + (size_t)c * EPL) * sizeof(T));
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t* pv = (const uint32_t*)&v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[2 * q] += __uint_as_float(pv[q] << 16);
+          acc[2 * q + 1] += __uint_as_float(pv[q] & 0xffff0000u);
+        }
+      } else {
+        acc[0] += __uint_as_float(v.x); acc[1] += __uint_as_float(v.y); acc[2] += __uint_as_float(v.z); acc[3] += __uint_as_float(v.w);
+      }
+    }
+    uint4 o;
+    if constexpr (sizeof(T) == 2) {
+      o.x = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
+      o.y = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
+      o.z = (uint32_t)f32_to_bf16(acc[4 % EPL]) | ((uint32_t)f32_to_bf16(acc[5 % EPL]) << 16);
+      o.w = (uint32_t)f32_to_bf16(acc[6 % EPL]) | ((uint32_t)f32_to_bf16(acc[7 % EPL]) << 16);
+    } else {
+      o = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
+    }
+    *(uint4*)(out + ((size_t)r * ld_out + (size_t)c * EPL) * sizeof(T)) = o;
   }
 }
 
@@ -560,12 +662,53 @@ extern "C" int td_dropout(const void* x, void* y, size_t n, float p, uint32_t se
   return check_launch("td_dropout");
 }
 
-extern "C" int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, float temperature, int dtype,
+extern "C" int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, float temperature, int rows_per_image, int dtype,
                            td_stream_t stream) {
   TD_REQUIRE(mask && pos, "td_pos_sine: null pointer");
   if (N == 0) return TD_OK;
+  const int rows = rows_per_image > 0 ? rows_per_image : h * w;
+  const int epl = dtype == TD_BF16 ? 8 : 4;
+  TD_REQUIRE(h >= 1 && w >= 1 && rows >= h * w, "td_pos_sine: rows_per_image=%d < h*w=%d", rows, h * w);
+  TD_REQUIRE(npf >= epl && npf % epl == 0, "td_pos_sine: num_pos_feats=%d must be a multiple of %d", npf, epl);
+  const size_t lds = (size_t)(2 * h * w + npf) * sizeof(float);
+  TD_REQUIRE(lds <= 64 * 1024, "td_pos_sine: feature map of %d x %d tokens is too large", h, w);
   hipStream_t st = (hipStream_t)stream;
-  TD_DISPATCH(dtype, (pos_sine_kernel<u16><<<N, 128, 0, st>>>(mask, (u16*)pos, h, w, npf, temperature)),
-              (pos_sine_kernel<float><<<N, 128, 0, st>>>(mask, (float*)pos, h, w, npf, temperature)), "td_pos_sine");
+  TD_DISPATCH(dtype, (pos_sine_kernel<u16><<<N, 256, lds, st>>>(mask, (u16*)pos, h, w, npf, temperature, rows)),
+              (pos_sine_kernel<float><<<N, 256, lds, st>>>(mask, (float*)pos, h, w, npf, temperature, rows)), "td_pos_sine");
   return check_launch("td_pos_sine");
+}
+
+extern "C" int td_rows_copy(const void* src, const int* src_map, const void* add, void* dst, const int* dst_map, int n_rows, int cols, int ld_src,
+                            int ld_add, int ld_dst, int dtype, td_stream_t stream) {
+  TD_REQUIRE(src && dst, "td_rows_copy: null pointer");
+  if (n_rows <= 0) return TD_OK;
+  const int epl = dtype == TD_BF16 ? 8 : 4;
+  TD_REQUIRE(cols >= epl && cols % epl == 0 && ld_src % epl == 0 && ld_dst % epl == 0 && (!add || ld_add % epl == 0) && ld_src >= cols && ld_dst >= cols,
+             "td_rows_copy: cols / row strides must be multiples of %d", epl);
+  TD_REQUIRE(((uintptr_t)src | (uintptr_t)dst | (uintptr_t)add) % 16 == 0, "td_rows_copy: pointers must be 16-byte aligned");
+  const int chunks = cols / epl;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned g = nblk((size_t)n_rows * chunks);
+  if (g > 16384) g = 16384;
+  TD_DISPATCH(dtype, (rows_copy_kernel<u16><<<g, 256, 0, st>>>((const char*)src, src_map, (const char*)add, (char*)dst, dst_map, n_rows, chunks, ld_src, ld_add, ld_dst)),
+              (rows_copy_kernel<float><<<g, 256, 0, st>>>((const char*)src, src_map, (const char*)add, (char*)dst, dst_map, n_rows, chunks, ld_src, ld_add, ld_dst)),
+              "td_rows_copy");
+  return check_launch("td_rows_copy");
+}
+
+extern "C" int td_rows_segment_sum(const void* in, const int* idx, const int* ptr, void* out, int n_out, int cols, int ld_in, int ld_out, int dtype,
+                                   td_stream_t stream) {
+  TD_REQUIRE(in && idx && ptr && out, "td_rows_segment_sum: null pointer");
+  if (n_out <= 0) return TD_OK;
+  const int epl = dtype == TD_BF16 ? 8 : 4;
+  TD_REQUIRE(cols >= epl && cols % epl == 0 && ld_in % epl == 0 && ld_out % epl == 0 && ld_in >= cols && ld_out >= cols,
+             "td_rows_segment_sum: cols / row strides must be multiples of %d", epl);
+  TD_REQUIRE(((uintptr_t)in | (uintptr_t)out) % 16 == 0, "td_rows_segment_sum: pointers must be 16-byte aligned");
+  const int chunks = cols / epl;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned g = nblk((size_t)n_out * chunks);
+  if (g > 16384) g = 16384;
+  TD_DISPATCH(dtype, (rows_segment_sum_kernel<u16><<<g, 256, 0, st>>>((const char*)in, idx, ptr, (char*)out, n_out, chunks, ld_in, ld_out)),
+              (rows_segment_sum_kernel<float><<<g, 256, 0, st>>>((const char*)in, idx, ptr, (char*)out, n_out, chunks, ld_in, ld_out)), "td_rows_segment_sum");
+  return check_launch("td_rows_segment_sum");
 }

@@ -40,6 +40,15 @@ struct GemmParams {
   float drop_scale;
   uint32_t seed;
   const uint32_t* seed_dev;
+  // td_linear_ex (GX instances): the activation operand is [ A1[a1_map[m]] (K1 columns) | A2[a2_map[m]] (K - K1 columns) ]
+  const char* src2;
+  uint32_t src2_bytes;
+  int K1, lda1, lda2, ldr;
+  int w_shared;  // 1: wmat is [N][K1] and multiplies BOTH sources (= (A1 + A2) W^T without a [W | W] copy)
+  const int* a1_map;
+  const int* a2_map;
+  const int* out_map;
+  const int* res_map;
 };
 
 template <typename T>
@@ -174,10 +183,16 @@ __device__ __forceinline__ void st16(char* p, const uint4& v) {
 // and, a multiply-add and a select per instruction instead of ~20 VALU operations of per-lane (r, s, c) decomposition and
 // bounds tests.  Which taps fall inside the image is a per-row bit mask computed once per workgroup.  Forward geometry with
 // any stride, or input-gradient geometry with stride 1.
-template <typename T, int BM, int BN, int NST, bool PW, bool TU = false>
+// GX = gather-extended pointwise operand (td_linear_ex): the K axis is the concatenation of TWO row-major sources - columns
+// < K1 from A1, the rest from A2 (K1 a multiple of the K tile: a tile never straddles the seam, the choice is wave-uniform) -
+// each read through an optional row index (a1_map / a2_map), the result row and the residual row through out_map / res_map.
+// That is how "x + pos" enters the Q/K projections without being formed ([x | pos] [W | W]^T = (x + pos) W^T,
+// models/transformer.py:637-640, 735-737) and how the temporal replication (:393-427) is an index inside its consumers.
+template <typename T, int BM, int BN, int NST, bool PW, bool TU = false, bool GX = false>
 // (three 24-KiB stages of a 64 x 128 tile = 72 KiB: two workgroups per CU, so that is what the NST == 3 instances declare)
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) void conv_gemm_kernel(GemmParams p) {
   static_assert(!(PW && TU), "pointwise layers have no taps");
+  static_assert(!GX || (PW && NST == 2), "the gather-extended operand is a pointwise, two-stage instance");
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;   // elements per 16-byte chunk
   constexpr int BK = 128 / ES;   // K elements per tile (128 bytes per row)
@@ -207,11 +222,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
 
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_src2 = __builtin_amdgcn_make_buffer_rsrc((void*)(GX ? p.src2 : p.src), 0, GX ? p.src2_bytes : p.src_bytes, 0x00020000);
 
   // per-lane row bookkeeping (fixed for the whole K loop)
   int a_img[AI], a_hb[AI], a_wb[AI];
   bool a_ok[AI];
   uint32_t a_off[AI];
+  uint32_t a_off2[GX ? AI : 1];  // GX: byte offset of this lane's row in the second source
   int a_base[AI];        // TU: pixel index of tap (0, 0) of this row (may be negative: only used for taps inside the image)
   uint32_t a_mask[AI];   // TU: bit (r*S + s) set = tap (r, s) of this row lies inside the image
   const int RS = d.R * d.S;
@@ -219,7 +236,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
   for (int i = 0; i < AI; ++i) {
     int m = m0 + (i * 4 + wave) * 8 + lrow;
     a_ok[i] = m < p.M;
-    if constexpr (PW) {
+    if constexpr (GX) {
+      const int mm = a_ok[i] ? m : 0;
+      const int r1 = p.a1_map ? p.a1_map[mm] : mm;
+      const int r2 = p.a2_map ? p.a2_map[mm] : mm;
+      a_off[i] = a_ok[i] ? (uint32_t)r1 * (uint32_t)p.lda1 * ES : OOB;
+      a_off2[i] = (a_ok[i] && p.src2) ? (uint32_t)r2 * (uint32_t)p.lda2 * ES : OOB;
+    } else if constexpr (PW) {
       a_off[i] = a_ok[i] ? (uint32_t)m * (uint32_t)p.K * ES : OOB;
     } else {
       int mm = a_ok[i] ? m : 0;
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     int n = n0 + (i * 4 + wave) * 8 + lrow;
-    b_off[i] = n < d.Nc ? (uint32_t)n * (uint32_t)p.K * ES : OOB;
+    b_off[i] = n < d.Nc ? (uint32_t)n * (uint32_t)((GX && p.w_shared) ? p.K1 : p.K) * ES : OOB;
   }
   // running decomposition of this lane's k index into (r, s, c)
   int kk = chunk * VEC;
@@ -268,6 +291,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
   }
   // TU: wave-uniform tile position (tap, channel base, pixel offset of the tap); the lane only contributes its chunk
   int t_tap = 0, t_ks = 0, t_kc = 0, t_pix = 0;
+  int k_tile0 = 0;  // first column of the tile being issued (wave-uniform; GX picks the source by it)
   const int lane_c = chunk * VEC;
 
   auto issue_tile = [&](char* stage) {
@@ -280,6 +304,14 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
       if constexpr (TU) {
         const bool ok = kvalid && ((a_mask[i] >> (t_tap & 31)) & 1u);
         off = ok ? (uint32_t)((a_base[i] + t_pix) * d.C + t_kc + lane_c) * ES : OOB;
+      } else if constexpr (GX) {
+        // k_tile0 (wave-uniform) is the tile's first column: below K1 the whole tile comes from A1, else from A2
+        if (k_tile0 >= p.K1) {
+          off = (kvalid && a_off2[i] != OOB) ? a_off2[i] + (uint32_t)(kk - p.K1) * ES : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src2, (lds_ptr_t)(stA + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+          continue;
+        }
+        off = (kvalid && a_off[i] != OOB) ? a_off[i] + (uint32_t)kk * ES : OOB;
       } else if constexpr (PW) {
         off = (kvalid && a_ok[i]) ? a_off[i] + (uint32_t)kk * ES : OOB;
       } else {
@@ -306,13 +338,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stA + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
     }
+    const int kw = (GX && p.w_shared && k_tile0 >= p.K1) ? kk - p.K1 : kk;  // shared weight: the second source re-reads the same columns
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      uint32_t off = (kvalid && b_off[i] != OOB) ? b_off[i] + (uint32_t)kk * ES : OOB;
+      uint32_t off = (kvalid && b_off[i] != OOB) ? b_off[i] + (uint32_t)kw * ES : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(stB + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
     }
     // advance this lane's k by one tile
     kk += BK;
+    k_tile0 += BK;
     if constexpr (TU) {
       t_kc += BK;
       if (t_kc >= d.C) {  // next tap (C is a multiple of BK: a tile never straddles two taps)
@@ -378,8 +412,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
   static_assert(2 * WM * WN * 4 <= (BM + BN) * 128, "staging region does not fit the stage buffer");
   const int cc = lane % LPR, rsub = lane / LPR;
   const int n = n0 + wx * WN + cc * EPL;
-  const bool vec_ok = ((d.ldc % EPL) == 0) && (n + EPL - 1 < d.Nc);
+  const bool vec_ok = ((d.ldc % EPL) == 0) && (!GX || (p.ldr % EPL) == 0) && (n + EPL - 1 < d.Nc);
   size_t offs[NIT];
+  size_t roffs[GX ? NIT : 1];  // GX: element offset of the residual row (its own row map and row stride)
   bool live[NIT];
   uint4 res[NIT], msk[NIT];
   // every residual / mask operand of this lane is requested in one go - 2*NIT independent 16-byte loads in flight
@@ -396,9 +431,14 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
         int ho = rem / d.Wo, wo = rem - ho * d.Wo;
         orow = ((size_t)ni * d.out_H + (size_t)ho * d.out_sp) * d.out_W + (size_t)wo * d.out_sp;
       }
+      if constexpr (GX) {
+        const size_t mm = orow;
+        if (p.out_map) orow = (size_t)p.out_map[mm];
+        roffs[it] = (p.res_map ? (size_t)p.res_map[mm] : orow) * (size_t)p.ldr + n;
+      }
       offs[it] = orow * d.ldc + n;
       if (vec_ok && live[it]) {
-        if (p.residual) res[it] = ld16(p.residual + offs[it] * ES);
+        if (p.residual) res[it] = ld16(p.residual + (GX ? roffs[it] : offs[it]) * ES);
         if (p.mask_src) msk[it] = ld16(p.mask_src + offs[it] * ES);
       }
     }
@@ -511,7 +551,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
       const int cnt = min(EPL, d.Nc - n);
       for (int r = 0; r < cnt; ++r) {
         float x = v[r];
-        if (p.residual) x += Elem<T>::load(p.residual, off + r);
+        if (p.residual) x += Elem<T>::load(p.residual, (GX ? roffs[it] : off) + r);
         if (p.relu) x = fmaxf(x, 0.f);
         if (p.sigmoid) x = sigmoidf_(x);
         if (p.mask_src) x = Elem<T>::load(p.mask_src, off + r) > 0.f ? x : 0.f;
@@ -1883,6 +1923,93 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   return check_launch("td_conv_gemm");
 }
 
+// out[out_map[m]][n] = epilogue( [A1[a1_map[m]] | A2[a2_map[m]]] @ wmat[n][K1 + K2]^T (+ residual[res_map[m]][n]) )
+extern "C" int td_linear_ex(const void* a1, const void* a2, const void* wmat, void* out, const td_linear_ex_desc* x, const td_epilogue* e,
+                            int dtype, td_stream_t stream) {
+  TD_REQUIRE(a1 && wmat && out && x, "td_linear_ex: null pointer");
+  TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "td_linear_ex: bad dtype %d", dtype);
+  const int vec = dtype == TD_BF16 ? 8 : 4, bk = dtype == TD_BF16 ? 64 : 32;
+  const int es = dtype == TD_BF16 ? 2 : 4;
+  const int K2 = a2 ? x->K2 : 0;
+  TD_REQUIRE(x->M >= 1 && x->N >= 1 && x->K1 >= vec && K2 >= 0, "td_linear_ex: bad sizes");
+  TD_REQUIRE(x->K1 % vec == 0 && K2 % vec == 0 && x->lda1 % vec == 0 && (!a2 || x->lda2 % vec == 0), "td_linear_ex: K1 / K2 / lda must be multiples of %d", vec);
+  TD_REQUIRE(!a2 || x->K1 % bk == 0, "td_linear_ex: with a second source K1=%d must be a multiple of the K tile (%d)", x->K1, bk);
+  TD_REQUIRE(x->lda1 >= x->K1 && (!a2 || x->lda2 >= K2) && x->ldc >= x->N, "td_linear_ex: row stride smaller than the row");
+  TD_REQUIRE(x->rows1 >= 1 && (!a2 || x->rows2 >= 1) && (x->a1_map || x->rows1 >= x->M) && (!a2 || x->a2_map || x->rows2 >= x->M),
+             "td_linear_ex: source has fewer rows than M and no row map");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = (const char*)a1;
+  p.src2 = (const char*)a2;
+  p.w = (const char*)wmat;
+  p.out = (char*)out;
+  p.M = x->M;
+  p.K = x->K1 + K2;
+  p.K1 = x->K1;
+  p.lda1 = x->lda1;
+  p.lda2 = a2 ? x->lda2 : 0;
+  p.ldr = x->ldr > 0 ? x->ldr : x->ldc;
+  p.w_shared = (a2 && x->w_shared) ? 1 : 0;
+  TD_REQUIRE(!p.w_shared || K2 == x->K1, "td_linear_ex: a shared weight needs K2 == K1");
+  p.a1_map = x->a1_map;
+  p.a2_map = a2 ? x->a2_map : nullptr;
+  p.out_map = x->out_map;
+  p.res_map = x->res_map;
+  td_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.N = 1; d.Hs = x->M; d.Ws = 1; d.C = p.K; d.Ho = x->M; d.Wo = 1; d.R = d.S = 1; d.stride = 1; d.Nc = x->N; d.ldc = x->ldc; d.out_sp = 1;
+  p.d = d;
+  {
+    const double b1 = (double)x->rows1 * x->lda1 * es, b2 = a2 ? (double)x->rows2 * x->lda2 * es : 16.0, wb = (double)x->N * (p.w_shared ? x->K1 : p.K) * es;
+    TD_REQUIRE(b1 < 4294967000.0 && b2 < 4294967000.0 && wb < 4294967000.0, "td_linear_ex: operand exceeds the 4 GiB buffer-descriptor range");
+    p.src_bytes = (uint32_t)b1;
+    p.src2_bytes = (uint32_t)b2;
+    p.w_bytes = (uint32_t)wb;
+  }
+  p.alpha = 1.f;
+  if (e) {
+    p.bias = e->bias;
+    p.residual = (const char*)e->residual;
+    p.mask_src = (const char*)e->mask_src;
+    p.relu = e->relu;
+    p.sigmoid = e->sigmoid;
+    if (e->alpha != 0.f) p.alpha = e->alpha;
+    if (e->dropout_p > 0.f) {
+      TD_REQUIRE(e->dropout_p < 1.f, "td_linear_ex: dropout_p must be < 1");
+      p.drop_thresh = (uint32_t)((double)e->dropout_p * 4294967296.0);
+      if (p.drop_thresh == 0) p.drop_thresh = 1;
+      p.drop_scale = 1.f / (1.f - e->dropout_p);
+      p.seed = e->dropout_seed;
+      p.seed_dev = e->dropout_counter;
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const bool narrow = x->N <= 64;
+  const int tiles128 = cdiv(p.M, 128) * cdiv(x->N, 128);
+  const bool small_m = !narrow && (tiles128 < 512 || p.K <= 512);
+  const int BMsel = small_m ? 64 : 128, BNsel = narrow ? 64 : 128;
+  dim3 grid(8 * cdiv(cdiv(p.M, BMsel), 8) * cdiv(x->N, BNsel));
+  const bool prof = prof_on();
+  if (prof) {
+    prof_begin(narrow ? TD_PROF_GEMM_128x64 : (small_m ? TD_PROF_GEMM_64x128 : TD_PROF_GEMM_128x128), dtype, 2.0 * p.M * x->N * p.K, st, p.M, x->N, p.K, 1, 1, 2);
+    double by = ((double)p.M * p.K + (double)x->N * p.K + (double)p.M * x->N) * es;  // every gathered row counted once per use
+    if (p.residual) by += (double)p.M * x->N * es;
+    if (p.mask_src) by += (double)p.M * x->N * es;
+    prof_set_bytes(by);
+  }
+#define TD_LX(TT)                                                                                     \
+  do {                                                                                                \
+    if (narrow) conv_gemm_kernel<TT, 128, 64, 2, true, false, true><<<grid, 256, 0, st>>>(p);         \
+    else if (small_m) conv_gemm_kernel<TT, 64, 128, 2, true, false, true><<<grid, 256, 0, st>>>(p);   \
+    else conv_gemm_kernel<TT, 128, 128, 2, true, false, true><<<grid, 256, 0, st>>>(p);               \
+  } while (0)
+  if (dtype == TD_BF16) TD_LX(u16);
+  else TD_LX(float);
+#undef TD_LX
+  if (prof) prof_end(st);
+  return check_launch("td_linear_ex");
+}
+
 static int wgrad_stages() {
   static const int nstg = [] { const char* e = getenv("TD_WGRAD_STAGES"); return (e && atoi(e) == 2) ? 2 : 4; }();
   return nstg;
@@ -1984,7 +2111,9 @@ extern "C" int td_conv_wgrad_bias(const void* g, const void* src, float* dw, flo
 // The job table of a launch lives in caller-provided memory: the library writes it into `table_host` (page-locked),
 // enqueues ONE hipMemcpyAsync into `table_dev` on the caller's stream and launches; no allocation, no synchronisation.
 static size_t wg_table_half(int n_jobs) { return (((size_t)n_jobs * sizeof(WgradParams)) + 255) & ~(size_t)255; }
-extern "C" size_t td_conv_wgrad_batch_table_bytes(int n_jobs) { return n_jobs > 0 ? 3 * wg_table_half(n_jobs) : 0; }  // general / pointwise / wide-tile tables
+extern "C" size_t td_conv_wgrad_batch_table_bytes(int n_jobs) { return n_jobs > 0 ? 6 * wg_table_half(n_jobs) : 0; }  // (general / pointwise / wide-tile tables) x (overwriting / accumulating jobs)
+
+static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev, size_t half, bool accumulate, td_stream_t stream);
 
 extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev,
                                    size_t table_bytes, td_stream_t stream) {
@@ -1992,6 +2121,18 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
   TD_REQUIRE(table_host && table_dev && table_bytes >= td_conv_wgrad_batch_table_bytes(n_jobs),
              "td_conv_wgrad_batch: job-table workspace missing or smaller than td_conv_wgrad_batch_table_bytes(%d)", n_jobs);
   const size_t half = wg_table_half(n_jobs);
+  // jobs flagged `accumulate` add to what the overwriting jobs of the same call wrote: they run as a second launch set behind them
+  std::vector<td_wgrad_job> first, second;
+  for (int i = 0; i < n_jobs; ++i) (jobs[i].accumulate ? second : first).push_back(jobs[i]);
+  int rc = TD_OK;
+  if (!first.empty()) rc = wgrad_batch_phase(first.data(), (int)first.size(), dtype, table_host, table_dev, half, false, stream);
+  if (rc == TD_OK && !second.empty())
+    rc = wgrad_batch_phase(second.data(), (int)second.size(), dtype, (char*)table_host + 3 * half, (char*)table_dev + 3 * half, half, true, stream);
+  return rc;
+}
+
+static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev, size_t half, bool accumulate,
+                             td_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   std::vector<WgradParams> tab[3];  // [0] general geometry, [1] pointwise, [2] wide tiles (conv_wgrad_wide_batch_kernel)
   double flops = 0, abytes = 0;
@@ -2026,9 +2167,10 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
     p.dbias = j.dbias;
     p.scale = j.scale;
     p.ci_real = j.ci_real;
-    p.out_mode = splits == 1 ? 2 : 1;
+    p.out_mode = (splits == 1 && !accumulate) ? 2 : 1;
+    TD_REQUIRE(!accumulate || !j.dbias, "td_conv_wgrad_batch: job %d: an accumulating job cannot carry a bias gradient", i);
     p.first = splits;  // (temporarily: the split count, replaced by the first workgroup index below)
-    if (splits > 1 &&
+    if (splits > 1 && !accumulate &&
         (hipMemsetAsync(j.dW, 0, (size_t)j.d.Nc * j.ci_real * j.d.R * j.d.S * sizeof(float), st) != hipSuccess ||
          (j.dbias && hipMemsetAsync(j.dbias, 0, (size_t)j.d.Nc * sizeof(float), st) != hipSuccess))) {
       set_error("td_conv_wgrad_batch: memset failed");

@@ -315,6 +315,7 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
       j.ldg = c.cout;
       j.ci_real = c.cin;
       j.dbias = nullptr;
+      j.accumulate = 0;
       jobs.push_back(j);
       return TD_OK;
     }
