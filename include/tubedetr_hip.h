@@ -296,10 +296,10 @@ int td_pos_sine(const uint8_t* mask, void* pos, int N, int h, int w, int npf, fl
  * instead of stored).  ld_* = row strides in elements, cols a multiple of 8 (bf16) / 4 (fp32). */
 int td_rows_copy(const void* src, const int* src_map, const void* add, void* dst, const int* dst_map, int n_rows, int cols, int ld_src,
                  int ld_add, int ld_dst, int dtype, td_stream_t stream);
-/* Segment sums over rows (the backward of that replication): out[r][0:cols] = sum_{j in [ptr[r], ptr[r+1])} in[idx[j]][0:cols], fp32
- * accumulation, r < n_out (ptr: device int32[n_out + 1], idx: device int32[ptr[n_out]]). */
-int td_rows_segment_sum(const void* in, const int* idx, const int* ptr, void* out, int n_out, int cols, int ld_in, int ld_out, int dtype,
-                        td_stream_t stream);
+/* Segment sums over rows (the backward of that replication): out[out_map[r]][0:cols] = sum_{j in [ptr[r], ptr[r+1])} in[idx[j]][0:cols],
+ * fp32 accumulation, r < n_out (ptr: device int32[n_out + 1], idx: device int32[ptr[n_out]], out_map: device int32[n_out] or NULL = r). */
+int td_rows_segment_sum(const void* in, const int* idx, const int* ptr, void* out, const int* out_map, int n_out, int cols, int ld_in,
+                        int ld_out, int dtype, td_stream_t stream);
 
 /* Multi-head attention core on already projected q,k,v (nn.MultiheadAttention internals,
  * models/transformer.py:613,638-640 encoder; 661,713-719 temporal self-attention; 662,734-740

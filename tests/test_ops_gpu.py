@@ -614,3 +614,145 @@ def test_dropout_masks_of_consecutive_steps_are_independent():
             b = mc[max(0, -shift) : n - max(0, shift)]
             agree = (a == b).float().mean().item()
             assert 0.45 < agree < 0.55, (c, shift, agree)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_pos_sine_writes_zero_text_rows(dt):
+    """rows_per_image > h*w: the rows behind the visual tokens are zeros (the text tokens' positional operand, transformer.py:323-326)."""
+    from oracle.tubedetr_oracle import pos_sine as pos_ref
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    mask = torch.rand(5, 7, 9, generator=g) > 0.7
+    mask[:, 0, 0] = False
+    S = 7 * 9 + 11
+    got = ops.pos_sine(mask.to(dev()), 128, dt, rows=S).float().cpu()
+    ref = pos_ref(mask, 128).flatten(2).permute(0, 2, 1)  # (N, hw, C)
+    assert got.shape == (5, S, 256)
+    assert (got[:, : 7 * 9] - ref).abs().max().item() < (1e-5 if dt == torch.float32 else 1e-2)
+    assert got[:, 7 * 9 :].abs().max().item() == 0
+
+
+LINEAR_EX = [
+    # M (mapped rows), rows1, rows2, K, N, maps?, residual?, shared weight?
+    (300, 77, 300, 256, 512, True, False, True),
+    (1000, 1000, 1000, 256, 256, False, False, True),
+    (40000, 9000, 40000, 256, 256, True, True, True),
+    (513, 200, 513, 64, 192, True, True, False),
+    (2000, 2000, 0, 256, 48, False, True, False),
+]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cfg", LINEAR_EX)
+def test_linear_ex_two_sources_and_row_maps(cfg, dt):
+    """td_linear_ex: [A1[a1_map] | A2] @ W^T (+ bias + residual[res_map]) written to out[out_map], shared and concatenated weights,
+    against the same arithmetic in fp32 torch on materialised operands."""
+    from tubedetr_amd import ops
+
+    M, rows1, rows2, K, N, mapped, with_res, shared = cfg
+    g = torch.Generator().manual_seed(M + N)
+    a1 = rnd((rows1, K), g, dt)
+    a2 = rnd((rows2, K), g, dt) if rows2 else None
+    w = rnd((N, K if (shared or a2 is None) else 2 * K), g, dt, 1.0 / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    a1_map = torch.randint(0, rows1, (M,), generator=g, dtype=torch.int32) if mapped else None
+    out_rows = M + 17 if mapped else M
+    out_map = torch.randperm(out_rows, generator=g)[:M].to(torch.int32) if mapped else None
+    res = rnd((rows1 if mapped else M, N), g, dt) if with_res else None
+    res_map = a1_map if (mapped and with_res) else None
+    X1 = a1[a1_map.long()] if mapped else a1[:M]
+    ref = X1 @ (w[:, :K]).t() + bias
+    if a2 is not None:
+        ref = ref + a2[:M] @ (w[:, :K] if shared else w[:, K:]).t()
+    if with_res:
+        ref = ref + (res[res_map.long()] if res_map is not None else res[:M])
+    ref = ref.relu()
+    d = dev()
+    to = lambda t_: None if t_ is None else t_.to(d, dt if t_.is_floating_point() else t_.dtype)
+    out = torch.full((out_rows, N), 7.0, dtype=dt, device=d)
+    ops.linear_ex(to(a1), to(w), bias.to(d), a2=to(a2), a1_map=to(a1_map), w_shared=shared, out=out, out_map=to(out_map), residual=to(res), res_map=to(res_map), relu=True)
+    got = out.float().cpu()
+    got_rows = got[out_map.long()] if mapped else got
+    assert rel_err(got_rows, ref) < TOL[dt], cfg
+    if mapped:  # rows no index points at stay untouched
+        untouched = torch.ones(out_rows, dtype=torch.bool)
+        untouched[out_map.long()] = False
+        assert (got[untouched] == 7.0).all()
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_rows_copy_and_segment_sum(dt):
+    from tubedetr_amd import ops
+
+    g = torch.Generator().manual_seed(12)
+    d = dev()
+    src = rnd((50, 256), g, dt)
+    add = rnd((120, 256), g, dt)
+    smap = torch.randint(0, 50, (120,), generator=g, dtype=torch.int32)
+    dmap = torch.randperm(200, generator=g)[:120].to(torch.int32)
+    dst = torch.full((200, 256), 3.0, dtype=dt, device=d)
+    ops.rows_copy(src.to(d, dt), smap.to(d), dst, dmap.to(d), 120)
+    got = dst.float().cpu()
+    assert torch.equal(got[dmap.long()], src[smap.long()])
+    dst2 = torch.empty((120, 256), dtype=dt, device=d)
+    ops.rows_copy(src.to(d, dt), smap.to(d), dst2, None, 120, add=add.to(d, dt))
+    assert rel_err(dst2.float().cpu(), src[smap.long()] + add) < TOL[dt]
+    # segment sums with ragged segments (incl. an empty one) and a scattered output
+    lens = torch.tensor([3, 0, 5, 1, 7, 2])
+    ptr = torch.zeros(7, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    idx = torch.randint(0, 120, (int(lens.sum()),), generator=g, dtype=torch.int32)
+    omap = torch.tensor([4, 0, 9, 2, 7, 5], dtype=torch.int32)
+    out = torch.full((10, 256), 5.0, dtype=dt, device=d)
+    ops.rows_segment_sum(add.to(d, dt), idx.to(d), ptr.to(d), out, omap.to(d))
+    got = out.float().cpu()
+    for r in range(6):
+        want = add[idx[ptr[r] : ptr[r + 1]].long()].sum(0)
+        assert (got[omap[r]] - want).abs().max().item() <= TOL[dt] * max(1.0, want.abs().max().item()), r
+    assert (got[[1, 3, 6, 8]] == 5.0).all()
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_replication_and_slow_fast_aggregation_match_indexing(dt):
+    """functional.SlowFastAggregateFn / ReplicateRowsFn (the temporal replication as an index inside its consumers) against the
+    reference's formulation on materialised tensors (transformer.py:393-445): forward and every gradient."""
+    from tubedetr_amd import functional as Fk
+
+    g = torch.Generator().manual_seed(31)
+    d_, hw, L, k = 256, 6, 3, 2
+    durations = [5, 4]
+    b, t = len(durations), max(durations)
+    n_clips = math.ceil(t / k)
+    n, S, F_ = b * n_clips, hw + L, b * t
+    owner = (torch.arange(b)[:, None] * n_clips + torch.arange(t)[None, :] // k).reshape(-1)
+    mem = rnd((n * S, d_), g, dt)
+    fast = rnd((F_ * hw, d_), g, dt)
+    W = rnd((d_, d_), g, dt, 1.0 / 16)
+    bias = torch.randn(d_, generator=g)
+    gy = rnd((F_ * S, d_), g, dt)
+    # reference formulation (fp32, materialised)
+    mr, fr, Wr, br = mem.clone().requires_grad_(), fast.clone().requires_grad_(), W.clone().requires_grad_(), bias.clone().requires_grad_()
+    frames = mr.view(n, S, d_)[owner]
+    vis = frames[:, :hw]
+    out_ref = torch.cat([vis + F.linear(vis + fr.view(F_, hw, d_), Wr, br), frames[:, hw:]], 1).reshape(F_ * S, d_)
+    out_ref.backward(gy)
+    dvc = dev()
+    maps = Fk.ReplicaMaps(owner, n, hw, L, dvc)
+    m2, f2 = mem.to(dvc, dt).requires_grad_(), fast.to(dvc, dt).requires_grad_()
+    W2, b2 = W.to(dvc).requires_grad_(), bias.to(dvc).requires_grad_()
+    out = Fk.SlowFastAggregateFn.apply(m2, f2, W2, b2, maps)
+    assert rel_err(out.float().cpu(), out_ref) < TOL[dt]
+    out.backward(gy.to(dvc, dt))
+    torch.cuda.synchronize()
+    for name, got, want in (("mem", m2.grad, mr.grad), ("fast", f2.grad, fr.grad), ("W", W2.grad, Wr.grad), ("b", b2.grad, br.grad)):
+        assert rel_err(got.float().cpu(), want) < 2 * TOL[dt], name
+    # --no_fast: plain replication
+    m3 = mem.to(dvc, dt).requires_grad_()
+    rep = Fk.ReplicateRowsFn.apply(m3, maps)
+    mr2 = mem.clone().requires_grad_()
+    rep_ref = mr2.view(n, S, d_)[owner].reshape(F_ * S, d_)
+    assert torch.equal(rep.float().cpu(), rep_ref.detach())
+    rep.backward(gy.to(dvc, dt))
+    rep_ref.backward(gy)
+    assert rel_err(m3.grad.float().cpu(), mr2.grad) < TOL[dt]

@@ -100,7 +100,7 @@ _SIGS = {
     "td_pos_sine": [_P, _P, _I, _I, _I, _I, _F, _I, _I, _P],
     "td_linear_ex": [_P, _P, _P, _P, C.POINTER(LinearExDesc), C.POINTER(Epilogue), _I, _P],
     "td_rows_copy": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "td_rows_segment_sum": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "td_rows_segment_sum": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "td_criterion_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "td_criterion_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "td_sted_decode": [_P, _P, _I, _I, _P],

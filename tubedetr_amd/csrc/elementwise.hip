@@ -473,7 +473,8 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(const char* __restrict__
 // out[r] = sum over its segment of input rows, fp32 accumulation: one thread per 16-byte run of an output row
 template <typename T>
 __global__ __launch_bounds__(256) void rows_segment_sum_kernel(const char* __restrict__ in, const int* __restrict__ idx, const int* __restrict__ ptr,
-                                                               char* __restrict__ out, int n_out, int chunks, int ld_in, int ld_out) {
+                                                               char* __restrict__ out, const int* __restrict__ out_map, int n_out, int chunks, int ld_in,
+                                                               int ld_out) {
   constexpr int EPL = 16 / sizeof(T);
   const size_t total = (size_t)n_out * chunks;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256) void rows_segment_sum_kernel(const char* __res
     } else {
       o = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
     }
-    *(uint4*)(out + ((size_t)r * ld_out + (size_t)c * EPL) * sizeof(T)) = o;
+    *(uint4*)(out + ((size_t)(out_map ? out_map[r] : r) * ld_out + (size_t)c * EPL) * sizeof(T)) = o;
   }
 }
 
@@ -696,8 +697,8 @@ extern "C" int td_rows_copy(const void* src, const int* src_map, const void* add
   return check_launch("td_rows_copy");
 }
 
-extern "C" int td_rows_segment_sum(const void* in, const int* idx, const int* ptr, void* out, int n_out, int cols, int ld_in, int ld_out, int dtype,
-                                   td_stream_t stream) {
+extern "C" int td_rows_segment_sum(const void* in, const int* idx, const int* ptr, void* out, const int* out_map, int n_out, int cols, int ld_in,
+                                   int ld_out, int dtype, td_stream_t stream) {
   TD_REQUIRE(in && idx && ptr && out, "td_rows_segment_sum: null pointer");
   if (n_out <= 0) return TD_OK;
   const int epl = dtype == TD_BF16 ? 8 : 4;
@@ -708,7 +709,7 @@ extern "C" int td_rows_segment_sum(const void* in, const int* idx, const int* pt
   hipStream_t st = (hipStream_t)stream;
   unsigned g = nblk((size_t)n_out * chunks);
   if (g > 16384) g = 16384;
-  TD_DISPATCH(dtype, (rows_segment_sum_kernel<u16><<<g, 256, 0, st>>>((const char*)in, idx, ptr, (char*)out, n_out, chunks, ld_in, ld_out)),
-              (rows_segment_sum_kernel<float><<<g, 256, 0, st>>>((const char*)in, idx, ptr, (char*)out, n_out, chunks, ld_in, ld_out)), "td_rows_segment_sum");
+  TD_DISPATCH(dtype, (rows_segment_sum_kernel<u16><<<g, 256, 0, st>>>((const char*)in, idx, ptr, (char*)out, out_map, n_out, chunks, ld_in, ld_out)),
+              (rows_segment_sum_kernel<float><<<g, 256, 0, st>>>((const char*)in, idx, ptr, (char*)out, out_map, n_out, chunks, ld_in, ld_out)), "td_rows_segment_sum");
   return check_launch("td_rows_segment_sum");
 }

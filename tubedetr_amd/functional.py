@@ -252,22 +252,28 @@ def _arm():
     torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrads)
 
 
-def _wgrad(g: Tensor, x: Tensor, defer: bool, *, want_bias: bool, out: Optional[Tensor] = None, dbias: Optional[Tensor] = None):
+def _wgrad(g: Tensor, x: Tensor, defer: bool, *, want_bias: bool, out: Optional[Tensor] = None, dbias: Optional[Tensor] = None,
+           x2: Optional[Tensor] = None):
     """(dW [N,K] fp32, db [N] fp32 | None) of a linear layer y = x W^T + b from g = dL/dy.  ``out`` / ``dbias``: row
     slices of a packed gradient (MHA in_proj) to write into.  defer=True: outputs are reserved now and filled by the
-    batched launch at the end of backward."""
+    batched launch at the end of backward.  ``x2``: second operand stream of a two-source layer y = (x + x2) W^T (the
+    positional operand, never added in memory): dW = g^T x + g^T x2, the second product as an accumulating job."""
     M, K = x.shape
     N = g.shape[1]
     dev = g.device
     if not defer:
         db = dbias if dbias is not None else (ops.zeros_f32(N, dev) if want_bias else None)
         dW = ops.linear_wgrad(g, x, out=out, dbias=db)
+        if x2 is not None:
+            ops.linear_wgrad(g, x2, out=dW)
         return dW, db
     dW = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
     db = dbias if dbias is not None else (torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None)
     with _DEFER_LOCK:
         # only raw pointers of the outputs are kept: a second reference would stop AccumulateGrad from adopting the tensor
         _DEFER_JOBS.append((g, x, dW.data_ptr(), db.data_ptr() if db is not None else None))
+        if x2 is not None:
+            _DEFER_JOBS.append((g, x2, dW.data_ptr(), None, True))
     return dW, db
 
 
@@ -397,24 +403,33 @@ class MHAFn(Function):
 
     q_in [B*Lq, E], k_in [B*Lk, E] (None = same tensor as q_in), v_in [B*Lk, E]; returns (out [B*Lq,E],
     wavg [B,Lq,Lk] fp32 or None).  The optional ``out_dropout`` is the residual-branch dropout that follows the
-    attention in the reference layers (dropout1 / dropout3), fused into the out_proj epilogue."""
+    attention in the reference layers (dropout1 / dropout3), fused into the out_proj epilogue.
+
+    ``q_pos`` [B*Lq, E] (or None): the positional operand of the query (and, for self-attention, key) projection -
+    ``with_pos_embed(x, pos)`` of the reference layers (transformer.py:637-640, 698, 735).  It is never added to x in memory:
+    the projection GEMM reads it as a second operand stream against the same weight (td_linear_ex), its weight gradient is a
+    second, accumulating job; the input gradient of the projection is the gradient of x AND of q_pos."""
 
     @staticmethod
-    def forward(ctx, q_in, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_w, p_attn, seed_attn, p_out, seed_out):
-        _note_use(ctx.needs_input_grad[3], W_in, b_in, W_out, b_out)
+    def forward(ctx, q_in, q_pos, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_w, p_attn, seed_attn, p_out, seed_out):
+        _note_use(ctx.needs_input_grad[4], W_in, b_in, W_out, b_out)
         E = q_in.shape[1]
         dt = q_in.dtype
         same_qk = k_in is None  # self-attention with q = k = x + pos: one fused [rows, 2E] projection
         bi = b_in.detach()
+
+        def proj(x_, w_, b_):
+            return ops.linear_ex(x_, w_, b_, a2=q_pos, w_shared=True) if q_pos is not None else ops.linear_fwd(x_, w_, b_)
+
         if same_qk:
             wqk_f, wqk_d, _, _ = prepared(W_in[: 2 * E], dt)
-            qk = ops.linear_fwd(q_in, wqk_f, bi[: 2 * E]).view(B, Lq, 2 * E)
+            qk = proj(q_in, wqk_f, bi[: 2 * E]).view(B, Lq, 2 * E)
             q, k = qk[..., :E], qk[..., E:]
             wd_list = (wqk_d,)
         else:
             wq_f, wq_d, _, _ = prepared(W_in[:E], dt)
             wk_f, wk_d, _, _ = prepared(W_in[E : 2 * E], dt)
-            q = ops.linear_fwd(q_in, wq_f, bi[:E]).view(B, Lq, E)
+            q = proj(q_in, wq_f, bi[:E]).view(B, Lq, E)
             k = ops.linear_fwd(k_in, wk_f, bi[E : 2 * E]).view(B, Lk, E)
             wd_list = (wq_d, wk_d)
         wv_f, wv_d, _, _ = prepared(W_in[2 * E :], dt)
@@ -429,7 +444,7 @@ class MHAFn(Function):
             kp = None
         wo_f, wo_d, _, _ = prepared(W_out, dt)
         out = ops.linear_fwd(ctxv.view(B * Lq, E), wo_f, b_out.detach(), dropout_p=p_out, seed=seed_out)
-        ctx.save_for_backward(q_in, k_in, v_in, q, k, v, probs, ctxv, wv_d, wo_d, *wd_list)
+        ctx.save_for_backward(q_in, q_pos, k_in, v_in, q, k, v, probs, ctxv, wv_d, wo_d, *wd_list)
         ctx.lean, ctx.kp = lean, kp
         ctx.cfg = (B, Lq, Lk, H, E, same_qk, scale, p_attn, seed_attn, p_out, seed_out)
         ctx.params = (W_in, b_in, W_out, b_out)
@@ -438,7 +453,7 @@ class MHAFn(Function):
     @staticmethod
     def backward(ctx, dout, dwavg):
         _arm()
-        q_in, k_in, v_in, q, k, v, probs, ctxv, wv_d, wo_d, *wd_list = ctx.saved_tensors
+        q_in, q_pos, k_in, v_in, q, k, v, probs, ctxv, wv_d, wo_d, *wd_list = ctx.saved_tensors
         B, Lq, Lk, H, E, same_qk, scale, p_attn, seed_attn, p_out, seed_out = ctx.cfg
         dt = q_in.dtype
         dev = q_in.device
@@ -466,52 +481,56 @@ class MHAFn(Function):
             ops.mha_bwd(q, k, v, dctx, probs, dwa, H, scale, dq, dk, dv, dropout_p=p_attn, seed=seed_attn)
         dv2 = dv.view(B * Lk, E)
         _wgrad(dv2, v_in, defer, want_bias=True, out=dW_in[2 * E :], dbias=db_in[2 * E :])
-        d_v_in = ops.linear_fwd(dv2, wv_d) if ctx.needs_input_grad[2] else None
+        d_v_in = ops.linear_fwd(dv2, wv_d) if ctx.needs_input_grad[3] else None
         d_q_in = d_k_in = None
+        need_q = ctx.needs_input_grad[0] or (q_pos is not None and ctx.needs_input_grad[1])
         if same_qk:
             dqk2 = dqk.view(B * Lq, 2 * E)
-            _wgrad(dqk2, q_in, defer, want_bias=True, out=dW_in[: 2 * E], dbias=db_in[: 2 * E])
-            if ctx.needs_input_grad[0]:
+            _wgrad(dqk2, q_in, defer, want_bias=True, out=dW_in[: 2 * E], dbias=db_in[: 2 * E], x2=q_pos)
+            if need_q:
                 d_q_in = ops.linear_fwd(dqk2, wd_list[0])
         else:
             dq2, dk2 = dq.view(B * Lq, E), dk.view(B * Lk, E)
-            _wgrad(dq2, q_in, defer, want_bias=True, out=dW_in[:E], dbias=db_in[:E])
+            _wgrad(dq2, q_in, defer, want_bias=True, out=dW_in[:E], dbias=db_in[:E], x2=q_pos)
             _wgrad(dk2, k_in, defer, want_bias=True, out=dW_in[E : 2 * E], dbias=db_in[E : 2 * E])
-            if ctx.needs_input_grad[0]:
+            if need_q:
                 d_q_in = ops.linear_fwd(dq2, wd_list[0])
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[2]:
                 d_k_in = ops.linear_fwd(dk2, wd_list[1])
-        return (d_q_in, d_k_in, d_v_in, dW_in, db_in, dW_out, db_out) + (None,) * 10
+        # d(x + pos) flows to both operands of the projection
+        return (d_q_in if ctx.needs_input_grad[0] else None, d_q_in if (q_pos is not None and ctx.needs_input_grad[1]) else None, d_k_in, d_v_in,
+                dW_in, db_in, dW_out, db_out) + (None,) * 10
 
 
 class _CrossKVShared:
     """Side channel between CrossKVFn and the six cross-attention nodes that consume its output: the key / value gradients of
     all layers land in ONE [rows, layers * E] buffer each (every layer's attention backward writes its own column block),
-    so the engine has nothing to accumulate and the hoisted node turns them into d(memory) with one GEMM."""
+    so the engine has nothing to accumulate and the hoisted node turns them into d(memory) with two chained GEMMs."""
 
-    def __init__(self, mem_k, mem_v, n_layers, E):
-        self.mem_k, self.mem_v, self.n_layers, self.E = mem_k, mem_v, n_layers, E
+    def __init__(self, mem, pos, n_layers, E):
+        self.mem, self.pos, self.n_layers, self.E = mem, pos, n_layers, E
         self.dK = self.dV = None
         self.written = set()
         self.wk_d = self.wv_d = None  # concatenated input-gradient weights [E, layers * E]
 
     def grads(self, like):
         if self.dK is None:
-            self.dK = torch.empty((self.mem_k.shape[0], self.n_layers * self.E), dtype=like.dtype, device=like.device)
+            self.dK = torch.empty((self.mem.shape[0], self.n_layers * self.E), dtype=like.dtype, device=like.device)
             self.dV = torch.empty_like(self.dK)
         return self.dK, self.dV
 
 
 class CrossKVFn(Function):
     """The key and value projections of ALL decoder layers' time-aligned cross-attention in two GEMMs (the memory is the same
-    for the six layers, transformer.py:734-740): K_all = mem_k [W_k,0 | ... | W_k,5]^T + b, V_all likewise, [rows, layers * E].
+    for the six layers, transformer.py:734-740): K_all = (mem + pos) [W_k,0 | ... | W_k,5]^T + b with pos as the GEMM's second
+    operand stream (td_linear_ex: ``memory + pos`` is never formed), V_all = mem [W_v,0 | ...]^T + b, [rows, layers * E].
     The parameters stay with their layers (each layer's node returns the gradient of its whole in_proj); this node only owns
-    d(mem_k), d(mem_v): one GEMM each over the column-concatenated gradients (K = layers * E) instead of 2 x layers GEMMs whose
-    results the autograd engine would sum with 2 x (layers - 1) elementwise launches."""
+    d(mem): two chained GEMMs over the column-concatenated gradients (K = layers * E), the second adding onto the first in
+    its epilogue - instead of 2 x layers GEMMs whose results the autograd engine would sum with elementwise launches."""
 
     @staticmethod
-    def forward(ctx, mem_k, mem_v, shared, *w_and_b):
-        E, dt = shared.E, mem_k.dtype
+    def forward(ctx, mem, pos, shared, *w_and_b):
+        E, dt = shared.E, mem.dtype
         Ws, bs = w_and_b[0::2], w_and_b[1::2]
         kf, vf, kd, vd = [], [], [], []
         for W in Ws:
@@ -521,8 +540,9 @@ class CrossKVFn(Function):
             vf.append(f); vd.append(d_)
         bk = torch.cat([b.detach()[E : 2 * E] for b in bs])
         bv = torch.cat([b.detach()[2 * E :] for b in bs])
-        K_all = ops.linear_fwd(mem_k, torch.cat(kf, dim=0), bk)
-        V_all = ops.linear_fwd(mem_v, torch.cat(vf, dim=0), bv)
+        wk = torch.cat(kf, dim=0)
+        K_all = ops.linear_ex(mem, wk, bk, a2=pos, w_shared=True) if pos is not None else ops.linear_fwd(mem, wk, bk)
+        V_all = ops.linear_fwd(mem, torch.cat(vf, dim=0), bv)
         shared.wk_d, shared.wv_d = torch.cat(kd, dim=1), torch.cat(vd, dim=1)
         ctx.shared = shared
         ctx.set_materialize_grads(False)
@@ -538,9 +558,11 @@ class CrossKVFn(Function):
             if l not in sh.written:
                 sh.dK[:, l * sh.E : (l + 1) * sh.E].zero_()
                 sh.dV[:, l * sh.E : (l + 1) * sh.E].zero_()
-        d_mem_k = ops.linear_fwd(sh.dK, sh.wk_d) if ctx.needs_input_grad[0] else None
-        d_mem_v = ops.linear_fwd(sh.dV, sh.wv_d) if ctx.needs_input_grad[1] else None
-        return (d_mem_k, d_mem_v, None) + (None,) * (2 * sh.n_layers)
+        d_mem = None
+        if ctx.needs_input_grad[0]:
+            d_mem = ops.linear_fwd(sh.dK, sh.wk_d)
+            d_mem = ops.linear_fwd(sh.dV, sh.wv_d, residual=d_mem, out=d_mem)  # (+=: every element is read and written by the same lane)
+        return (d_mem, None, None) + (None,) * (2 * sh.n_layers)
 
 
 class MHAPreKVFn(Function):
@@ -550,20 +572,23 @@ class MHAPreKVFn(Function):
     rows) is produced here, so the parameter has a single owner and its weight gradients stay deferrable."""
 
     @staticmethod
-    def forward(ctx, q_in, K_all, V_all, W_in, b_in, W_out, b_out, key_pad, shared, layer, B, Lq, Lk, H, need_w, p_attn, seed_attn, p_out, seed_out):
-        _note_use(ctx.needs_input_grad[3], W_in, b_in, W_out, b_out)
+    def forward(ctx, q_in, q_pos, K_all, V_all, W_in, b_in, W_out, b_out, key_pad, shared, layer, B, Lq, Lk, H, need_w, p_attn, seed_attn, p_out, seed_out):
+        _note_use(ctx.needs_input_grad[4], W_in, b_in, W_out, b_out)
         E = q_in.shape[1]
         dt = q_in.dtype
         nl = shared.n_layers
         wq_f, wq_d, _, _ = prepared(W_in[:E], dt)
-        q = ops.linear_fwd(q_in, wq_f, b_in.detach()[:E]).view(B, Lq, E)
+        if q_pos is not None:  # tgt + query_pos as two operand streams of the projection (transformer.py:735)
+            q = ops.linear_ex(q_in, wq_f, b_in.detach()[:E], a2=q_pos, w_shared=True).view(B, Lq, E)
+        else:
+            q = ops.linear_fwd(q_in, wq_f, b_in.detach()[:E]).view(B, Lq, E)
         k = K_all.view(B, Lk, nl * E)[..., layer * E : (layer + 1) * E]
         v = V_all.view(B, Lk, nl * E)[..., layer * E : (layer + 1) * E]
         scale = 1.0 / math.sqrt(E // H)
         ctxv, probs, wavg = ops.mha_fwd(q, k, v, key_pad, H, scale, need_wavg=need_w, dropout_p=p_attn, seed=seed_attn)
         wo_f, wo_d, _, _ = prepared(W_out, dt)
         out = ops.linear_fwd(ctxv.view(B * Lq, E), wo_f, b_out.detach(), dropout_p=p_out, seed=seed_out)
-        ctx.save_for_backward(q_in, q, K_all, V_all, probs, ctxv, wq_d, wo_d)
+        ctx.save_for_backward(q_in, q_pos, q, K_all, V_all, probs, ctxv, wq_d, wo_d)
         ctx.cfg = (B, Lq, Lk, H, E, scale, p_attn, seed_attn, p_out, seed_out, layer)
         ctx.params = (W_in, b_in, W_out, b_out)
         ctx.shared = shared
@@ -572,7 +597,7 @@ class MHAPreKVFn(Function):
     @staticmethod
     def backward(ctx, dout, dwavg):
         _arm()
-        q_in, q, K_all, V_all, probs, ctxv, wq_d, wo_d = ctx.saved_tensors
+        q_in, q_pos, q, K_all, V_all, probs, ctxv, wq_d, wo_d = ctx.saved_tensors
         B, Lq, Lk, H, E, scale, p_attn, seed_attn, p_out, seed_out, layer = ctx.cfg
         sh = ctx.shared
         nl = sh.n_layers
@@ -598,31 +623,155 @@ class MHAPreKVFn(Function):
         ops.mha_bwd(q, k, v, dctx, probs, dwa, H, scale, dq, dk, dv, dropout_p=p_attn, seed=seed_attn)
         sh.written.add(layer)
         dq2 = dq.view(B * Lq, E)
-        _wgrad(dq2, q_in, defer, want_bias=True, out=dW_in[:E], dbias=db_in[:E])
-        _wgrad(dK_all[:, cols], sh.mem_k, defer, want_bias=True, out=dW_in[E : 2 * E], dbias=db_in[E : 2 * E])
-        _wgrad(dV_all[:, cols], sh.mem_v, defer, want_bias=True, out=dW_in[2 * E :], dbias=db_in[2 * E :])
-        d_q_in = ops.linear_fwd(dq2, wq_d) if ctx.needs_input_grad[0] else None
-        return (d_q_in, None, None, dW_in, db_in, dW_out, db_out) + (None,) * 12
+        _wgrad(dq2, q_in, defer, want_bias=True, out=dW_in[:E], dbias=db_in[:E], x2=q_pos)
+        _wgrad(dK_all[:, cols], sh.mem, defer, want_bias=True, out=dW_in[E : 2 * E], dbias=db_in[E : 2 * E], x2=sh.pos)
+        _wgrad(dV_all[:, cols], sh.mem, defer, want_bias=True, out=dW_in[2 * E :], dbias=db_in[2 * E :])
+        need_pos = q_pos is not None and ctx.needs_input_grad[1]
+        d_q_in = ops.linear_fwd(dq2, wq_d) if (ctx.needs_input_grad[0] or need_pos) else None
+        return (d_q_in if ctx.needs_input_grad[0] else None, d_q_in if need_pos else None, None, None, dW_in, db_in, dW_out, db_out) + (None,) * 12
 
 
-def cross_kv(mem_k, mem_v, attn_modules):
-    """-> (K_all, V_all, shared) for ``multihead_attention_prekv``; attn_modules: the layers' cross-attention parameter holders."""
+def cross_kv(mem, pos, attn_modules):
+    """-> (K_all, V_all, shared) for ``multihead_attention_prekv``: keys from mem + pos (pos: rows like mem, or None), values from
+    mem; attn_modules: the layers' cross-attention parameter holders."""
     E = attn_modules[0].embed_dim
-    shared = _CrossKVShared(mem_k, mem_v, len(attn_modules), E)
+    shared = _CrossKVShared(mem, pos, len(attn_modules), E)
     flat = []
     for m in attn_modules:
         flat += [m.in_proj_weight, m.in_proj_bias]
-    K_all, V_all = CrossKVFn.apply(mem_k, mem_v, shared, *flat)
+    K_all, V_all = CrossKVFn.apply(mem, pos, shared, *flat)
     return K_all, V_all, shared
 
 
 def multihead_attention_prekv(q_in, kv, layer, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_weights=False, attn_dropout=0.0,
-                              out_dropout=0.0, training=False):
+                              out_dropout=0.0, training=False, q_pos=None):
     pa = attn_dropout if training else 0.0
     po = out_dropout if training else 0.0
     K_all, V_all, shared = kv
-    return MHAPreKVFn.apply(q_in, K_all, V_all, W_in, b_in, W_out, b_out, key_pad, shared, layer, B, Lq, Lk, H, need_weights,
+    return MHAPreKVFn.apply(q_in, q_pos, K_all, V_all, W_in, b_in, W_out, b_out, key_pad, shared, layer, B, Lq, Lk, H, need_weights,
                             pa, _seed() if pa > 0 else 0, po, _seed() if po > 0 else 0)
+
+
+class ReplicaMaps:
+    """Index vectors of the temporal replication (transformer.py:393-427: frame (i, j) of video i takes the memory of clip
+    i * n_clips + j // k), built once per (durations, stride, hw, L) on the host and kept on the device.  Rows of the clip
+    memory are c * S + s, rows of the frame memory f * S + s (S = hw visual + L text tokens).
+
+      vis_src / vis_dst   [F * hw]   clip row / frame row of every visual token of every frame
+      txt_src / txt_dst   [F * L]    the same for the text tokens
+      all_src             [F * S]    clip row of every frame row (--no_fast: the whole memory is replicated)
+      seg_*               CSR lists "frame rows summed into this clip row" for the backward: visual rows (compact output
+                          [n * hw]), text rows (output rows clip_txt), all rows
+      clip_vis / clip_txt [n * hw] / [n * L]  clip rows of the visual / text tokens"""
+
+    def __init__(self, owner, n: int, hw: int, L: int, device):
+        owner = owner.cpu().long()
+        F, S = owner.numel(), hw + L
+        i32 = lambda t_: t_.to(torch.int32).contiguous().to(device)
+        p, l_ = torch.arange(hw), torch.arange(L)
+        f = torch.arange(F)
+        self.F, self.n, self.hw, self.L, self.S = F, n, hw, L, S
+        self.vis_src = i32((owner[:, None] * S + p[None, :]).reshape(-1))
+        self.vis_dst = i32((f[:, None] * S + p[None, :]).reshape(-1))
+        self.txt_src = i32((owner[:, None] * S + hw + l_[None, :]).reshape(-1))
+        self.txt_dst = i32((f[:, None] * S + hw + l_[None, :]).reshape(-1))
+        self.all_src = i32((owner[:, None] * S + torch.arange(S)[None, :]).reshape(-1))
+        c = torch.arange(n)
+        self.iota_vis = i32(torch.arange(n * hw))  # identity (a residual read by compact row while the output row is mapped)
+        self.clip_vis = i32((c[:, None] * S + p[None, :]).reshape(-1))
+        self.clip_txt = i32((c[:, None] * S + hw + l_[None, :]).reshape(-1))
+        # frames of every clip, in frame order (owner is non-decreasing by construction, but nothing here relies on it)
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=n)
+        starts = torch.cumsum(counts, 0) - counts
+
+        def csr(cols, row_off):
+            """output row (c, j) sums the input rows frame * S + row_off + j over the frames of clip c (input = frame-memory rows)"""
+            m = cols.numel()
+            per = counts[:, None].expand(n, m).reshape(-1)           # segment length of output row (c, j)
+            ptr = torch.zeros(n * m + 1, dtype=torch.long)
+            ptr[1:] = torch.cumsum(per, 0)
+            idx = torch.empty(int(ptr[-1]), dtype=torch.long)
+            for ci in range(n):  # n is the number of clips (tens to hundreds): host work done once per batch pattern
+                fr = order[starts[ci] : starts[ci] + counts[ci]]
+                blk = (fr[None, :] * S + row_off + cols[:, None]).reshape(-1)   # [m, count] -> row-major: segment of (c, j) contiguous
+                idx[ptr[ci * m] : ptr[ci * m] + blk.numel()] = blk
+            return i32(idx), i32(ptr)
+
+        self.seg_vis = csr(p, 0)
+        self.seg_txt = csr(l_, hw)
+        self.seg_all = csr(torch.arange(S), 0)
+
+
+class ReplicateRowsFn(Function):
+    """frames[f * S + s] = mem[owner[f] * S + s]: the temporal replication as ONE gather pass of 16-byte accesses (td_rows_copy)
+    instead of a Python loop of slice assignments; backward = segment sums over the frames of each clip (td_rows_segment_sum).
+    The default (slow-fast) model never runs this for the visual tokens - SlowFastAggregateFn reads the clip rows through the
+    index inside its GEMM; it serves --no_fast, where the replicated memory itself is what the decoder attends to."""
+
+    @staticmethod
+    def forward(ctx, mem, maps):
+        out = torch.empty((maps.F * maps.S, mem.shape[1]), dtype=mem.dtype, device=mem.device)
+        ops.rows_copy(mem, maps.all_src, out, None, maps.F * maps.S)
+        ctx.maps, ctx.rows = maps, mem.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        maps = ctx.maps
+        g = g.contiguous()
+        d_mem = torch.empty((ctx.rows, g.shape[1]), dtype=g.dtype, device=g.device)
+        ops.rows_segment_sum(g, maps.seg_all[0], maps.seg_all[1], d_mem)
+        return d_mem, None
+
+
+class SlowFastAggregateFn(Function):
+    """Temporal replication + slow-fast aggregation (transformer.py:393-445) producing the frame memory [F * S, d] directly:
+
+        frames[f, p]      = vis + fast_residual(vis + fast_mem[f, p]),   vis = mem[owner[f], p]      (visual tokens)
+        frames[f, hw + l] = mem[owner[f], hw + l]                                                    (text tokens)
+
+    ONE GEMM (td_linear_ex) reads the clip rows through the replication index as its first operand stream, the fast
+    features as its second (same weight: (vis + fast) W^T), takes the residual through the same index and writes straight
+    into the frame rows; one gather pass copies the text rows.  Neither mem[owner], nor vis + fast_mem, nor a concatenation
+    exists in memory.  Backward: by linearity the replication's segment sum commutes with the aggregation -
+    d_mem[vis] = G + G Wr with G = segment sum of the visual-row gradients (a GEMM over n * hw clip rows instead of F * hw frame
+    rows); the mix operand of the weight gradient is re-formed (gather + add in one pass) instead of having been stored."""
+
+    @staticmethod
+    def forward(ctx, mem, fast_mem, W, b, maps):
+        _note_use(ctx.needs_input_grad[2], W, b)
+        dt = mem.dtype
+        wf, wd, _, _ = prepared(W, dt)
+        frames = torch.empty((maps.F * maps.S, mem.shape[1]), dtype=dt, device=mem.device)
+        ops.linear_ex(mem, wf, b.detach(), a1_map=maps.vis_src, a2=fast_mem, w_shared=True, residual=mem, res_map=maps.vis_src, out=frames, out_map=maps.vis_dst)
+        ops.rows_copy(mem, maps.txt_src, frames, maps.txt_dst, maps.F * maps.L)
+        ctx.save_for_backward(mem, fast_mem, wd)
+        ctx.maps, ctx.params = maps, (W, b)
+        return frames
+
+    @staticmethod
+    def backward(ctx, g):
+        _arm()
+        mem, fast_mem, wd = ctx.saved_tensors
+        maps = ctx.maps
+        g = g.contiguous()
+        d, dt, dev = g.shape[1], g.dtype, g.device
+        n_vis = maps.F * maps.hw
+        g_vis = torch.empty((n_vis, d), dtype=dt, device=dev)
+        ops.rows_copy(g, maps.vis_dst, g_vis, None, n_vis)                       # visual-row gradients, compact
+        d_fast = ops.linear_fwd(g_vis, wd) if ctx.needs_input_grad[1] else None   # d(vis + fast) = g Wr
+        mix = torch.empty((n_vis, d), dtype=dt, device=dev)
+        ops.rows_copy(mem, maps.vis_src, mix, None, n_vis, add=fast_mem)          # vis + fast_mem, re-formed for the weight gradient
+        dW, db = _wgrad(g_vis, mix, _can_defer(*ctx.params), want_bias=True)
+        d_mem = None
+        if ctx.needs_input_grad[0]:
+            d_mem = torch.empty_like(mem)
+            ops.rows_segment_sum(g, maps.seg_txt[0], maps.seg_txt[1], d_mem, maps.clip_txt)
+            G = torch.empty((maps.n * maps.hw, d), dtype=dt, device=dev)
+            ops.rows_segment_sum(g, maps.seg_vis[0], maps.seg_vis[1], G)
+            ops.linear_ex(G, wd, None, residual=G, res_map=maps.iota_vis, out=d_mem, out_map=maps.clip_vis)  # d_mem[vis] = G + G Wr
+        return d_mem, d_fast, dW, db, None
 
 
 class AttnCoreFn(Function):
@@ -655,10 +804,10 @@ def attention_core(q, k, v, key_pad, B, Lq, Lk, H, dropout_p=0.0, training=False
 
 
 def multihead_attention(q_in, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_weights=False,
-                        attn_dropout=0.0, out_dropout=0.0, training=False):
+                        attn_dropout=0.0, out_dropout=0.0, training=False, q_pos=None):
     pa = attn_dropout if training else 0.0
     po = out_dropout if training else 0.0
-    return MHAFn.apply(q_in, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_weights,
+    return MHAFn.apply(q_in, q_pos, k_in, v_in, W_in, b_in, W_out, b_out, key_pad, B, Lq, Lk, H, need_weights,
                        pa, _seed() if pa > 0 else 0, po, _seed() if po > 0 else 0)
 
 

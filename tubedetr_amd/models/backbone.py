@@ -342,12 +342,16 @@ class Joiner(nn.Sequential):
         self[0].compute_dtype = dt
         self[1].compute_dtype = dt
 
-    def forward(self, tensor_list: NestedTensor, n_grad=None):
+    def forward(self, tensor_list: NestedTensor, n_grad=None, want_pos: bool = True):
+        """-> (features, pos) like the reference (backbone.py:225-233).  ``want_pos=False`` (TubeDETR's own call when the
+        encoding is the sine one): pos entries are None - the transformer then produces the positional operand itself, straight
+        from the pad mask and already extended by the zero rows of the text tokens (td_pos_sine), instead of receiving a
+        tensor it would have to concatenate zeros to."""
         xs = self[0](tensor_list, n_grad)
         out, pos = [], []
         for _, x in xs.items():
             out.append(x)
-            pos.append(self[1](x))
+            pos.append(self[1](x) if want_pos else None)
         return out, pos
 
 

@@ -26,6 +26,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import functional as Fk
+from .. import ops as _ops
 from ..util.misc import LRUCache
 from .position_encoding import TimeEmbeddingLearned, TimeEmbeddingSine
 
@@ -45,15 +46,18 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.0)
 
-    def run_prekv(self, q_in, kv, layer, key_pad, B, Lq, Lk, need_weights, out_dropout, training):
+    def run_prekv(self, q_in, kv, layer, key_pad, B, Lq, Lk, need_weights, out_dropout, training, q_pos=None):
         """Keys / values already projected for all layers (functional.cross_kv): this layer reads column block ``layer``."""
         return Fk.multihead_attention_prekv(q_in, kv, layer, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight, self.out_proj.bias, key_pad,
-                                            B, Lq, Lk, self.num_heads, need_weights, attn_dropout=self.dropout, out_dropout=out_dropout, training=training)
+                                            B, Lq, Lk, self.num_heads, need_weights, attn_dropout=self.dropout, out_dropout=out_dropout, training=training,
+                                            q_pos=q_pos)
 
-    def run(self, q_in, k_in, v_in, key_pad, B, Lq, Lk, need_weights, out_dropout, training):
+    def run(self, q_in, k_in, v_in, key_pad, B, Lq, Lk, need_weights, out_dropout, training, q_pos=None):
+        """q_pos: the positional operand of the query (self-attention: query and key) projection - with_pos_embed() of the
+        reference layers as a second operand stream of the projection GEMM, never added in memory (functional.MHAFn)."""
         return Fk.multihead_attention(q_in, k_in, v_in, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight,
                                       self.out_proj.bias, key_pad, B, Lq, Lk, self.num_heads, need_weights,
-                                      attn_dropout=self.dropout, out_dropout=out_dropout, training=training)
+                                      attn_dropout=self.dropout, out_dropout=out_dropout, training=training, q_pos=q_pos)
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -70,8 +74,8 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, src: Tensor, pos: Optional[Tensor], key_pad: Optional[Tensor], B: int, S: int) -> Tensor:
         """src, pos: rows [B*S, d] (batch-major); post-norm layer of transformer.py:629-646."""
-        qk = Fk.AddFn.apply(src, pos) if pos is not None else src
-        a, _ = self.self_attn.run(qk, None, src, key_pad, B, S, S, False, self.p, self.training)
+        # q = k = src + pos (transformer.py:637-640): pos is the projection's second operand stream, not a materialised sum
+        a, _ = self.self_attn.run(src, None, src, key_pad, B, S, S, False, self.p, self.training, q_pos=pos)
         src = Fk.add_layernorm(a, src, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         f = Fk.ffn(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.p, self.training)
         return Fk.add_layernorm(f, src, self.norm2.weight, self.norm2.bias, self.norm2.eps)
@@ -109,20 +113,21 @@ class TransformerDecoderLayer(nn.Module):
         self.p = dropout
         self.no_tsa = no_tsa
 
-    def forward(self, tgt, query_pos, mem_k, mem_v, query_mask, memory_mask, b: int, t: int, S: int, kv=None, index: int = 0):
-        """tgt/query_pos rows [b*t, d] (video-major frames); mem_k = memory+pos, mem_v = memory rows [b*t*S, d]
-        (transformer.py:684-751).  kv: the hoisted key / value projections of all layers (TransformerDecoder.forward)."""
-        qk = Fk.AddFn.apply(tgt, query_pos)
+    def forward(self, tgt, query_pos, mem, pos, query_mask, memory_mask, b: int, t: int, S: int, kv=None, index: int = 0):
+        """tgt/query_pos rows [b*t, d] (video-major frames); mem / pos = memory and its positional rows [b*t*S, d]
+        (transformer.py:684-751).  kv: the hoisted key / value projections of all layers (TransformerDecoder.forward).
+        Every with_pos_embed() of the reference layer (tgt + query_pos for the self-attention's q = k and the cross-attention's
+        query, memory + pos for its keys) is a second operand stream of the projection GEMM."""
         if self.no_tsa:  # every frame attends to itself only: sequence length 1 (transformer.py:701-711)
-            a, w = self.self_attn.run(qk, None, tgt, None, b * t, 1, 1, True, self.p, self.training)
+            a, w = self.self_attn.run(tgt, None, tgt, None, b * t, 1, 1, True, self.p, self.training, q_pos=query_pos)
         else:
-            a, w = self.self_attn.run(qk, None, tgt, query_mask, b, t, t, True, self.p, self.training)
+            a, w = self.self_attn.run(tgt, None, tgt, query_mask, b, t, t, True, self.p, self.training, q_pos=query_pos)
         tgt = Fk.add_layernorm(a, tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qc = Fk.AddFn.apply(tgt, query_pos)
         if kv is not None:
-            a, cw = self.cross_attn_image.run_prekv(qc, kv, index, memory_mask, b * t, 1, S, True, self.p, self.training)
-        else:
-            a, cw = self.cross_attn_image.run(qc, mem_k, mem_v, memory_mask, b * t, 1, S, True, self.p, self.training)
+            a, cw = self.cross_attn_image.run_prekv(tgt, kv, index, memory_mask, b * t, 1, S, True, self.p, self.training, q_pos=query_pos)
+        else:  # (TD_KV_HOIST=0, A/B only: per-layer key / value projections over a materialised memory + pos)
+            mem_k = Fk.AddFn.apply(mem, pos) if pos is not None else mem
+            a, cw = self.cross_attn_image.run(tgt, mem_k, mem, memory_mask, b * t, 1, S, True, self.p, self.training, q_pos=query_pos)
         tgt = Fk.add_layernorm(a, tgt, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         f = Fk.ffn(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.p, self.training)
         tgt = Fk.add_layernorm(f, tgt, self.norm4.weight, self.norm4.bias, self.norm4.eps)
@@ -138,13 +143,14 @@ class TransformerDecoder(nn.Module):
         self.return_intermediate = return_intermediate
         self.return_weights = return_weights
 
-    def forward(self, tgt, query_pos, mem_k, mem_v, query_mask, memory_mask, b, t, S):
+    def forward(self, tgt, query_pos, mem, pos, query_mask, memory_mask, b, t, S):
         inter, ws, cws = [], [], []
         out = tgt
-        # one key and one value projection GEMM for the six layers' shared memory (functional.CrossKVFn)
-        kv = Fk.cross_kv(mem_k, mem_v, [l.cross_attn_image for l in self.layers]) if os.environ.get("TD_KV_HOIST", "1") != "0" else None
+        # one key and one value projection GEMM for the six layers' shared memory (functional.CrossKVFn); keys = memory + pos
+        # with pos as the GEMM's second operand stream
+        kv = Fk.cross_kv(mem, pos, [l.cross_attn_image for l in self.layers]) if os.environ.get("TD_KV_HOIST", "1") != "0" else None
         for i, layer in enumerate(self.layers):
-            out, w, cw = layer(out, query_pos, mem_k, mem_v, query_mask, memory_mask, b, t, S, kv=kv, index=i)
+            out, w, cw = layer(out, query_pos, mem, pos, query_mask, memory_mask, b, t, S, kv=kv, index=i)
             if self.return_intermediate:
                 inter.append(Fk.add_layernorm(out, None, self.norm.weight, self.norm.bias, self.norm.eps))
                 ws.append(w)
@@ -264,6 +270,7 @@ class Transformer(nn.Module):
         self.expander_dropout = 0.1
         self.resizer = FeatureResizer(self.text_encoder.config.hidden_size, d_model, self.expander_dropout)
         self.d_model, self.nhead = d_model, nhead
+        self.sine_pos = None  # (num_pos_feats, temperature) of the backbone's PositionEmbeddingSine, set by TubeDETR: forward(pos_embed=None, pos_mask=...)
         self.video_max_len, self.stride = video_max_len, stride
         self.compute_dtype = torch.float32
         self.hip_text_encoder = __import__("os").environ.get("TD_HIP_ROBERTA", "1") != "0"  # 0: HF RobertaModel as a torch module
@@ -287,6 +294,13 @@ class Transformer(nn.Module):
                 nn.init.constant_(p, 0)
 
     # ---- helpers ----
+    def _replica_maps(self, durations, n_clips, owner, n, hw, L, device):
+        key = ("maps", tuple(durations), n_clips, self.stride, hw, L, str(device))
+        hit = self._idx_cache.get(key)
+        if hit is None:
+            hit = self._idx_cache[key] = Fk.ReplicaMaps(owner, n, hw, L, device)
+        return hit
+
     def _indices(self, durations, n_clips_per_video: int, device):
         """owner clip of every (video, frame) and the per-clip / per-frame video index; cached per durations."""
         key = (tuple(durations), n_clips_per_video, str(device))
@@ -361,18 +375,18 @@ class Transformer(nn.Module):
 
     def forward(self, src=None, mask=None, query_embed=None, pos_embed=None, text=None, encode_and_save=True, durations=None,
                 tpad_mask_t=None, fast_src=None, img_memory=None, query_mask=None, text_memory=None, text_mask=None,
-                memory_mask=None):
+                memory_mask=None, pos_mask=None):
         if not self.pass_pos_and_query:
             # the reference sets pos_embed = None in this mode (transformer.py:242-248) and then concatenates it with the text
             # rows (:325, TypeError), and its decode branch adds to a `src` that is None (:463-469): the flag cannot complete a
             # step there either, so the same failure class is raised here instead of silently running something else
             raise TypeError("pass_pos_and_query=False: the reference's Transformer.forward fails in this mode (models/transformer.py:242-248 -> 325, 463-469)")
         if encode_and_save:
-            return self._encode(src, mask, query_embed, pos_embed, text, durations, tpad_mask_t, fast_src)
+            return self._encode(src, mask, query_embed, pos_embed, text, durations, tpad_mask_t, fast_src, pos_mask)
         return self._decode(img_memory, mask, pos_embed, query_embed, query_mask)
 
     # ---- encode (transformer.py:195-460) ----
-    def _encode(self, src, mask, query_embed, pos_embed, text, durations, tpad_mask_t, fast_src):
+    def _encode(self, src, mask, query_embed, pos_embed, text, durations, tpad_mask_t, fast_src, pos_mask=None):
         n, d, h, w = src.shape  # (n_clips_total, d, h, w) channels-last view of NHWC rows
         dev, dt = src.device, self.compute_dtype
         hw = h * w
@@ -380,7 +394,6 @@ class Transformer(nn.Module):
         n_clips = math.ceil(t / self.stride) if self.stride else t  # stride 0 (dense ablation): one clip per frame, no replication
         assert n == b * n_clips, "every video of the batch must yield the same number of slow clips"
         src_bm = src.permute(0, 2, 3, 1).reshape(n, hw, d)  # zero-copy when src is channels-last
-        pos_bm = pos_embed.permute(0, 2, 3, 1).reshape(n, hw, d)
         # all index / mask tensors of a (durations) pattern are built once and stay on the device: a host->device copy
         # inside the step is a stream synchronisation point
         owner, vid_of_clip, vid_of_frame, query_mask, clip_vid_list = self._indices(durations, n_clips, dev)
@@ -403,35 +416,44 @@ class Transformer(nn.Module):
 
         S = hw + L
         x = torch.cat([src_bm.to(dt), text_clip], dim=1)  # [n, S, d]
-        pos_full = torch.cat([pos_bm.to(dt), torch.zeros(n, L, d, dtype=dt, device=dev)], dim=1)
+        sine = pos_embed is None
+        if sine:
+            # PositionEmbeddingSine (position_encoding.py:71-94) straight from the pad mask, S rows per clip with the text
+            # tokens' zero rows already in place (transformer.py:323-326) - one kernel, no tensor to concatenate zeros to
+            assert self.sine_pos is not None and pos_mask is not None, "pos_embed=None needs the sine encoding's pad mask (pos_mask)"
+            pos_full = _ops.pos_sine(pos_mask, self.sine_pos[0], dt, self.sine_pos[1], rows=S)
+        else:  # a positional tensor handed in by the caller (learned encodings, the dense --stride 0 path, external callers)
+            pos_bm = pos_embed.permute(0, 2, 3, 1).reshape(n, hw, d)
+            pos_full = torch.cat([pos_bm.to(dt), torch.zeros(n, L, d, dtype=dt, device=dev)], dim=1)
         key_pad = torch.cat([mask.flatten(1), text_mask_clip], dim=1).to(torch.uint8)  # [n, S], 1 = ignore
         if self.fast and self.fast_mode == "noslow":  # no space-text attention for this baseline (transformer.py:330-340)
             mem = x
         else:
             mem = self.encoder(x.reshape(n * S, d), key_pad, pos_full.reshape(n * S, d), n, S).view(n, S, d)
 
+        variant = self.fast and self.fast_mode not in FAST_MODES_IN_HIP
+        if self.fast and fast_src is None:
+            raise AttributeError("fast=True needs temporal sampling (stride > 0): the reference builds no fast_src without it (models/tubedetr.py:140-153)")
         if self.stride:
-            # temporal replication (transformer.py:393-427): frame (i, j) <- clip i*n_clips + j//k
-            frames_mem = mem[owner]  # [b*t, S, d]
-            frames_pos = pos_full[owner]
+            # temporal replication (transformer.py:393-427): frame (i, j) <- clip i*n_clips + j//k, as index vectors
+            maps = self._replica_maps(durations, n_clips, owner, n, hw, L, dev)
             frame_mask = torch.cat([tpad_mask_t.flatten(1), text_attention_mask_orig[vid_of_frame]], dim=1)  # [b*t, S]
             frame_mask[:, 0] = False  # "avoid empty masks" (transformer.py:424)
+            if sine:  # the frames' positional rows come from the same kernel (a frame has its clip's pad mask), not from a gather of pos_full
+                frames_pos = _ops.pos_sine(pos_mask[owner], self.sine_pos[0], dt, self.sine_pos[1], rows=S)
+            else:
+                frames_pos = Fk.ReplicateRowsFn.apply(pos_full.reshape(n * S, d), maps).view(b * t, S, d)
+            mem2d = mem.reshape(n * S, d)
+            if self.fast and not variant:  # transformer.py:373-375,387,441-445: replication + aggregation in one GEMM
+                fs = fast_src.permute(0, 2, 3, 1).reshape(b * t * hw, d)
+                fast_mem = Fk.linear(fs.to(dt), self.fast_encoder.weight, self.fast_encoder.bias)
+                frames_mem = Fk.SlowFastAggregateFn.apply(mem2d, fast_mem, self.fast_residual.weight, self.fast_residual.bias, maps).view(b * t, S, d)
+            else:
+                frames_mem = Fk.ReplicateRowsFn.apply(mem2d, maps).view(b * t, S, d)
         else:
             frames_mem, frames_pos, frame_mask = mem, pos_full, key_pad.bool()
-        if self.fast and self.fast_mode not in FAST_MODES_IN_HIP:
-            if fast_src is None:
-                raise AttributeError("fast=True needs temporal sampling (stride > 0): the reference builds no fast_src without it (models/tubedetr.py:140-153)")
+        if variant:
             frames_mem = self._aggregate_variant(frames_mem, fast_src, tpad_mask_t, text_resized, vid_of_frame, b, t, hw, d)
-        elif self.fast:  # transformer.py:373-375,387,441-445
-            if fast_src is None:
-                raise AttributeError("fast=True needs temporal sampling (stride > 0): the reference builds no fast_src without it (models/tubedetr.py:140-153)")
-            fs = fast_src.permute(0, 2, 3, 1).reshape(b * t * hw, d)
-            fast_mem = Fk.linear(fs.to(dt), self.fast_encoder.weight, self.fast_encoder.bias).view(b * t, hw, d)
-            vis = frames_mem[:, :hw].reshape(b * t * hw, d)
-            mix = Fk.AddFn.apply(vis, fast_mem.reshape(b * t * hw, d))
-            agg = Fk.linear(mix, self.fast_residual.weight, self.fast_residual.bias)
-            vis = Fk.AddFn.apply(vis, agg).view(b * t, hw, d)
-            frames_mem = torch.cat([vis, frames_mem[:, hw:]], dim=1)
         return {
             "text_memory_resized": text_clip.transpose(0, 1),  # (L, n, d) seq-first views like the reference
             "text_memory": frames_mem[:, hw:].transpose(0, 1),
@@ -498,11 +520,10 @@ class Transformer(nn.Module):
         t, b, _ = query_embed.shape
         mem = img_memory.transpose(0, 1).reshape(bt * S, d)  # zero-copy for the cache produced by _encode
         pos = pos_embed.transpose(0, 1).reshape(bt * S, d)
-        mem = Fk.cast(mem, dt)
-        mem_k = Fk.AddFn.apply(mem, Fk.cast(pos, dt))  # keys = memory + pos, shared by the six layers
+        mem, pos = Fk.cast(mem, dt), Fk.cast(pos, dt)  # keys = memory + pos: pos is the key projection's second operand stream
         query_pos = Fk.cast(query_embed.transpose(0, 1).reshape(b * t, d).contiguous(), dt)
         tgt = torch.zeros_like(query_pos)
-        res = self.decoder(tgt, query_pos, mem_k, mem, query_mask, mask, b, t, S)
+        res = self.decoder(tgt, query_pos, mem, pos, query_mask, mask, b, t, S)
         if self.return_weights:
             hs, weights, cross_weights = res
         else:

@@ -77,6 +77,12 @@ class TubeDETR(nn.Module):
         if sted:
             self.sted_embed = MLP(hidden_dim, hidden_dim, 2, 2, dropout=0.5)
         self._idx_cache = LRUCache()
+        from .position_encoding import PositionEmbeddingSine
+
+        pe = backbone[1] if hasattr(backbone, "__getitem__") else None
+        self._sine_pos = isinstance(pe, PositionEmbeddingSine)
+        if self._sine_pos:
+            transformer.sine_pos = (pe.num_pos_feats, float(pe.temperature))
         # Opt-in (bench.py / callers whose data pipeline guarantees it, like datasets/vidstg.py:250-251 does): the slow
         # frames ARE the fast frames [::stride] of each video.  The trunk then runs once over the fast frames only
         # (slow ones first, so backward still walks a contiguous prefix) instead of recomputing the same pixels.
@@ -158,6 +164,8 @@ class TubeDETR(nn.Module):
         if not self.stride:
             return self._encode_dense(samples, durations, captions)
         b, t, k = len(durations), max(durations), self.stride
+        # sine encoding: the transformer forms the positional operand from the (original) pad mask itself, see Joiner.forward
+        want_pos = not self._sine_pos
         merged = self.fast and samples_fast is not None and torch.is_grad_enabled() and samples_fast.tensors.shape[1:] == samples.tensors.shape[1:]
         if merged and self.slow_frames_are_strided_fast and sum(durations) == samples_fast.tensors.shape[0]:
             # one trunk pass over the fast frames, permuted so that the slow (= every k-th) frames come first
@@ -166,9 +174,9 @@ class TubeDETR(nn.Module):
             assert perm.numel() == samples_fast.tensors.shape[0] and n_slow == sum(math.ceil(d / k) for d in durations)
             # (the permutation is an index list handed to the trunk's input kernel: the pixels are not copied)
             both = NestedTensor(FrameSources([(_one_tensor(samples_fast.tensors), perm)], _valid(samples_fast.tensors)), samples_fast.mask[perm])
-            features, pos_all = self.backbone(both, n_slow)
+            features, pos_all = self.backbone(both, n_slow, want_pos=want_pos)
             src_all, mask_all = features[-1].decompose()
-            src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow]]
+            src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow] if want_pos else None]
             src_fast_feat, mask_fast = src_all.detach()[inv], mask_all[inv]
         elif merged:
             # slow (grad) and fast (no_grad, tubedetr.py:128-129) frames share the trunk weights: one launch sequence over
@@ -176,12 +184,12 @@ class TubeDETR(nn.Module):
             n_slow = samples.tensors.shape[0]
             both = NestedTensor(FrameSources(_parts(samples.tensors) + _parts(samples_fast.tensors), _valid(samples.tensors) + _valid(samples_fast.tensors)),
                                 torch.cat([samples.mask, samples_fast.mask]))
-            features, pos_all = self.backbone(both, n_slow)
+            features, pos_all = self.backbone(both, n_slow, want_pos=want_pos)
             src_all, mask_all = features[-1].decompose()
-            src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow]]
+            src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow] if want_pos else None]
             src_fast_feat, mask_fast = src_all[n_slow:].detach(), mask_all[n_slow:]
         else:
-            features, pos = self.backbone(samples)
+            features, pos = self.backbone(samples, want_pos=want_pos)
             src, mask = features[-1].decompose()
         dev = src.device
         dest = self._frame_index(durations, dev)
@@ -213,7 +221,7 @@ class TubeDETR(nn.Module):
         tpad_mask[:, 0, 0] = False  # avoid empty masks
         tpad_mask_t[:, 0, 0] = False
         return self.transformer(src, tpad_mask, self.query_embed.weight, pos[-1], captions, encode_and_save=True,
-                                durations=durations, tpad_mask_t=tpad_mask_t, fast_src=fast_src)
+                                durations=durations, tpad_mask_t=tpad_mask_t, fast_src=fast_src, pos_mask=None if want_pos else mask)
 
     def _decode(self, memory_cache):
         res = self.transformer(img_memory=memory_cache["img_memory"], mask=memory_cache["mask"], pos_embed=memory_cache["pos_embed"],

@@ -243,13 +243,15 @@ def linear_wgrad_batch(jobs) -> None:
             linear_wgrad_batch(sub)
         return
     arr = (_hip.WgradJob * len(jobs))()
-    for a, (g, x, dw_ptr, db_ptr) in zip(arr, jobs):
+    for a, job in zip(arr, jobs):
+        g, x, dw_ptr, db_ptr = job[:4]
         M, K = x.shape
         Nn = g.shape[1]
         assert g.shape[0] == M and g.stride(1) == 1 and x.is_contiguous() and g.dtype == x.dtype  # g: rows of stride ldg (a column block is fine)
         a.g, a.src, a.dW, a.scale, a.dbias = g.data_ptr(), x.data_ptr(), dw_ptr, None, db_ptr
         a.d = _desc(1, M, 1, K, M, 1, 1, 1, 1, 0, 0, Nn, Nn)
         a.ldg, a.ci_real = g.stride(0), K
+        a.accumulate = int(len(job) > 4 and bool(job[4]))  # second operand stream of a two-source layer: dW += g^T x, behind the overwriting jobs
     nbytes = _hip.lib().td_conv_wgrad_batch_table_bytes(len(jobs))
     dev = jobs[0][0].device
     th, td_, done = job_tables.take(nbytes, dev)
@@ -267,6 +269,64 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, residual=
     y = out if out is not None else torch.empty((M, Nn), dtype=x.dtype, device=x.device)
     conv_gemm_raw(x, w, y, _desc(1, M, 1, K, M, 1, 1, 1, 1, 0, 0, Nn, Nn), _epi(bias, residual, mask_src, relu, sigmoid, dropout_p, seed, alpha))
     return y
+
+
+def _rows2d(t: Tensor):
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D operand expected (unit column stride)"
+    return t
+
+
+def linear_ex(a1: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, a2: Optional[Tensor] = None, a1_map: Optional[Tensor] = None,
+              a2_map: Optional[Tensor] = None, w_shared: bool = False, out: Optional[Tensor] = None, out_map: Optional[Tensor] = None,
+              out_rows: Optional[int] = None, residual: Optional[Tensor] = None, res_map: Optional[Tensor] = None, relu=False, mask_src=None,
+              dropout_p=0.0, seed=0, alpha=1.0) -> Tensor:
+    """td_linear_ex: out[out_map[m]] = epilogue([a1[a1_map[m]] | a2[a2_map[m]]] @ w^T + bias + residual[res_map[m]]).  a1 / a2 / out /
+    residual are row-major 2-D (row stride = stride(0)); maps are int32 device vectors of length M (None = identity);
+    w_shared: w is [N, K1] and multiplies both sources (= (a1 + a2) @ w^T)."""
+    _rows2d(a1)
+    K1 = a1.shape[1]
+    K2 = _rows2d(a2).shape[1] if a2 is not None else 0
+    M = int(a1_map.numel()) if a1_map is not None else a1.shape[0]
+    Nn = w.shape[0]
+    assert w.is_contiguous() and w.dtype == a1.dtype and w.shape[1] == (K1 if (w_shared or a2 is None) else K1 + K2)
+    for m_ in (a1_map, a2_map, out_map, res_map):
+        assert m_ is None or (m_.dtype == torch.int32 and m_.is_contiguous() and m_.numel() == M)
+    if out is None:
+        out = torch.empty((out_rows if out_rows is not None else M, Nn), dtype=a1.dtype, device=a1.device)
+    _rows2d(out)
+    x = _hip.LinearExDesc()
+    x.M, x.N, x.K1, x.K2 = M, Nn, K1, K2
+    x.lda1, x.lda2, x.ldc = a1.stride(0), (a2.stride(0) if a2 is not None else 0), out.stride(0)
+    x.ldr = _rows2d(residual).stride(0) if residual is not None else 0
+    x.w_shared = int(bool(w_shared and a2 is not None))
+    x.rows1, x.rows2 = a1.shape[0], (a2.shape[0] if a2 is not None else 0)
+    x.a1_map, x.a2_map, x.out_map, x.res_map = ptr(a1_map), ptr(a2_map), ptr(out_map), ptr(res_map)
+    epi = _epi(bias, residual, mask_src, relu, False, dropout_p, seed, alpha)
+    check(_hip.lib().td_linear_ex(ptr(a1), ptr(a2), ptr(w), ptr(out), C.byref(x), C.byref(epi), dtype_code(a1.dtype), stream_ptr()), "td_linear_ex")
+    return out
+
+
+def rows_copy(src: Tensor, src_map: Optional[Tensor], dst: Tensor, dst_map: Optional[Tensor], n_rows: int, add: Optional[Tensor] = None) -> Tensor:
+    """dst[dst_map[i]] = src[src_map[i]] (+ add[i]) for i < n_rows; all row-major 2-D with the same column count."""
+    _rows2d(src), _rows2d(dst)
+    cols = src.shape[1]
+    assert dst.shape[1] == cols and dst.dtype == src.dtype and (add is None or (_rows2d(add).shape[1] == cols and add.dtype == src.dtype and add.shape[0] >= n_rows))
+    for m_ in (src_map, dst_map):
+        assert m_ is None or (m_.dtype == torch.int32 and m_.is_contiguous() and m_.numel() == n_rows)
+    check(_hip.lib().td_rows_copy(ptr(src), ptr(src_map), ptr(add), ptr(dst), ptr(dst_map), n_rows, cols, src.stride(0), add.stride(0) if add is not None else 0,
+                                  dst.stride(0), dtype_code(src.dtype), stream_ptr()), "td_rows_copy")
+    return dst
+
+
+def rows_segment_sum(inp: Tensor, idx: Tensor, seg_ptr: Tensor, out: Tensor, out_map: Optional[Tensor] = None) -> Tensor:
+    """out[out_map[r]] = sum of inp[idx[j]] over j in [seg_ptr[r], seg_ptr[r+1]) (fp32 accumulation)."""
+    _rows2d(inp), _rows2d(out)
+    n_out = seg_ptr.numel() - 1
+    assert idx.dtype == torch.int32 and seg_ptr.dtype == torch.int32 and out.dtype == inp.dtype and out.shape[1] == inp.shape[1]
+    assert out_map is None or (out_map.dtype == torch.int32 and out_map.numel() == n_out)
+    check(_hip.lib().td_rows_segment_sum(ptr(inp), ptr(idx), ptr(seg_ptr), ptr(out), ptr(out_map), n_out, inp.shape[1], inp.stride(0), out.stride(0),
+                                         dtype_code(inp.dtype), stream_ptr()), "td_rows_segment_sum")
+    return out
 
 
 def pw_chain(x: Tensor, w1: Tensor, b1: Tensor, residual: Tensor, w2: Tensor, b2: Tensor):
@@ -392,12 +452,14 @@ def relu_bwd(dy: Tensor, y: Tensor, scale: float = 1.0) -> Tensor:
     return g
 
 
-def pos_sine(mask: Tensor, npf: int, dtype: torch.dtype, temperature: float = 10000.0) -> Tensor:
-    """mask (N,h,w) bool/uint8 -> pos [N, h*w, 2*npf]."""
+def pos_sine(mask: Tensor, npf: int, dtype: torch.dtype, temperature: float = 10000.0, rows: Optional[int] = None) -> Tensor:
+    """mask (N,h,w) bool/uint8 -> pos [N, rows, 2*npf]; rows >= h*w (default h*w), the rows behind the h*w tokens are zeros (the
+    positional operand of the text tokens that follow the visual ones in the encoder's sequence)."""
     N, h, w = mask.shape
     m8 = mask.to(torch.uint8).contiguous()
-    pos = torch.empty((N, h * w, 2 * npf), dtype=dtype, device=mask.device)
-    check(_hip.lib().td_pos_sine(ptr(m8), ptr(pos), N, h, w, npf, temperature, dtype_code(dtype), stream_ptr()), "td_pos_sine")
+    rows = h * w if rows is None else int(rows)
+    pos = torch.empty((N, rows, 2 * npf), dtype=dtype, device=mask.device)
+    check(_hip.lib().td_pos_sine(ptr(m8), ptr(pos), N, h, w, npf, temperature, rows, dtype_code(dtype), stream_ptr()), "td_pos_sine")
     return pos
 
 
