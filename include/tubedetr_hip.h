@@ -206,6 +206,13 @@ int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const float* mean, co
  * half the input bytes.  w_fwd[0] must then be the [64][7][4][8] weight td_stem_pair_weights derives from the prepared
  * [64][7][7][8] one. */
 int td_stem_pair_weights(const void* w_fwd_8, void* w_pairs, int Co, int dtype, td_stream_t stream);
+/* The whole frozen stem in one pass (torchvision resnet conv1 + bn1 + relu + maxpool, reached through models/backbone.py:94-98):
+ * pooled[N][PH][PW][64] = maxpool3x3s2p1( relu( conv7x7s2p3(x) + bias ) ), x_pairs = the frames as 4-channel pixels (two per 16-byte
+ * element: [N][H][W/2][8], what td_frames_to_nhwc writes with Cpad = 4), w_pairs = td_stem_pair_weights' [64][7][4][8], bf16.  The
+ * 64-channel convolution output stays in LDS (it is 4 GB per 1 000 frames of res 352 otherwise, written once and read 1.5 times).
+ * td_resnet_fwd uses it when stem_pairs = 1; exported for the parity test. */
+int td_stem_pool(const void* x_pairs, const void* w_pairs, const float* bias, void* pooled, int N, int H, int W, int dtype,
+                 td_stream_t stream);
 /* Backward through the stages >= first_train_stage (0..3; the reference trains layer2-4 = 1, backbone.py:82-89):
  * dfeat = gradient of *feat; fwd_ws = the save=1 workspace of the forward; dW[i] receives the gradient of conv i in
  * the parameter's own [Co][Ci][R][S] fp32 layout (FrozenBN scale un-folded); entries of frozen convs are ignored.

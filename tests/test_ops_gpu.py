@@ -190,6 +190,38 @@ def test_stem_pixel_pair_form_equals_the_7x7_convolution():
     assert rel_err(y, y8) < 4e-3  # same products, different summation order
 
 
+@pytest.mark.parametrize("size", [(3, 46, 60), (2, 352, 352), (5, 64, 96), (1, 30, 34), (2, 224, 224)])
+def test_fused_stem_equals_conv_relu_maxpool(size):
+    """td_stem_pool (conv7x7s2 + bias + ReLU + maxpool3x3s2 in one pass, the 64-channel map kept in LDS) against
+    F.max_pool2d(F.relu(F.conv2d(...))) in fp32, and bit-for-bit against the two-launch pipeline it replaces (pixel-pair
+    convolution written as bf16, then td_maxpool3x3s2): image borders, pooled sizes that do not fill the tiles, both tile widths."""
+    from tubedetr_amd import _hip, ops
+
+    dt = torch.bfloat16
+    N, H, W = size
+    Co = 64
+    g = torch.Generator().manual_seed(H + W)
+    x = rnd((N, 3, H, W), g, dt)
+    w = rnd((Co, 3, 7, 7), g, dt, 0.1)
+    bias = torch.randn(Co, generator=g)
+    ref = F.max_pool2d(F.relu(F.conv2d(x, w, bias, stride=2, padding=3)), 3, 2, 1)
+    PH, PW = ref.shape[2], ref.shape[3]
+    wf8, _, b_out, _ = ops.weight_prep(w.to(dev()), dt, bias=bias.to(dev()), need_dgrad=False, cpad=8)
+    wp = torch.empty((Co, 7 * 4 * 8), dtype=dt, device=dev())
+    _hip.check(_hip.lib().td_stem_pair_weights(wf8.data_ptr(), wp.data_ptr(), Co, _hip.TD_BF16, _hip.stream_ptr()), "td_stem_pair_weights")
+    x4 = ops.nchw_to_nhwc(x.to(dev()), dt, 4)  # [N, H, W, 4] == [N, H, W/2, 8]
+    y = torch.full((N, PH, PW, Co), float("nan"), dtype=dt, device=dev())
+    _hip.check(_hip.lib().td_stem_pool(x4.data_ptr(), wp.data_ptr(), b_out.data_ptr(), y.data_ptr(), N, H, W, _hip.TD_BF16, _hip.stream_ptr()), "td_stem_pool")
+    assert rel_err(from_nhwc(y), ref) < TOL[dt]
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    c = torch.empty((N, Ho, Wo, Co), dtype=dt, device=dev())
+    ops.conv_gemm_raw(x4.view(N, H, W // 2, 8), wp, c, ops._desc(N, H, W // 2, 8, Ho, Wo, 7, 4, 2, 3, 0, Co, Co, stride_w=1, pad_w=2), ops._epi(b_out, None, None, True))
+    two = ops.maxpool3x3s2(c)
+    # same bf16 products; the fp32 sums of the two kernels run in different orders, so a conv output may round to the neighbouring bf16
+    assert rel_err(y, two) < 8e-3
+    assert (y.float() - two.float()).abs().gt(0).float().mean().item() < 0.05
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_frozen_bn_fold_and_mask_epilogues(dt):
     from tubedetr_amd import ops

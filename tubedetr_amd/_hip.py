@@ -79,6 +79,7 @@ _SIGS = {
     "td_resnet_fwd": [C.POINTER(FrameSource), _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ,
                       C.POINTER(_P), C.POINTER(C.c_int), _I, _I, _P],
     "td_stem_pair_weights": [_P, _P, _I, _I, _P],
+    "td_stem_pool": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "td_pw_chain": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "td_frames_to_nhwc": [C.POINTER(FrameSource), _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P],
     "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _P, _P, _SZ, _I, _P],

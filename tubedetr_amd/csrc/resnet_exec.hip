@@ -149,25 +149,36 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   TD_REQUIRE(ws_bytes >= P.total, "td_resnet_fwd: workspace too small (%zu < %zu)", ws_bytes, P.total);
   char* base = (char*)ws;
   int rc;
+  bool stem_done = false;  // the fused stem wrote the pooled tensor already
   if (stem_pairs) {
     // pixel-pair stem (see tubedetr_hip.h): 4-channel pixels in the first half of x's region = [H][W/2] elements of 8 channels
     TD_REQUIRE(dtype == TD_BF16 && (W & 1) == 0, "td_resnet_fwd: the pixel-pair stem needs bf16 and an even frame width");
     rc = td_frames_to_nhwc(srcs, n_srcs, 3, H, W, 4, mean, inv_std, base + P.x.off, dtype, stream);
     if (rc) return rc;
-    td_conv_desc d = {N, H, W / 2, 8, P.stem.H, P.stem.W, 7, 4, 2, 3, 0, 64, 64, 1, 0, 0, 1, 1, 2};
-    td_epilogue e;
-    memset(&e, 0, sizeof(e));
-    e.bias = bias[0];
-    e.relu = 1;
-    rc = td_conv_gemm(base + P.x.off, w_fwd[0], base + P.stem.off, &d, &e, dtype, stream);
+    // conv + bias + ReLU + max-pool in one pass (stem.hip): the 64-channel stem output never exists in HBM.  TD_STEM_FUSED=0:
+    // the pixel-pair convolution and the pooling kernel as two launches (A/B).
+    static const int fused = [] { const char* e_ = getenv("TD_STEM_FUSED"); return e_ ? atoi(e_) : 1; }();
+    if (fused) {
+      rc = td_stem_pool(base + P.x.off, w_fwd[0], bias[0], base + P.pool.off, N, H, W, dtype, stream);
+      stem_done = true;
+    } else {
+      td_conv_desc d = {N, H, W / 2, 8, P.stem.H, P.stem.W, 7, 4, 2, 3, 0, 64, 64, 1, 0, 0, 1, 1, 2};
+      td_epilogue e;
+      memset(&e, 0, sizeof(e));
+      e.bias = bias[0];
+      e.relu = 1;
+      rc = td_conv_gemm(base + P.x.off, w_fwd[0], base + P.stem.off, &d, &e, dtype, stream);
+    }
   } else {
     rc = td_frames_to_nhwc(srcs, n_srcs, 3, H, W, P.x.C, mean, inv_std, base + P.x.off, dtype, stream);
     if (rc) return rc;
     rc = run_conv(base, P.x, P.stem, N, P.convs[0], w_fwd[0], bias[0], nullptr, 1, dtype, stream);
   }
   if (rc) return rc;
-  rc = td_maxpool3x3s2(base + P.stem.off, base + P.pool.off, N, P.stem.H, P.stem.W, 64, dtype, stream);
-  if (rc) return rc;
+  if (!stem_done) {
+    rc = td_maxpool3x3s2(base + P.stem.off, base + P.pool.off, N, P.stem.H, P.stem.W, 64, dtype, stream);
+    if (rc) return rc;
+  }
   // conv3 of a layer1 block + conv1 of the block behind it as ONE launch (td_pw_chain): 64 -> 256 -> 64 (| 128 into layer2)
   static const int chain_on = [] { const char* e = getenv("TD_PW_CHAIN"); return e ? atoi(e) : 3; }();  // bit 0: inside layer1, bit 1: into layer2
   bool conv1_done = false;  // this block's conv1 was produced by the previous block's chained launch

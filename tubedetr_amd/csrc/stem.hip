@@ -1,0 +1,186 @@
+// ResNet stem in ONE pass: 7x7 stride-2 convolution (pixel-pair form, FrozenBN folded) + bias + ReLU + 3x3 stride-2 max-pool.
+// Replaces conv1 / bn1 / relu / maxpool of the torchvision trunk reached through models/backbone.py:94-98 for the frozen
+// stem (no gradient ever flows here, backbone.py:82-89), on every frame of the step (1 000 per 8-clip step at res 352).
+//
+// Why its own kernel: as an implicit GEMM the stem is M = N*176*176 rows x 64 channels x K = 224 - 242 000 workgroups of a
+// 3.5-tile K loop each (prologue / epilogue bound: 0.15 of the MFMA roof and 0.14 of the HBM roof measured), its 64-channel
+// 176 x 176 output (4 GB per 1 000 frames) is written, re-read 1.5x by the pooling kernel and never used again.  Here a
+// workgroup owns a tile of POOLED pixels: it stages the input patch once in LDS (the 28 taps of an output pixel are
+// re-read from there, not through 28 gathers), keeps the whole 64 x 224 weight matrix as MFMA fragments in registers for
+// the launch (persistent workgroups), leaves the convolution outputs of its tile (+ the one-pixel pooling halo) in LDS as
+// bf16 and pools from there: HBM sees the 4-channel frames once and the pooled tensor once.
+//
+// Pixel-pair form (td_stem_pair_weights): frames are stored with 4 channels per pixel, two horizontally adjacent pixels form
+// one 16-byte element; out(cy, cx) = sum_{r<7, t<4} W[r][t][8] . X[2cy + r - 3][cx + t - 2][8].  One k-step of the MFMA
+// (v_mfma_f32_16x16x32_bf16: 32 k = 4 elements) is exactly one filter row r; lane group lg supplies tap t = lg.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "td_common.h"
+
+namespace td {
+
+struct StemParams {
+  const char* x;      // [N][H][W/2] elements of 8 bf16
+  const char* w;      // [64][7][4][8] bf16
+  const float* bias;  // [64]
+  char* y;            // pooled [N][PH][PW][64] bf16
+  int N, H, WP;       // WP = W / 2 (pairs per row)
+  int CH, CW;         // convolution output size
+  int PH, PW;         // pooled size
+  int tiles_y, tiles_x, n_tiles;
+};
+
+// pooled tile TY x TX -> convolution region (2TY+1) x (2TX+1) (one halo row / column towards -1) -> input patch
+// (2(2TY+1)+5) rows x ((2TX+1)+3) pairs
+template <int TY, int TX>
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
+  constexpr int CR = 2 * TY + 1, CC = 2 * TX + 1;      // convolution rows / columns of a tile
+  constexpr int MROWS = CR * CC, MB = (MROWS + 15) / 16;  // GEMM rows of a tile, 16-row blocks
+  constexpr int PR = 2 * CR + 5, PC = CC + 3;          // input patch: rows x pairs
+  constexpr int CPITCH = 144;                           // bytes per convolution-output row in LDS (64 bf16 + pad: 16-byte aligned, row r at bank 4r)
+  __shared__ __attribute__((aligned(16))) char patch[PR * PC * 16];
+  __shared__ __attribute__((aligned(16))) char ctile[MB * 16 * CPITCH];
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int lr = lane & 15, lg = lane >> 4;
+  // the weight matrix as MFMA A-operand fragments, resident for the whole launch: wreg[r][i] = rows (channels) i*16 + lr,
+  // k = r*32 + lg*8 .. +8  (= filter row r, tap lg)
+  uint4 wreg[7][4];
+#pragma unroll
+  for (int r = 0; r < 7; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wreg[r][i] = *(const uint4*)(p.w + ((size_t)(i * 16 + lr) * 224 + r * 32 + lg * 8) * 2);
+  float bias4[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias4[i][q] = p.bias[i * 16 + 4 * lg + q];
+
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const int img = tile / (p.tiles_y * p.tiles_x);
+    const int trem = tile - img * (p.tiles_y * p.tiles_x);
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int py0 = ty * TY, px0 = tx * TX;
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;    // first convolution row / column of the tile (may be -1: pooling pad)
+    const int iy0 = 2 * cy0 - 3, ix0 = cx0 - 2;         // first input row / pair of the patch
+    // (1) input patch -> LDS (zeros outside the frame)
+    const char* ximg = p.x + (size_t)img * p.H * p.WP * 16;
+    for (int e = t; e < PR * PC; e += 256) {
+      const int r = e / PC, c = e - r * PC;
+      const int iy = iy0 + r, ix = ix0 + c;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.WP) v = *(const uint4*)(ximg + ((size_t)iy * p.WP + ix) * 16);
+      *(uint4*)(patch + e * 16) = v;
+    }
+    __syncthreads();
+    // (2) convolution of the tile's rows, 16 at a time per wavefront; result (+ bias, ReLU; 0 outside the image = pooling pad,
+    //     valid because every window holds at least one real, non-negative value) -> LDS as bf16
+    for (int mb = wave; mb < MB; mb += 4) {
+      const int m = mb * 16 + lr;
+      const int mm = m < MROWS ? m : 0;
+      const int cyl = mm / CC, cxl = mm - cyl * CC;
+      const char* a0 = patch + ((2 * cyl) * PC + cxl + lg) * 16;  // tap (r = 0, t = lg) of this lane's output pixel
+      f32x4 acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      uint4 af[7];
+#pragma unroll
+      for (int r = 0; r < 7; ++r) af[r] = *(const uint4*)(a0 + r * (PC * 16));
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&wreg[r][i], *(const bf16x8*)&af[r], acc[i], 0, 0, 0);
+      // D[n = i*16 + 4*lg + q][m = lr]: this lane holds 4 consecutive channels of output pixel m
+      const int cy = cy0 + cyl, cx = cx0 + cxl;
+      const bool inside = m < MROWS && (unsigned)cy < (unsigned)p.CH && (unsigned)cx < (unsigned)p.CW;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = inside ? fmaxf(acc[i][q] + bias4[i][q], 0.f) : 0.f;
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *(uint2*)(ctile + m * CPITCH + (i * 16 + 4 * lg) * 2) = o;
+      }
+    }
+    __syncthreads();
+    // (3) 3x3 stride-2 max-pool from LDS: pooled (pyl, pxl) covers convolution rows 2pyl .. 2pyl+2, columns 2pxl .. 2pxl+2 of the tile
+    for (int e = t; e < TY * TX * 8; e += 256) {
+      const int c8 = e & 7, px_ = (e >> 3) % TX, py_ = (e >> 3) / TX;
+      const int py = py0 + py_, px = px0 + px_;
+      if (py >= p.PH || px >= p.PW) continue;
+      float mx[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mx[q] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const uint4 v = *(const uint4*)(ctile + ((2 * py_ + dy) * CC + 2 * px_ + dx) * CPITCH + c8 * 16);
+          const uint32_t* pv = (const uint32_t*)&v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            mx[2 * q] = fmaxf(mx[2 * q], __uint_as_float(pv[q] << 16));
+            mx[2 * q + 1] = fmaxf(mx[2 * q + 1], __uint_as_float(pv[q] & 0xffff0000u));
+          }
+        }
+      uint4 o;  // the maxima are bf16 values already: repacking is exact
+      o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
+      o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
+      o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
+      o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
+      *(uint4*)(p.y + (((size_t)img * p.PH + py) * p.PW + px) * 128 + c8 * 16) = o;
+    }
+    __syncthreads();  // the next tile's patch / convolution rows overwrite what the pooling just read
+  }
+}
+
+}  // namespace td
+using namespace td;
+
+extern "C" int td_stem_pool(const void* x_pairs, const void* w_pairs, const float* bias, void* pooled, int N, int H, int W, int dtype,
+                            td_stream_t stream) {
+  TD_REQUIRE(x_pairs && w_pairs && bias && pooled, "td_stem_pool: null pointer");
+  TD_REQUIRE(dtype == TD_BF16, "td_stem_pool: the fused stem is a bf16 kernel (the exact-fp32 mode runs conv + pool separately)");
+  TD_REQUIRE(N >= 1 && H >= 2 && W >= 2 && (W & 1) == 0, "td_stem_pool: frames must have an even width (pixel pairs)");
+  StemParams p;
+  p.x = (const char*)x_pairs;
+  p.w = (const char*)w_pairs;
+  p.bias = bias;
+  p.y = (char*)pooled;
+  p.N = N;
+  p.H = H;
+  p.WP = W / 2;
+  p.CH = (H + 6 - 7) / 2 + 1;
+  p.CW = (W + 6 - 7) / 2 + 1;
+  p.PH = (p.CH + 2 - 3) / 2 + 1;
+  p.PW = (p.CW + 2 - 3) / 2 + 1;
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+  }();
+  hipStream_t st = (hipStream_t)stream;
+  const bool prof = prof_on();
+  if (prof) {
+    prof_begin(TD_PROF_GEMM_128x64, dtype, 2.0 * N * p.CH * p.CW * 64.0 * 224.0, st, N * p.CH * p.CW, 64, 224, 7, 2, 0);
+    prof_set_bytes(((double)N * H * W * 4 + (double)N * p.PH * p.PW * 64 + 64.0 * 224) * 2.0);
+  }
+  // 22-wide tiles when they divide the pooled width (res 352 -> 88 = 4 x 22: no half-empty tile column), else 16-wide
+  const bool wide = p.PW % 22 == 0;
+  const int TX = wide ? 22 : 16, TY = 4;
+  p.tiles_y = cdiv(p.PH, TY);
+  p.tiles_x = cdiv(p.PW, TX);
+  const long long nt = (long long)N * p.tiles_y * p.tiles_x;
+  TD_REQUIRE(nt < 2000000000LL, "td_stem_pool: too many tiles");
+  p.n_tiles = (int)nt;
+  const int grid = (int)std::min<long long>(nt, 2LL * n_cu);
+  if (wide) stem_pool_kernel<4, 22><<<grid, 256, 0, st>>>(p);
+  else stem_pool_kernel<4, 16><<<grid, 256, 0, st>>>(p);
+  if (prof) prof_end(st);
+  return check_launch("td_stem_pool");
+}

@@ -558,11 +558,16 @@ class CrossKVFn(Function):
             if l not in sh.written:
                 sh.dK[:, l * sh.E : (l + 1) * sh.E].zero_()
                 sh.dV[:, l * sh.E : (l + 1) * sh.E].zero_()
-        d_mem = None
-        if ctx.needs_input_grad[0]:
-            d_mem = ops.linear_fwd(sh.dK, sh.wk_d)
-            d_mem = ops.linear_fwd(sh.dV, sh.wv_d, residual=d_mem, out=d_mem)  # (+=: every element is read and written by the same lane)
-        return (d_mem, None, None) + (None,) * (2 * sh.n_layers)
+        d_mem = d_pos = None
+        need_pos = sh.pos is not None and ctx.needs_input_grad[1]  # learned position embeddings (the sine ones carry no gradient)
+        if ctx.needs_input_grad[0] or need_pos:
+            d_k = ops.linear_fwd(sh.dK, sh.wk_d)  # gradient of (mem + pos) through the key projections
+            if need_pos:
+                d_pos = d_k
+            if ctx.needs_input_grad[0]:
+                # += the value path, in the GEMM's epilogue (in place unless d_k is also the positional gradient)
+                d_mem = ops.linear_fwd(sh.dV, sh.wv_d, residual=d_k, out=None if need_pos else d_k)
+        return (d_mem, d_pos, None) + (None,) * (2 * sh.n_layers)
 
 
 class MHAPreKVFn(Function):
