@@ -199,7 +199,16 @@ size_t td_resnet_fwd_ws_bytes(int N, int H, int W, const int* nblocks, int dtype
 int td_resnet_num_convs(const int* nblocks);
 int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const float* mean, const float* inv_std, int N, int H, int W,
                   const int* nblocks, const void* const* w_fwd, const float* const* bias, int save, void* ws, size_t ws_bytes,
-                  void** feat, int* feat_hw, int stem_pairs, int dtype, td_stream_t stream);
+                  void** feat, int* feat_hw, int stem_pairs, int first_train_stage, int dtype, td_stream_t stream);
+/* first_train_stage (0..4, as for td_resnet_bwd): the stages below it are frozen - td_resnet_bwd never reads their inner
+ * activations, so with save = 1 they may still run fused (td_bottleneck_fused); with save = 0 everything may. */
+/* One whole frozen 64-plane bottleneck (layer1 of the torchvision trunk, models/backbone.py:82-98) in one pass:
+ * out[N][H][W][256] = relu(conv3(relu(conv2_3x3(relu(conv1(x))))) + identity), identity = x (Cin = 256, wd = NULL) or the
+ * block's downsample 1x1 (Cin = 64, wd / bd given); prepared (FrozenBN-folded, K-contiguous) bf16 weights: w1 [64][Cin],
+ * w2 [64][3*3*64], w3 [256][64], wd [256][64].  The 64-channel tensors between the three convolutions stay in LDS.
+ * Used by td_resnet_fwd; exported for the parity test. */
+int td_bottleneck_fused(const void* x, void* out, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                        const float* b3, const void* wd, const float* bd, int N, int H, int W, int Cin, int dtype, td_stream_t stream);
 /* stem_pairs = 1 (bf16, even W): the stem runs in its pixel-pair form - the frames are laid down with 4 channels per
  * pixel (3 + one zero), two horizontally adjacent pixels form one 8-channel element, and the 7x7 stride-2 convolution
  * becomes a 7x4 convolution with stride (2, 1) and padding (3, 2) over them: K = 224 instead of 392 (3 channels padded to 8),

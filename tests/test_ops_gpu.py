@@ -222,6 +222,44 @@ def test_fused_stem_equals_conv_relu_maxpool(size):
     assert (y.float() - two.float()).abs().gt(0).float().mean().item() < 0.05
 
 
+@pytest.mark.parametrize("cfg", [(2, 24, 32, 256), (3, 19, 27, 256), (2, 24, 32, 64), (1, 9, 50, 64), (2, 88, 88, 256), (1, 5, 3, 64)])
+def test_fused_frozen_bottleneck_equals_the_three_convolutions(cfg):
+    """td_bottleneck_fused (a whole frozen layer1 block in one launch: conv1 -> conv2 3x3 -> conv3 (+ downsample) + identity + ReLU,
+    the 64-channel tensors kept in LDS) against the block in fp32 torch on the same bf16 weights, and against the layer-by-layer
+    kernels it replaces: tiles cut by the image border, maps smaller than a tile, both block types."""
+    from tubedetr_amd import _hip, ops
+
+    dt = torch.bfloat16
+    N, H, W, Cin = cfg
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = rnd((N, Cin, H, W), g, dt).relu()
+    w1 = rnd((64, Cin, 1, 1), g, dt, 1.0 / math.sqrt(Cin))
+    w2 = rnd((64, 64, 3, 3), g, dt, 1.0 / math.sqrt(576))
+    w3 = rnd((256, 64, 1, 1), g, dt, 1.0 / 8)
+    wd = rnd((256, Cin, 1, 1), g, dt, 1.0 / 8) if Cin == 64 else None
+    b1, b2, b3, bd = (torch.randn(n_, generator=g) * 0.3 for n_ in (64, 64, 256, 256))
+    h = F.relu(F.conv2d(x, w1, b1)).to(dt).float()          # the fused kernel keeps the inner tensors as bf16, like the separate launches do
+    h = F.relu(F.conv2d(h, w2, b2, padding=1)).to(dt).float()
+    idt = x if wd is None else F.conv2d(x, wd, bd)
+    ref = F.relu(F.conv2d(h, w3, b3) + idt)
+    d = dev()
+    prep = lambda w_, b_: ops.weight_prep(w_.to(d), dt, bias=b_.to(d), need_dgrad=False)
+    (w1f, _, b1f, _), (w2f, _, b2f, _), (w3f, _, b3f, _) = prep(w1, b1), prep(w2, b2), prep(w3, b3)
+    wdf, bdf = (None, None) if wd is None else prep(wd, bd)[0::2]
+    xd = nhwc(x, dt)
+    out = torch.full((N, H, W, 256), float("nan"), dtype=dt, device=d)
+    _hip.check(_hip.lib().td_bottleneck_fused(xd.data_ptr(), out.data_ptr(), w1f.data_ptr(), b1f.data_ptr(), w2f.data_ptr(), b2f.data_ptr(), w3f.data_ptr(),
+                                              b3f.data_ptr(), _hip.ptr(wdf), _hip.ptr(bdf), N, H, W, Cin, _hip.TD_BF16, _hip.stream_ptr()), "td_bottleneck_fused")
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(from_nhwc(out), ref) < TOL[dt], cfg
+    # the launches it replaces
+    h1 = ops.conv_fwd(xd, w1f, b1f, 1, 1, 1, 0, relu=True)
+    h2 = ops.conv_fwd(h1, w2f, b2f, 3, 3, 1, 1, relu=True)
+    idn = xd if wd is None else ops.conv_fwd(xd, wdf, bdf, 1, 1, 1, 0)
+    sep = ops.conv_fwd(h2, w3f, b3f, 1, 1, 1, 0, residual=idn, relu=True)
+    assert rel_err(out, sep) < 8e-3, cfg
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_frozen_bn_fold_and_mask_epilogues(dt):
     from tubedetr_amd import ops

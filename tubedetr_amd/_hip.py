@@ -77,7 +77,8 @@ _SIGS = {
     "td_conv_wgrad_batch": [C.POINTER(WgradJob), _I, _I, _P, _P, _SZ, _P],
     "td_resnet_num_convs": [C.POINTER(C.c_int)],
     "td_resnet_fwd": [C.POINTER(FrameSource), _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _I, C.POINTER(C.c_int), C.POINTER(_P), C.POINTER(_P), _I, _P, _SZ,
-                      C.POINTER(_P), C.POINTER(C.c_int), _I, _I, _P],
+                      C.POINTER(_P), C.POINTER(C.c_int), _I, _I, _I, _P],
+    "td_bottleneck_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "td_stem_pair_weights": [_P, _P, _I, _I, _P],
     "td_stem_pool": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "td_pw_chain": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

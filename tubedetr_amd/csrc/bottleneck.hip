@@ -1,0 +1,313 @@
+// A whole FROZEN bottleneck of layer1 in one pass:
+//     out = relu( conv3( relu( conv2_3x3( relu( conv1(x) ) ) ) ) + identity ),   identity = x  or  downsample_1x1(x)
+// (torchvision Bottleneck.forward with FrozenBatchNorm folded into weights / biases, reached through models/backbone.py:94-98;
+// layer1 and the stem never train, backbone.py:82-89: no gradient passes through and none of the block's inner tensors is ever
+// needed again - for the slow frames no more than for the no-grad fast frames.)
+//
+// Why: at res 352 the three layer1 blocks run on 88 x 88 maps of 256 channels - 4 GB per 1 000 frames and tensor.  Launched
+// layer by layer a block moves ~13 GB through HBM (the 64-channel inner tensors written and read back, the 256-channel input
+// read by conv1 AND as the residual) for 1.1 TFLOP: every launch is HBM-bound, 3.8 ms per block.  Fused, HBM sees the block's
+// input once and its output once (7.9 GB): the 64-channel tensors live in LDS, the residual is the input tile itself.
+//
+// One workgroup (4 wavefronts, two workgroups per CU) owns an 8 x 16 tile of output pixels:
+//   phase 1  conv1 (1x1, CIN -> 64) on the tile + its one-pixel halo (10 x 18 = 180 pixels), the input streamed through LDS in
+//            64-channel chunks (double buffer, the next chunk requested into registers before the current one is multiplied);
+//            result (bias, ReLU, ZERO outside the image = conv2's padding) -> LDS as bf16
+//   phase 2  conv2 (3x3, 64 -> 64) on the 128 centre pixels, its 9 taps read from the LDS halo tile by address arithmetic -> LDS
+//   phase 3  conv3 (1x1, 64 -> 256) (+ the downsample 1x1 of block 0 as two more k-steps over the input tile still in LDS),
+//            + bias + identity + ReLU -> HBM
+// The output channels are split over the wavefronts (16 / 16 / 64 per wavefront in the three phases): a wavefront's weight
+// fragments are 8 - 18 registers' worth per phase, loaded from L2 at the phase head; every activation fragment is read from
+// LDS by all four wavefronts (4x LDS traffic - the block stays HBM-bound: ~14 000 cycles of HBM time per tile and CU against
+// ~5 000 cycles of MFMA issue and ~4 000 LDS cycles).
+// LDS rows are 128 bytes (64 bf16), 16-byte chunks XOR-swizzled by (row & 7) like everywhere in this library.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "td_common.h"
+
+namespace td {
+
+typedef __bf16 bn_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bn_cvt_pk(float lo, float hi) {
+  bn_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return *(uint32_t*)&v;
+}
+#define TD_BN_BARRIER()                                  \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                        \
+  } while (0)
+
+struct BneckParams {
+  const char* x;   // [N][H][W][CIN] bf16
+  char* out;       // [N][H][W][256] bf16
+  const char* w1;  // [64][CIN]
+  const char* w2;  // [64][3][3][64]  (K = (r*3 + s)*64 + c)
+  const char* w3;  // [256][64]
+  const char* wd;  // [256][CIN] (block 0: CIN = 64) or null
+  const float *b1, *b2, *b3, *bd;
+  int N, H, W;
+  int tiles_y, tiles_x, n_tiles;
+};
+
+template <int CIN, bool DS>
+__global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p) {
+  static_assert(CIN == 64 || CIN == 256, "layer1 blocks");
+  static_assert(!DS || CIN == 64, "the downsample branch belongs to block 0 (64 input channels)");
+  constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2;
+  constexpr int NHALO = HH * HW, HROWS = 192, NCEN = TH * TW;  // 180 halo pixels (padded to 12 blocks of 16), 128 centre pixels
+  constexpr int NC = CIN / 64;                                 // 64-channel input chunks
+  constexpr int XBUFS = NC > 1 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char xbuf[XBUFS][HROWS * 128];
+  __shared__ __attribute__((aligned(16))) char h1[HROWS * 128];
+  __shared__ __attribute__((aligned(16))) char h2own[NC > 1 ? 16 : NCEN * 128];
+  char* h2 = NC > 1 ? xbuf[1] : h2own;  // CIN = 256: the second chunk buffer is dead after phase 1
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+
+  // ---- input chunk loader: 192 rows x 8 chunks of 16 bytes = 6 per thread ----
+  uint4 pre[6];
+  auto fetch_chunk = [&](int tile, int kc) {
+    const int img = tile / tiles_per_img;
+    const int trem = tile - img * tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int e = t + j * 256;
+      const int row = e >> 3, c = e & 7;
+      const int hy = row / HW, hx = row - hy * HW;
+      const int y = y0 + hy, x = x0 + hx;
+      pre[j] = make_uint4(0, 0, 0, 0);
+      if (tile < p.n_tiles && row < NHALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+        pre[j] = *(const uint4*)(p.x + ((((size_t)img * p.H + y) * p.W + x) * CIN + kc * 64 + c * 8) * 2);
+    }
+  };
+  auto store_chunk = [&](char* buf) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int e = t + j * 256;
+      const int row = e >> 3, c = e & 7;
+      *(uint4*)(buf + row * 128 + ((c ^ (row & 7)) << 4)) = pre[j];
+    }
+  };
+  auto frag = [&](const char* buf, int row, int c16) -> uint4 { return *(const uint4*)(buf + row * 128 + ((c16 ^ (row & 7)) << 4)); };
+
+  fetch_chunk(blockIdx.x, 0);
+  store_chunk(xbuf[0]);
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const int img = tile / tiles_per_img;
+    const int trem = tile - img * tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;  // first centre pixel
+    // ================= phase 1: conv1 on the halo tile, channels 16*wave .. +15 =================
+    {
+      uint4 w1r[NC][2];
+#pragma unroll
+      for (int kc = 0; kc < NC; ++kc)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w1r[kc][ks] = *(const uint4*)(p.w1 + ((size_t)(16 * wave + lr) * CIN + kc * 64 + ks * 32 + lg * 8) * 2);
+      f32x4 acc[12];
+#pragma unroll
+      for (int mb = 0; mb < 12; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      TD_BN_BARRIER();  // chunk 0 is complete in xbuf[0] (stored at the end of the previous tile / before the loop)
+#pragma unroll
+      for (int kc = 0; kc < NC; ++kc) {
+        if (kc + 1 < NC) fetch_chunk(tile, kc + 1);
+        const char* xb = xbuf[kc & (XBUFS - 1)];
+        // groups of 6 fragments, double-buffered: group g + 1 is requested before the MFMAs of group g, and the scheduler may not
+        // move anything across a group boundary (left alone it hoists every fragment read of the phase and spills)
+        uint4 fr[2][6];
+        auto load6 = [&](int g, uint4 (&dst)[6]) {  // g = ks * 2 + (which half of the 12 row blocks)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) dst[j] = frag(xb, ((g & 1) * 6 + j) * 16 + lr, (g >> 1) * 4 + lg);
+        };
+        load6(0, fr[0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (g + 1 < 4) load6(g + 1, fr[(g + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            acc[(g & 1) * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w1r[kc][g >> 1], *(const bf16x8*)&fr[g & 1][j], acc[(g & 1) * 6 + j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kc + 1 < NC) {
+          store_chunk(xbuf[(kc + 1) & (XBUFS - 1)]);  // that buffer was last read two chunks ago: every wavefront has passed a barrier since
+          TD_BN_BARRIER();
+        }
+      }
+      float b1v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b1v[q] = p.b1[16 * wave + 4 * lg + q];
+#pragma unroll
+      for (int mb = 0; mb < 12; ++mb) {
+        const int row = mb * 16 + lr;
+        const int hy = row / HW, hx = row - hy * HW;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool inside = row < NHALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;  // outside: conv2's zero padding
+        uint2 o;
+        o.x = inside ? bn_cvt_pk(fmaxf(acc[mb][0] + b1v[0], 0.f), fmaxf(acc[mb][1] + b1v[1], 0.f)) : 0u;
+        o.y = inside ? bn_cvt_pk(fmaxf(acc[mb][2] + b1v[2], 0.f), fmaxf(acc[mb][3] + b1v[3], 0.f)) : 0u;
+        *(uint2*)(h1 + row * 128 + (((2 * wave + (lg >> 1)) ^ (row & 7)) << 4) + (lg & 1) * 8) = o;
+      }
+    }
+    fetch_chunk(tile + gridDim.x, 0);  // next tile's first chunk: in flight during phases 2 and 3
+    TD_BN_BARRIER();                   // h1 complete
+    // ================= phase 2: conv2 3x3 on the centre pixels, channels 16*wave .. +15 =================
+    {
+      uint4 w2r[18];
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) w2r[ks] = *(const uint4*)(p.w2 + ((size_t)(16 * wave + lr) * 576 + ks * 32 + lg * 8) * 2);
+      f32x4 acc[TH];
+#pragma unroll
+      for (int mb = 0; mb < TH; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // 18 k-steps (tap, channel half) of 8 fragments each, double-buffered like phase 1
+      uint4 fr[2][TH];
+      auto load8 = [&](int ks, uint4 (&dst)[TH]) {
+        const int tap = ks >> 1, r = tap / 3, s = tap - 3 * r;
+#pragma unroll
+        for (int mb = 0; mb < TH; ++mb) dst[mb] = frag(h1, (mb + r) * HW + lr + s, (ks & 1) * 4 + lg);  // centre pixel (mb, lr) -> halo pixel (mb + r, lr + s)
+      };
+      load8(0, fr[0]);
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) {
+        if (ks + 1 < 18) load8(ks + 1, fr[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < TH; ++mb)
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w2r[ks], *(const bf16x8*)&fr[ks & 1][mb], acc[mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float b2v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b2v[q] = p.b2[16 * wave + 4 * lg + q];
+#pragma unroll
+      for (int mb = 0; mb < TH; ++mb) {
+        const int row = mb * 16 + lr;
+        uint2 o;
+        o.x = bn_cvt_pk(fmaxf(acc[mb][0] + b2v[0], 0.f), fmaxf(acc[mb][1] + b2v[1], 0.f));
+        o.y = bn_cvt_pk(fmaxf(acc[mb][2] + b2v[2], 0.f), fmaxf(acc[mb][3] + b2v[3], 0.f));
+        *(uint2*)(h2 + row * 128 + (((2 * wave + (lg >> 1)) ^ (row & 7)) << 4) + (lg & 1) * 8) = o;
+      }
+    }
+    TD_BN_BARRIER();  // h2 complete
+    // ================= phase 3: conv3 (+ downsample) + identity + ReLU, channels 64*wave .. +63 =================
+    {
+      uint4 w3r[4][2], wdr[DS ? 4 : 1][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          w3r[i][ks] = *(const uint4*)(p.w3 + ((size_t)(64 * wave + 16 * i + lr) * 64 + ks * 32 + lg * 8) * 2);
+          if constexpr (DS) wdr[i][ks] = *(const uint4*)(p.wd + ((size_t)(64 * wave + 16 * i + lr) * 64 + ks * 32 + lg * 8) * 2);
+        }
+      float b3v[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = 64 * wave + 16 * i + 4 * lg + q;
+          b3v[i][q] = p.b3[n] + (DS ? p.bd[n] : 0.f);
+        }
+      const int x = x0 + lr;
+      uint2 res[2][4];
+      auto fetch_res = [&](int mb, int b) {  // identity rows of centre row mb: 4 x 8 bytes per lane (the input tile was read moments ago: L2)
+        if constexpr (!DS) {
+          const int y = y0 + mb;
+          const bool ok = y < p.H && x < p.W;
+          const char* base = p.x + ((((size_t)img * p.H + (ok ? y : 0)) * p.W + (ok ? x : 0)) * CIN + 64 * wave + 4 * lg) * 2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) res[b][i] = *(const uint2*)(base + 32 * i);
+        }
+      };
+      fetch_res(0, 0);
+#pragma unroll
+      for (int mb = 0; mb < TH; ++mb) {
+        if (mb + 1 < TH) fetch_res(mb + 1, (mb + 1) & 1);
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int row = mb * 16 + lr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const uint4 a = frag(h2, row, ks * 4 + lg);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w3r[i][ks], *(const bf16x8*)&a, acc[i], 0, 0, 0);
+        }
+        if constexpr (DS) {  // identity = downsample(x): two more k-steps over the input tile (halo pixel (mb + 1, lr + 1))
+          const int hp = (mb + 1) * HW + lr + 1;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const uint4 a = frag(xbuf[0], hp, ks * 4 + lg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&wdr[i][ks], *(const bf16x8*)&a, acc[i], 0, 0, 0);
+          }
+        }
+        const int y = y0 + mb;
+        if (y < p.H && x < p.W) {
+          char* orow = p.out + ((((size_t)img * p.H + y) * p.W + x) * 256 + 64 * wave + 4 * lg) * 2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = acc[i][q] + b3v[i][q];
+            if constexpr (!DS) {
+              const uint2 r2 = res[mb & 1][i];
+              v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+              v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+            }
+            uint2 o;
+            o.x = bn_cvt_pk(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+            o.y = bn_cvt_pk(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+            *(uint2*)(orow + 32 * i) = o;
+          }
+        }
+      }
+    }
+    TD_BN_BARRIER();  // every wavefront is done with h2 / the input tile: the next tile's first chunk may land
+    store_chunk(xbuf[0]);
+  }
+}
+
+}  // namespace td
+using namespace td;
+
+extern "C" int td_bottleneck_fused(const void* x, void* out, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                                   const float* b3, const void* wd, const float* bd, int N, int H, int W, int Cin, int dtype, td_stream_t stream) {
+  TD_REQUIRE(x && out && w1 && b1 && w2 && b2 && w3 && b3, "td_bottleneck_fused: null pointer");
+  TD_REQUIRE(dtype == TD_BF16, "td_bottleneck_fused: bf16 only (the exact-fp32 mode runs the block layer by layer)");
+  TD_REQUIRE((Cin == 64 && wd && bd) || (Cin == 256 && !wd), "td_bottleneck_fused: a layer1 block (64 -> 64 -> 256 with downsample, or 256 -> 64 -> 256)");
+  TD_REQUIRE(N >= 1 && H >= 1 && W >= 1 && (double)N * H * W * 256 < 2147483647.0, "td_bottleneck_fused: bad geometry");
+  BneckParams p;
+  p.x = (const char*)x; p.out = (char*)out;
+  p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.w3 = (const char*)w3; p.wd = (const char*)wd;
+  p.b1 = b1; p.b2 = b2; p.b3 = b3; p.bd = bd;
+  p.N = N; p.H = H; p.W = W;
+  p.tiles_y = cdiv(H, 8);
+  p.tiles_x = cdiv(W, 16);
+  const long long nt = (long long)N * p.tiles_y * p.tiles_x;
+  TD_REQUIRE(nt < 2000000000LL, "td_bottleneck_fused: too many tiles");
+  p.n_tiles = (int)nt;
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+  }();
+  hipStream_t st = (hipStream_t)stream;
+  const bool prof = prof_on();
+  const double rows = (double)N * H * W;
+  if (prof) {
+    prof_begin(TD_PROF_PW_RESIDENT, dtype, 2.0 * rows * (64.0 * Cin + 64.0 * 576 + 256.0 * 64 + (wd ? 256.0 * 64 : 0.0)), st, (int)std::min(rows, 2147483647.0), 256, Cin, 3, 1, 0);
+    prof_set_bytes((rows * (Cin + 256.0) + 64.0 * Cin + 64.0 * 576 + 256.0 * 64) * 2.0);
+  }
+  const int grid = (int)std::min<long long>(nt, 2LL * n_cu);
+  if (Cin == 64) bottleneck_fused_kernel<64, true><<<grid, 256, 0, st>>>(p);
+  else bottleneck_fused_kernel<256, false><<<grid, 256, 0, st>>>(p);
+  if (prof) prof_end(st);
+  return check_launch("td_bottleneck_fused");
+}

@@ -137,7 +137,7 @@ extern "C" int td_resnet_num_convs(const int* nblocks) {
 
 extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const float* mean, const float* inv_std, int N, int H, int W,
                              const int* nblocks, const void* const* w_fwd, const float* const* bias, int save, void* ws,
-                             size_t ws_bytes, void** feat, int* feat_hw, int stem_pairs, int dtype, td_stream_t stream) {
+                             size_t ws_bytes, void** feat, int* feat_hw, int stem_pairs, int first_train_stage, int dtype, td_stream_t stream) {
   TD_REQUIRE(srcs && n_srcs >= 1 && nblocks && w_fwd && bias && ws && feat, "td_resnet_fwd: null pointer");
   TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "td_resnet_fwd: bad dtype");
   {
@@ -182,9 +182,20 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   // conv3 of a layer1 block + conv1 of the block behind it as ONE launch (td_pw_chain): 64 -> 256 -> 64 (| 128 into layer2)
   static const int chain_on = [] { const char* e = getenv("TD_PW_CHAIN"); return e ? atoi(e) : 3; }();  // bit 0: inside layer1, bit 1: into layer2
   bool conv1_done = false;  // this block's conv1 was produced by the previous block's chained launch
+  // frozen 64-plane bottlenecks (layer1: stages below first_train_stage are never back-propagated, so none of their inner
+  // tensors is needed again) run as ONE launch each (bottleneck.hip): input read once, output written once.  TD_L1_FUSED=0: layer by layer.
+  static const int l1_fused = [] { const char* e = getenv("TD_L1_FUSED"); return e ? atoi(e) : 1; }();
   for (size_t bi = 0; bi < P.blocks.size(); ++bi) {
     auto& b = P.blocks[bi];
     const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
+    if (l1_fused && dtype == TD_BF16 && !conv1_done && (!save || b.stage < first_train_stage) && b.stride == 1 && P.convs[c1].cout == 64 &&
+        P.convs[c3].cout == 256 && ((P.convs[c1].cin == 64 && cd >= 0) || (P.convs[c1].cin == 256 && cd < 0)) &&
+        (double)N * b.out.H * b.out.W * 256 < 2147483647.0) {
+      if ((rc = td_bottleneck_fused(base + b.in.off, base + b.out.off, w_fwd[c1], bias[c1], w_fwd[c2], bias[c2], w_fwd[c3], bias[c3],
+                                    cd >= 0 ? w_fwd[cd] : nullptr, cd >= 0 ? bias[cd] : nullptr, N, b.in.H, b.in.W, P.convs[c1].cin, dtype, stream)))
+        return rc;
+      continue;
+    }
     if (!conv1_done && (rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream))) return rc;
     conv1_done = false;
     if ((rc = run_conv(base, b.h1, b.h2, N, P.convs[c2], w_fwd[c2], bias[c2], nullptr, 1, dtype, stream))) return rc;

@@ -21,6 +21,27 @@
 
 namespace td {
 
+typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_v __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 (v_cvt_pk_bf16_f32, round to nearest even)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  bf16x2_v v = {(__bf16)lo, (__bf16)hi};
+  return *(uint32_t*)&v;
+}
+// element-wise maximum of two packed pairs of NON-NEGATIVE bf16 values: their bit patterns order like unsigned integers (v_pk_max_u16)
+__device__ __forceinline__ uint32_t max_pk_nonneg_bf16(uint32_t a, uint32_t b) {
+  const u16x2_v r = __builtin_elementwise_max(*(const u16x2_v*)&a, *(const u16x2_v*)&b);
+  return *(const uint32_t*)&r;
+}
+
+// workgroup barrier that orders LDS traffic only: the patch prefetch (global loads into registers) stays in flight across it
+// (__syncthreads() would drain vmcnt and stall every tile on the HBM latency the prefetch exists to hide)
+#define TD_LDS_BARRIER()                                   \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                          \
+  } while (0)
+
 struct StemParams {
   const char* x;      // [N][H][W/2] elements of 8 bf16
   const char* w;      // [64][7][4][8] bf16
@@ -58,23 +79,43 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bias4[i][q] = p.bias[i * 16 + 4 * lg + q];
 
+  // The input patch of tile i + 1 is requested (into registers) before the convolution of tile i and written to LDS behind its
+  // pooling: the HBM latency of a patch is covered by a whole tile of work instead of stalling the workgroup at every tile head.
+  constexpr int PLD = (PR * PC + 255) / 256;  // 16-byte patch elements per thread
+  uint4 pre[PLD];
+  auto fetch_patch = [&](int tile) {
+    const int img = tile / (p.tiles_y * p.tiles_x);
+    const int trem = tile - img * (p.tiles_y * p.tiles_x);
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int iy0 = 2 * (2 * ty * TY - 1) - 3, ix0 = (2 * tx * TX - 1) - 2;  // first input row / pair of the patch
+    const char* ximg = p.x + (size_t)img * p.H * p.WP * 16;
+#pragma unroll
+    for (int j = 0; j < PLD; ++j) {
+      const int e = t + j * 256;
+      const int r = e / PC, c = e - r * PC;
+      const int iy = iy0 + r, ix = ix0 + c;
+      pre[j] = make_uint4(0, 0, 0, 0);  // zeros outside the frame
+      if (e < PR * PC && tile < p.n_tiles && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.WP)
+        pre[j] = *(const uint4*)(ximg + ((size_t)iy * p.WP + ix) * 16);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int j = 0; j < PLD; ++j) {
+      const int e = t + j * 256;
+      if (e < PR * PC) *(uint4*)(patch + e * 16) = pre[j];
+    }
+  };
+  fetch_patch(blockIdx.x);
+  store_patch();
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
     const int img = tile / (p.tiles_y * p.tiles_x);
     const int trem = tile - img * (p.tiles_y * p.tiles_x);
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
     const int py0 = ty * TY, px0 = tx * TX;
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;    // first convolution row / column of the tile (may be -1: pooling pad)
-    const int iy0 = 2 * cy0 - 3, ix0 = cx0 - 2;         // first input row / pair of the patch
-    // (1) input patch -> LDS (zeros outside the frame)
-    const char* ximg = p.x + (size_t)img * p.H * p.WP * 16;
-    for (int e = t; e < PR * PC; e += 256) {
-      const int r = e / PC, c = e - r * PC;
-      const int iy = iy0 + r, ix = ix0 + c;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.WP) v = *(const uint4*)(ximg + ((size_t)iy * p.WP + ix) * 16);
-      *(uint4*)(patch + e * 16) = v;
-    }
-    __syncthreads();
+    fetch_patch(tile + gridDim.x);                     // (1) next tile's patch: in flight during this tile's work
+    TD_LDS_BARRIER();
     // (2) convolution of the tile's rows, 16 at a time per wavefront; result (+ bias, ReLU; 0 outside the image = pooling pad,
     //     valid because every window holds at least one real, non-negative value) -> LDS as bf16
     for (int mb = wave; mb < MB; mb += 4) {
@@ -101,41 +142,33 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = inside ? fmaxf(acc[i][q] + bias4[i][q], 0.f) : 0.f;
-        uint2 o;
-        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        uint2 o;  // (sign bits cleared: a -0.0 out of the ReLU would not order as an unsigned pattern in the pooling below)
+        o.x = cvt_pk_bf16(v[0], v[1]) & 0x7fff7fffu;
+        o.y = cvt_pk_bf16(v[2], v[3]) & 0x7fff7fffu;
         *(uint2*)(ctile + m * CPITCH + (i * 16 + 4 * lg) * 2) = o;
       }
     }
-    __syncthreads();
+    TD_LDS_BARRIER();
     // (3) 3x3 stride-2 max-pool from LDS: pooled (pyl, pxl) covers convolution rows 2pyl .. 2pyl+2, columns 2pxl .. 2pxl+2 of the tile
     for (int e = t; e < TY * TX * 8; e += 256) {
       const int c8 = e & 7, px_ = (e >> 3) % TX, py_ = (e >> 3) / TX;
       const int py = py0 + py_, px = px0 + px_;
       if (py >= p.PH || px >= p.PW) continue;
-      float mx[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) mx[q] = 0.f;
+      uint4 o = make_uint4(0, 0, 0, 0);  // non-negative bf16 values order like their bit patterns: packed unsigned maxima, two channels per operation
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           const uint4 v = *(const uint4*)(ctile + ((2 * py_ + dy) * CC + 2 * px_ + dx) * CPITCH + c8 * 16);
-          const uint32_t* pv = (const uint32_t*)&v;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            mx[2 * q] = fmaxf(mx[2 * q], __uint_as_float(pv[q] << 16));
-            mx[2 * q + 1] = fmaxf(mx[2 * q + 1], __uint_as_float(pv[q] & 0xffff0000u));
-          }
+          o.x = max_pk_nonneg_bf16(o.x, v.x);
+          o.y = max_pk_nonneg_bf16(o.y, v.y);
+          o.z = max_pk_nonneg_bf16(o.z, v.z);
+          o.w = max_pk_nonneg_bf16(o.w, v.w);
         }
-      uint4 o;  // the maxima are bf16 values already: repacking is exact
-      o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
-      o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
-      o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
-      o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
       *(uint4*)(p.y + (((size_t)img * p.PH + py) * p.PW + px) * 128 + c8 * 16) = o;
     }
-    __syncthreads();  // the next tile's patch / convolution rows overwrite what the pooling just read
+    store_patch();    // every wavefront is done reading this tile's patch since the barrier behind the convolution
+    TD_LDS_BARRIER();  // the next tile's convolution rows overwrite what the pooling just read; its patch is complete
   }
 }
 

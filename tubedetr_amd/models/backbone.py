@@ -190,6 +190,11 @@ class ResNetTrunkFn(Function):
             _hip.check(L.td_stem_pair_weights(preps[0][0].data_ptr(), w_pairs.data_ptr(), w_pairs.shape[0], code, _hip.stream_ptr()), "td_stem_pair_weights")
             w_ptrs = [w_pairs] + w_ptrs[1:]
         keep_alive = [t.detach().contiguous() for t, _ in x.parts]
+        first_stage = 4  # first stage with trainable weights (the reference trains layer2-4: 1); the frozen ones below it may run fused
+        for name, blk in body.blocks():
+            if blk.conv1.weight.requires_grad:
+                first_stage = int(name[5]) - 1
+                break
 
         def sources(a: int, b: int):
             """td_frame_source array describing frames [a, b) of the concatenated source list (pointer arithmetic only)."""
@@ -230,7 +235,7 @@ class ResNetTrunkFn(Function):
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
                 feat_p = C.c_void_p()
                 _hip.check(L.td_resnet_fwd(srcs, n_srcs, mean, inv_std, b - a, H, W, nb, _ptr_array(w_ptrs), _ptr_array([p[2] for p in preps]),
-                                           0, ws.data_ptr(), nbytes, C.byref(feat_p), hw, int(pairs), code, _hip.stream_ptr()), "td_resnet_fwd")
+                                           0, ws.data_ptr(), nbytes, C.byref(feat_p), hw, int(pairs), first_stage, code, _hip.stream_ptr()), "td_resnet_fwd")
                 off = feat_p.value - ws.data_ptr()
                 n_el = (b - a) * hw[0] * hw[1] * hw[2]
                 feats.append(ws[off : off + n_el * dt.itemsize].view(dt).view(b - a, hw[0], hw[1], hw[2]).clone())
@@ -241,7 +246,7 @@ class ResNetTrunkFn(Function):
         feat_p = C.c_void_p()
         hw = (C.c_int * 3)()
         _hip.check(L.td_resnet_fwd(srcs, n_srcs, mean, inv_std, N, H, W, nb, _ptr_array(w_ptrs), _ptr_array([p[2] for p in preps]),
-                                   save, ws.data_ptr(), nbytes, C.byref(feat_p), hw, int(pairs), code, _hip.stream_ptr()), "td_resnet_fwd")
+                                   save, ws.data_ptr(), nbytes, C.byref(feat_p), hw, int(pairs), first_stage, code, _hip.stream_ptr()), "td_resnet_fwd")
         off = feat_p.value - ws.data_ptr()
         n_el = N * hw[0] * hw[1] * hw[2]
         feat = ws[off : off + n_el * dt.itemsize].view(dt).view(N, hw[0], hw[1], hw[2])
