@@ -49,8 +49,10 @@ int td_abi_version(void);
 #define TD_PROF_WGRAD 2
 #define TD_PROF_GEMM_64x128 3
 #define TD_PROF_PW_RESIDENT 4 /* persistent weight-stationary pointwise instance */
-#define TD_PROF_GEMM_256 5 /* 256-row tiles, eight wavefronts (conv_gemm_big_kernel) */
-#define TD_PROF_FAMILIES 6
+#define TD_PROF_GEMM_256 5    /* 256-row tiles, eight wavefronts (conv_gemm_big_kernel), spatial (3x3) layers: the MFMA-bound members */
+#define TD_PROF_GEMM_256_PW 6 /* the same kernel on pointwise layers with K >= 512: HBM-bound (4.2 TB/s of algorithmic bytes) */
+#define TD_PROF_FUSED 7       /* LDS-resident chains: fused stem (stem.hip), fused frozen bottlenecks (bottleneck.hip) */
+#define TD_PROF_FAMILIES 8
 int td_prof_enable(int on);
 int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
 /* Sum of the ALGORITHMIC HBM bytes of the same launches (each operand / result tensor counted once per launch). */

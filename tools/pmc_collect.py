@@ -27,8 +27,11 @@ def family(name):
         return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, *, *>"
     if "td::pw_resident_kernel" in name:
         return "td::pw_resident_kernel<*>"
-    if "td::conv_gemm_big_kernel" in name:
-        return "td::conv_gemm_big_kernel<*>"
+    m = re.search(r"td::conv_gemm_big_kernel<\d+, (true|false)>", name)
+    if m:  # the 256-row tile kernel on spatial (3x3, MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers
+        return f"td::conv_gemm_big_kernel<*, {m.group(1)}>"
+    if "td::stem_pool_kernel" in name or "td::bottleneck_fused_kernel" in name:
+        return "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>"
     if "td::conv_wgrad_wide_batch_kernel" in name or "td::conv_wgrad_batch_kernel" in name:
         return "td::conv_wgrad_*batch_kernel"
     m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)
@@ -57,6 +60,24 @@ def agg(src, dst):
         for (k, c), (n, s, d) in sorted(acc.items()):
             w.writerow([k, c, n, s, d])
     print(f"{len(acc)} (kernel, counter) rows from {len(files)} file(s) -> {dst}")
+    # the same sums per (kernel, grid size): launches of ONE kernel instance are told apart by their grid (the hoisted decoder
+    # key / value projections among the other launches of the shared GEMM kernel)
+    accg = {}
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            key = (r["Kernel_Name"], r.get("Grid_Size", ""), r["Counter_Name"])
+            a = accg.setdefault(key, [0, 0.0, 0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            try:
+                a[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            except Exception:
+                pass
+    with open(os.path.splitext(dst)[0] + "_by_grid.csv", "w", newline="") as fo:
+        w = csv.writer(fo)
+        w.writerow(["kernel", "grid", "counter", "dispatches", "sum", "duration_ns"])
+        for (k, g_, c), (n, s, d) in sorted(accg.items()):
+            w.writerow([k, g_, c, n, s, d])
 
 
 def mfma(src, dst, command=""):
@@ -104,6 +125,38 @@ def mfma(src, dst, command=""):
     if g:
         res["decoder_attention_group"] = {"attention_kernels": g, "target": 0.40,
                                           "with_gemm_family_64x128": util(att + [f for f in per if "conv_gemm_kernel" in f and ", 64, 128," in f])}
+    # The precise group (per (kernel, grid) rows written by `agg` next to its output): the decoder's attention kernels - the
+    # probabilities-based MFMA instances; the encoder runs the lean ones, RoBERTa the head-dim-64 VALU ones - plus the launches of
+    # the shared GEMM kernel whose grid is that of the hoisted key / value projections (M = b*t*S rows, N = layers * 256).
+    by_grid = os.path.splitext(src)[0] + "_by_grid.csv"
+    kv_grid = os.environ.get("TD_KV_GRID", "")
+    if os.path.exists(by_grid):
+        rows = list(csv.DictReader(open(by_grid)))
+
+        def util_rows(sel):
+            mf = ga = dur = 0.0
+            n = 0
+            for r in rows:
+                if not sel(r):
+                    continue
+                v = float(r["sum"])
+                if r["counter"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    mf += v
+                elif r["counter"] == "GRBM_GUI_ACTIVE":
+                    ga += v
+                    n += int(r["dispatches"])
+                    dur += float(r.get("duration_ns") or 0)
+            if ga <= 0:
+                return None
+            return {"dispatches": n, "mfma_util": round(mf / (ga / XCDS * SIMDS), 4), "duration_us": round(dur / 1e3, 1)}
+
+        is_att = lambda r: re.search(r"td::mha_(fwd_mfma_kernel<\d+, false>|bwd_dq_mfma_kernel|bwd_dkv_mfma_kernel)", r["kernel"]) is not None
+        is_kv = lambda r: bool(kv_grid) and "td::conv_gemm_kernel" in r["kernel"] and r["grid"] == kv_grid
+        res["decoder_attention_group_precise"] = {
+            "definition": "decoder temporal self-attention + time-aligned cross-attention kernels (mha_*_mfma_kernel, probabilities-based instances) "
+                          "+ the hoisted key / value projection GEMMs (launches of td::conv_gemm_kernel with grid " + (kv_grid or "<TD_KV_GRID unset>") + ")",
+            "target": 0.40, "attention_kernels": util_rows(is_att), "kv_projections": util_rows(is_kv),
+            "group": util_rows(lambda r: is_att(r) or is_kv(r))}
     json.dump(res, open(dst, "w"), indent=1)
     for f, v in res.items():
         if isinstance(v, dict) and "mfma_util" in v:

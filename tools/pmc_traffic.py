@@ -13,8 +13,11 @@ def family(name):
         return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, *, *>"  # stages and pointwise flag merged
     if "td::pw_resident_kernel" in name:
         return "td::pw_resident_kernel<*>"
-    if "td::conv_gemm_big_kernel" in name:
-        return "td::conv_gemm_big_kernel<*>"
+    m = re.search(r"td::conv_gemm_big_kernel<\d+, (true|false)>", name)
+    if m:  # the 256-row tile kernel on spatial (3x3, MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers
+        return f"td::conv_gemm_big_kernel<*, {m.group(1)}>"
+    if "td::stem_pool_kernel" in name or "td::bottleneck_fused_kernel" in name:
+        return "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>"
     if "td::conv_wgrad_wide_batch_kernel" in name or "td::conv_wgrad_batch_kernel" in name:
         return "td::conv_wgrad_*batch_kernel"
     m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)

@@ -64,13 +64,17 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
   __shared__ __attribute__((aligned(16))) char h1[HROWS * 128];
   __shared__ __attribute__((aligned(16))) char h2own[NC > 1 ? 16 : NCEN * 128];
   char* h2 = NC > 1 ? xbuf[1] : h2own;  // CIN = 256: the second chunk buffer is dead after phase 1
-  const int t = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-  const int lr = lane & 15, lg = lane >> 4;
+  const int t0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6);
+  // t / lr / lg are re-"defined" at the head of every tile (an empty asm the optimiser cannot see through): all the per-lane
+  // address arithmetic below is then recomputed per tile - a handful of VALU operations - instead of being hoisted out of the
+  // persistent loop, kept live across all three phases and spilled (every scratch access would wait behind the phase-3 stores)
+  int t = t0, lr = t0 & 15, lg = (t0 & 63) >> 4;
   const int tiles_per_img = p.tiles_y * p.tiles_x;
 
   // ---- input chunk loader: 192 rows x 8 chunks of 16 bytes = 6 per thread ----
   uint4 pre[6];
+  bool ok[6];
   auto fetch_chunk = [&](int tile, int kc) {
     const int img = tile / tiles_per_img;
     const int trem = tile - img * tiles_per_img;
@@ -82,9 +86,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
       const int row = e >> 3, c = e & 7;
       const int hy = row / HW, hx = row - hy * HW;
       const int y = y0 + hy, x = x0 + hx;
-      pre[j] = make_uint4(0, 0, 0, 0);
-      if (tile < p.n_tiles && row < NHALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-        pre[j] = *(const uint4*)(p.x + ((((size_t)img * p.H + y) * p.W + x) * CIN + kc * 64 + c * 8) * 2);
+      // branch-free: every lane always issues its 6 loads (from the tensor's first bytes when the pixel lies outside the frame /
+      // the tile does not exist) and the zero is selected afterwards - a load under a branch cannot be counted by the compiler's
+      // vmcnt bookkeeping, which then waits for EVERYTHING in flight (this prefetch included) at the next weight-fragment use
+      ok[j] = tile < p.n_tiles && row < NHALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const size_t off = ok[j] ? ((((size_t)img * p.H + y) * p.W + x) * CIN + kc * 64 + c * 8) * 2 : (size_t)0;
+      pre[j] = *(const uint4*)(p.x + off);
     }
   };
   auto store_chunk = [&](char* buf) {
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
     for (int j = 0; j < 6; ++j) {
       const int e = t + j * 256;
       const int row = e >> 3, c = e & 7;
-      *(uint4*)(buf + row * 128 + ((c ^ (row & 7)) << 4)) = pre[j];
+      *(uint4*)(buf + row * 128 + ((c ^ (row & 7)) << 4)) = ok[j] ? pre[j] : make_uint4(0, 0, 0, 0);
     }
   };
   auto frag = [&](const char* buf, int row, int c16) -> uint4 { return *(const uint4*)(buf + row * 128 + ((c16 ^ (row & 7)) << 4)); };
@@ -100,17 +107,23 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
   fetch_chunk(blockIdx.x, 0);
   store_chunk(xbuf[0]);
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    asm volatile("" : "+v"(t), "+v"(lr), "+v"(lg));
     const int img = tile / tiles_per_img;
     const int trem = tile - img * tiles_per_img;
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;  // first centre pixel
     // ================= phase 1: conv1 on the halo tile, channels 16*wave .. +15 =================
     {
+      // (requested behind the previous tile's output stores in the in-order VMEM queue: the first MFMA below may wait for their
+      //  write latency - the other workgroup of the CU computes meanwhile; keeping these 32 registers resident instead spills)
       uint4 w1r[NC][2];
 #pragma unroll
       for (int kc = 0; kc < NC; ++kc)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) w1r[kc][ks] = *(const uint4*)(p.w1 + ((size_t)(16 * wave + lr) * CIN + kc * 64 + ks * 32 + lg * 8) * 2);
+      float b1v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b1v[q] = p.b1[16 * wave + 4 * lg + q];
       f32x4 acc[12];
 #pragma unroll
       for (int mb = 0; mb < 12; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -119,21 +132,21 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
       for (int kc = 0; kc < NC; ++kc) {
         if (kc + 1 < NC) fetch_chunk(tile, kc + 1);
         const char* xb = xbuf[kc & (XBUFS - 1)];
-        // groups of 6 fragments, double-buffered: group g + 1 is requested before the MFMAs of group g, and the scheduler may not
+        // groups of 4 fragments, double-buffered: group g + 1 is requested before the MFMAs of group g, and the scheduler may not
         // move anything across a group boundary (left alone it hoists every fragment read of the phase and spills)
-        uint4 fr[2][6];
-        auto load6 = [&](int g, uint4 (&dst)[6]) {  // g = ks * 2 + (which half of the 12 row blocks)
+        uint4 fr[2][4];
+        auto load4 = [&](int g, uint4 (&dst)[4]) {  // g = ks * 3 + (which third of the 12 row blocks)
 #pragma unroll
-          for (int j = 0; j < 6; ++j) dst[j] = frag(xb, ((g & 1) * 6 + j) * 16 + lr, (g >> 1) * 4 + lg);
+          for (int j = 0; j < 4; ++j) dst[j] = frag(xb, ((g % 3) * 4 + j) * 16 + lr, (g / 3) * 4 + lg);
         };
-        load6(0, fr[0]);
+        load4(0, fr[0]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (g + 1 < 4) load6(g + 1, fr[(g + 1) & 1]);
+        for (int g = 0; g < 6; ++g) {
+          if (g + 1 < 6) load4(g + 1, fr[(g + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 6; ++j)
-            acc[(g & 1) * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w1r[kc][g >> 1], *(const bf16x8*)&fr[g & 1][j], acc[(g & 1) * 6 + j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j)
+            acc[(g % 3) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w1r[kc][g / 3], *(const bf16x8*)&fr[g & 1][j], acc[(g % 3) * 4 + j], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (kc + 1 < NC) {
@@ -141,9 +154,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
           TD_BN_BARRIER();
         }
       }
-      float b1v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) b1v[q] = p.b1[16 * wave + 4 * lg + q];
 #pragma unroll
       for (int mb = 0; mb < 12; ++mb) {
         const int row = mb * 16 + lr;
@@ -156,36 +166,40 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
         *(uint2*)(h1 + row * 128 + (((2 * wave + (lg >> 1)) ^ (row & 7)) << 4) + (lg & 1) * 8) = o;
       }
     }
-    fetch_chunk(tile + gridDim.x, 0);  // next tile's first chunk: in flight during phases 2 and 3
-    TD_BN_BARRIER();                   // h1 complete
+    TD_BN_BARRIER();  // h1 complete
     // ================= phase 2: conv2 3x3 on the centre pixels, channels 16*wave .. +15 =================
     {
       uint4 w2r[18];
 #pragma unroll
       for (int ks = 0; ks < 18; ++ks) w2r[ks] = *(const uint4*)(p.w2 + ((size_t)(16 * wave + lr) * 576 + ks * 32 + lg * 8) * 2);
-      f32x4 acc[TH];
-#pragma unroll
-      for (int mb = 0; mb < TH; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // 18 k-steps (tap, channel half) of 8 fragments each, double-buffered like phase 1
-      uint4 fr[2][TH];
-      auto load8 = [&](int ks, uint4 (&dst)[TH]) {
-        const int tap = ks >> 1, r = tap / 3, s = tap - 3 * r;
-#pragma unroll
-        for (int mb = 0; mb < TH; ++mb) dst[mb] = frag(h1, (mb + r) * HW + lr + s, (ks & 1) * 4 + lg);  // centre pixel (mb, lr) -> halo pixel (mb + r, lr + s)
-      };
-      load8(0, fr[0]);
-#pragma unroll
-      for (int ks = 0; ks < 18; ++ks) {
-        if (ks + 1 < 18) load8(ks + 1, fr[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mb = 0; mb < TH; ++mb)
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w2r[ks], *(const bf16x8*)&fr[ks & 1][mb], acc[mb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      // next tile's first input chunk: in flight during phases 2 and 3.  Requested BEHIND this phase's weights: loads return in
+      // order, so the first MFMA (which waits for w2r[0]) would otherwise also wait for the HBM latency of the prefetch
       float b2v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) b2v[q] = p.b2[16 * wave + 4 * lg + q];
+      __builtin_amdgcn_sched_barrier(0);  // (keeps the issue order: the compiler would otherwise be free to put the prefetch first)
+      fetch_chunk(tile + gridDim.x, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[TH];
+#pragma unroll
+      for (int mb = 0; mb < TH; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // 18 k-steps (tap, channel half) x 2 groups of 4 fragments, double-buffered like phase 1
+      uint4 fr[2][4];
+      auto load4 = [&](int g, uint4 (&dst)[4]) {  // g = ks * 2 + (rows 0-3 | rows 4-7 of the tile)
+        const int ks = g >> 1, tap = ks >> 1, r = tap / 3, s = tap - 3 * r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = frag(h1, ((g & 1) * 4 + j + r) * HW + lr + s, (ks & 1) * 4 + lg);  // centre pixel (mb, lr) -> halo pixel (mb + r, lr + s)
+      };
+      load4(0, fr[0]);
+#pragma unroll
+      for (int g = 0; g < 36; ++g) {
+        if (g + 1 < 36) load4(g + 1, fr[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[(g & 1) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w2r[g >> 1], *(const bf16x8*)&fr[g & 1][j], acc[(g & 1) * 4 + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int mb = 0; mb < TH; ++mb) {
         const int row = mb * 16 + lr;
@@ -215,20 +229,22 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
           b3v[i][q] = p.b3[n] + (DS ? p.bd[n] : 0.f);
         }
       const int x = x0 + lr;
-      uint2 res[2][4];
-      auto fetch_res = [&](int mb, int b) {  // identity rows of centre row mb: 4 x 8 bytes per lane (the input tile was read moments ago: L2)
-        if constexpr (!DS) {
+      // identity rows of the whole tile (8 centre rows x 4 x 8 bytes per lane; the input tile was read moments ago: L2 / Infinity
+      // Cache), ALL requested before the first output store: vmcnt counts loads and stores in one in-order queue on this ISA, so a
+      // load issued behind a store cannot be waited for without waiting for the store's (long) write latency as well
+      uint2 res[DS ? 1 : TH][4];
+      if constexpr (!DS) {
+#pragma unroll
+        for (int mb = 0; mb < TH; ++mb) {
           const int y = y0 + mb;
           const bool ok = y < p.H && x < p.W;
           const char* base = p.x + ((((size_t)img * p.H + (ok ? y : 0)) * p.W + (ok ? x : 0)) * CIN + 64 * wave + 4 * lg) * 2;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) res[b][i] = *(const uint2*)(base + 32 * i);
+          for (int i = 0; i < 4; ++i) res[mb][i] = *(const uint2*)(base + 32 * i);
         }
-      };
-      fetch_res(0, 0);
+      }
 #pragma unroll
       for (int mb = 0; mb < TH; ++mb) {
-        if (mb + 1 < TH) fetch_res(mb + 1, (mb + 1) & 1);
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = acc[i][q] + b3v[i][q];
             if constexpr (!DS) {
-              const uint2 r2 = res[mb & 1][i];
+              const uint2 r2 = res[mb][i];
               v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
               v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
             }
@@ -302,7 +318,7 @@ extern "C" int td_bottleneck_fused(const void* x, void* out, const void* w1, con
   const bool prof = prof_on();
   const double rows = (double)N * H * W;
   if (prof) {
-    prof_begin(TD_PROF_PW_RESIDENT, dtype, 2.0 * rows * (64.0 * Cin + 64.0 * 576 + 256.0 * 64 + (wd ? 256.0 * 64 : 0.0)), st, (int)std::min(rows, 2147483647.0), 256, Cin, 3, 1, 0);
+    prof_begin(TD_PROF_FUSED, dtype, 2.0 * rows * (64.0 * Cin + 64.0 * 576 + 256.0 * 64 + (wd ? 256.0 * 64 : 0.0)), st, (int)std::min(rows, 2147483647.0), 256, Cin, 3, 1, 0);
     prof_set_bytes((rows * (Cin + 256.0) + 64.0 * Cin + 64.0 * 576 + 256.0 * 64) * 2.0);
   }
   const int grid = (int)std::min<long long>(nt, 2LL * n_cu);

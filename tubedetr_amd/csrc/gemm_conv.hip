@@ -1868,7 +1868,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
     if (big_on && dtype == TD_BF16 && (pw || tu) && d->Nc % 128 == 0 && p.K % 64 == 0 && p.K >= 512 && d->ldc % 8 == 0 && !p.sigmoid &&
         !p.drop_thresh && wgs >= big_min && (double)p.M * d->ldc < 2147483647.0) {
       if (prof) {
-        prof_begin(TD_PROF_GEMM_256, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
+        prof_begin(tu ? TD_PROF_GEMM_256 : TD_PROF_GEMM_256_PW, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
         double by = ((double)d->N * d->Hs * d->Ws * d->C + (double)d->Nc * p.K + (double)p.M * d->Nc) * 2.0;
         if (p.residual) by += (double)p.M * d->Nc * 2.0;
         if (p.mask_src) by += (double)p.M * d->Nc * 2.0;

@@ -200,7 +200,7 @@ extern "C" int td_stem_pool(const void* x_pairs, const void* w_pairs, const floa
   hipStream_t st = (hipStream_t)stream;
   const bool prof = prof_on();
   if (prof) {
-    prof_begin(TD_PROF_GEMM_128x64, dtype, 2.0 * N * p.CH * p.CW * 64.0 * 224.0, st, N * p.CH * p.CW, 64, 224, 7, 2, 0);
+    prof_begin(TD_PROF_FUSED, dtype, 2.0 * N * p.CH * p.CW * 64.0 * 224.0, st, N * p.CH * p.CW, 64, 224, 7, 2, 0);
     prof_set_bytes(((double)N * H * W * 4 + (double)N * p.PH * p.PW * 64 + 64.0 * 224) * 2.0);
   }
   // 22-wide tiles when they divide the pooled width (res 352 -> 88 = 4 x 22: no half-empty tile column), else 16-wide

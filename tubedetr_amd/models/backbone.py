@@ -111,16 +111,23 @@ class ResNetBody(nn.Module):
     def forward(self, x: torch.Tensor, compute_dtype: torch.dtype, n_grad=None) -> torch.Tensor:
         """x (N,3,H,W) fp32 NCHW -> layer4 features [N,h,w,2048] NHWC in ``compute_dtype``.  ``n_grad``: only the first
         n_grad frames are back-propagated (the rest are the reference's no_grad "fast" frames run in the same pass)."""
+        feat, rest = self.forward_split(x, compute_dtype, n_grad)
+        return feat if rest.shape[0] == 0 else torch.cat([feat, rest])  # (callers that want both parts use forward_split: no copy)
+
+    def forward_split(self, x, compute_dtype: torch.dtype, n_grad=None):
+        """-> (features of the first n_grad frames, differentiable; features of the remaining frames, not differentiable): two views
+        of the pass's own workspace.  One tensor sliced afterwards would make autograd zero-fill and copy a full-size gradient
+        (0.5 GB at 1 000 frames) for the slice's backward."""
         tw = self.trainable_weights() if torch.is_grad_enabled() else []
-        feat = ResNetTrunkFn.apply(self, x, compute_dtype, x.shape[0] if n_grad is None else int(n_grad), *tw)
+        feat, rest = ResNetTrunkFn.apply(self, x, compute_dtype, x.shape[0] if n_grad is None else int(n_grad), *tw)
         if self.split_backward and tw:
             # cut the autograd graph at the trunk output: loss.backward() then stops here (stage 1: decoder, encoder, text
             # encoder, input_proj) and backward_trunk() runs the trunk's backward as a separate stage - the gradient
             # exchange of everything else overlaps it (tubedetr_amd.harness.backward_in_stages)
             leaf = feat.detach().requires_grad_()
             self._split = (feat, leaf)
-            return leaf
-        return feat
+            return leaf, rest
+        return feat, rest
 
     def backward_trunk(self) -> bool:
         """Second backward stage of a split step; returns False when there is nothing to do."""
@@ -228,6 +235,7 @@ class ResNetTrunkFn(Function):
         if n_chunks > 1:
             step_n = -(-N // n_chunks)
             feats, hw = [], (C.c_int * 3)()
+            assert n_grad == N or not save
             for a in range(0, N, step_n):
                 b = min(N, a + step_n)
                 srcs, n_srcs = sources(a, b)
@@ -239,7 +247,8 @@ class ResNetTrunkFn(Function):
                 off = feat_p.value - ws.data_ptr()
                 n_el = (b - a) * hw[0] * hw[1] * hw[2]
                 feats.append(ws[off : off + n_el * dt.itemsize].view(dt).view(b - a, hw[0], hw[1], hw[2]).clone())
-            return torch.cat(feats)
+            full = torch.cat(feats)
+            return full[:n_grad], full[n_grad:]
         srcs, n_srcs = sources(0, N)
         nbytes = L.td_resnet_fwd_ws_bytes(N, H, W, nb, code, save)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -251,12 +260,16 @@ class ResNetTrunkFn(Function):
         n_el = N * hw[0] * hw[1] * hw[2]
         feat = ws[off : off + n_el * dt.itemsize].view(dt).view(N, hw[0], hw[1], hw[2])
         if not save:
-            return feat.clone()  # let the ring workspace go
+            feat = feat.clone()  # let the ring workspace go
+            return feat[:n_grad], feat[n_grad:]
+        # two views of the workspace (kept alive by them and by ctx until backward): the frames that are back-propagated and the rest
         ctx.body, ctx.dt, ctx.ws, ctx.preps, ctx.dims = body, dt, ws, preps, (n_grad, N, H, W)
-        return feat.clone()
+        a, b = feat[:n_grad], feat[n_grad:]
+        ctx.mark_non_differentiable(b)
+        return a, b
 
     @staticmethod
-    def backward(ctx, dfeat):
+    def backward(ctx, dfeat, _drest=None):
         import ctypes as C
 
         from .. import _hip
@@ -302,17 +315,28 @@ class BackboneBase(nn.Module):
         self.num_channels = num_channels
         self.compute_dtype = torch.float32
 
-    def forward(self, tensor_list: NestedTensor, n_grad=None):
-        feat = self.body(tensor_list.tensors, self.compute_dtype, n_grad)  # [N,h,w,C] NHWC
-        n, h, w, _ = feat.shape
-        m = tensor_list.mask
+    @staticmethod
+    def _mask_like(m: torch.Tensor, h: int, w: int) -> torch.Tensor:
         # F.interpolate(mode="nearest") index rule: floor(dst * float32(in/out))  (backbone.py:101-103)
         iy = _nearest_index(h, m.shape[-2], m.device)
         ix = _nearest_index(w, m.shape[-1], m.device)
-        mask = m[:, iy][:, :, ix]
+        return m[:, iy][:, :, ix]
+
+    def forward(self, tensor_list: NestedTensor, n_grad=None):
+        feat = self.body(tensor_list.tensors, self.compute_dtype, n_grad)  # [N,h,w,C] NHWC
+        n, h, w, _ = feat.shape
         out = OrderedDict()
-        out[0] = NestedTensor(feat.permute(0, 3, 1, 2), mask)  # (N,C,h,w) view, channels-last strides
+        out[0] = NestedTensor(feat.permute(0, 3, 1, 2), self._mask_like(tensor_list.mask, h, w))  # (N,C,h,w) view, channels-last strides
         return out
+
+    def forward_split(self, frames, n_grad: int, mask_grad: torch.Tensor, mask_rest: torch.Tensor):
+        """The slow (back-propagated) and fast (no_grad, tubedetr.py:128-129) frames of a step in ONE trunk pass, returned apart:
+        (NestedTensor of the first n_grad frames, NestedTensor of the rest).  The pad masks are down-sampled separately (the
+        full-resolution masks of 1 000 frames are 124 MB: nothing concatenates them)."""
+        a, b = self.body.forward_split(frames, self.compute_dtype, n_grad)
+        h, w = a.shape[1], a.shape[2]
+        return (NestedTensor(a.permute(0, 3, 1, 2), self._mask_like(mask_grad, h, w)),
+                NestedTensor(b.permute(0, 3, 1, 2), self._mask_like(mask_rest, h, w)))
 
 
 _IDX_CACHE: dict = {}
@@ -358,6 +382,11 @@ class Joiner(nn.Sequential):
             out.append(x)
             pos.append(self[1](x) if want_pos else None)
         return out, pos
+
+    def forward_split(self, frames, n_grad: int, mask_grad, mask_rest, want_pos: bool = True):
+        """-> (slow features, their pos or None, fast features): BackboneBase.forward_split + the positional encoding of the slow part."""
+        slow, fast = self[0].forward_split(frames, n_grad, mask_grad, mask_rest)
+        return slow, (self[1](slow) if want_pos else None), fast
 
 
 def build_backbone(args):

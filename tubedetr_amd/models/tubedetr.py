@@ -182,12 +182,10 @@ class TubeDETR(nn.Module):
             # slow (grad) and fast (no_grad, tubedetr.py:128-129) frames share the trunk weights: one launch sequence over
             # both, with the slow frames first; only they are saved-for / reached-by backward.
             n_slow = samples.tensors.shape[0]
-            both = NestedTensor(FrameSources(_parts(samples.tensors) + _parts(samples_fast.tensors), _valid(samples.tensors) + _valid(samples_fast.tensors)),
-                                torch.cat([samples.mask, samples_fast.mask]))
-            features, pos_all = self.backbone(both, n_slow, want_pos=want_pos)
-            src_all, mask_all = features[-1].decompose()
-            src, mask, pos = src_all[:n_slow], mask_all[:n_slow], [pos_all[-1][:n_slow] if want_pos else None]
-            src_fast_feat, mask_fast = src_all[n_slow:].detach(), mask_all[n_slow:]
+            both = FrameSources(_parts(samples.tensors) + _parts(samples_fast.tensors), _valid(samples.tensors) + _valid(samples_fast.tensors))
+            slow, pos_slow, fast = self.backbone.forward_split(both, n_slow, samples.mask, samples_fast.mask, want_pos=want_pos)
+            (src, mask), pos = slow.decompose(), [pos_slow]
+            src_fast_feat, mask_fast = fast.decompose()
         else:
             features, pos = self.backbone(samples, want_pos=want_pos)
             src, mask = features[-1].decompose()
