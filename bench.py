@@ -343,11 +343,13 @@ def main():
             # with a process group alive its watchdog thread polls HIP events: only THIS thread's calls are held to capture rules
             cap_mode = "thread_local" if distributed else "global"
             graph = torch.cuda.CUDAGraph()
+            ops_.reset_capture_arena()
             with torch.cuda.graph(graph, capture_error_mode=cap_mode):
                 static_loss = body1()
             graph2 = None
             if staged:
                 graph2 = torch.cuda.CUDAGraph()
+                ops_.reset_capture_arena()
                 with torch.cuda.graph(graph2, pool=graph.pool(), capture_error_mode=cap_mode):
                     body2()
             torch.cuda.synchronize()

@@ -256,6 +256,9 @@ def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step():
             l_, _, _, _ = forward_step(model, criterion, weight_dict, batch)
             l_.backward()
             reducer2.gather_stage(early=True)
+        from tubedetr_amd import ops as _ops
+
+        _ops.reset_capture_arena()  # (two captures back to back: the second graph gets zero-fill nodes of its own)
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
             model.backbone[0].body.backward_trunk()
             reducer2.gather_stage(early=False)

@@ -21,12 +21,11 @@ Tensor = torch.Tensor
 
 class _ZeroArena:
     """Pre-zeroed fp32 arena for the accumulate-into outputs of the backward kernels (weight / bias / LayerNorm
-    gradients are produced with atomics): one fill per ~128 MB instead of one torch.zeros launch per gradient
-    (~200 per step).  Slices are handed out once and never reused; the arena lives as long as any slice does."""
+    gradients are produced with atomics): one fill per chunk instead of one torch.zeros launch per gradient
+    (~200 per step).  Slices are handed out once and never reused; a chunk lives as long as any slice of it does."""
 
-    CHUNK = 32 * 1024 * 1024  # floats
-
-    def __init__(self):
+    def __init__(self, chunk: int):
+        self.chunk = chunk  # floats
         self.buf = None
         self.off = 0
 
@@ -34,13 +33,9 @@ class _ZeroArena:
         n = 1
         for d_ in shape:
             n *= int(d_)
-        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            # inside a HIP-graph capture every gradient gets its own captured fill node (sharing one arena between the
-            # capture's private pool and later eager steps faulted on ROCm 7.0)
-            return torch.zeros(shape, dtype=torch.float32, device=device)
         n_al = (n + 63) // 64 * 64  # keep 256-byte alignment of every slice
         if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
-            self.buf = torch.zeros(max(self.CHUNK, n_al), dtype=torch.float32, device=device)
+            self.buf = torch.zeros(max(self.chunk, n_al), dtype=torch.float32, device=device)
             self.off = 0
         out = self.buf[self.off : self.off + n].view(shape)
         self.off += n_al
@@ -48,6 +43,14 @@ class _ZeroArena:
 
 
 _ARENAS: dict = {}  # one arena per launch stream: a chunk returns to the allocator pool of the stream that allocated it
+_CAPTURE_ARENAS: dict = {}  # stream -> arena of the stream capture in progress (its chunks belong to that graph's private pool)
+
+
+def reset_capture_arena() -> None:
+    """Call before starting a new stream capture that directly follows another one (two graphs captured back to back): slices of
+    a chunk whose fill node belongs to the previous graph must not be handed to the next.  (A capture that follows eager
+    launches needs nothing: the first eager zeros_f32 call drops the arenas.)"""
+    _CAPTURE_ARENAS.clear()
 
 
 _USE_ARENA = __import__("os").environ.get("TD_ZERO_ARENA", "1") != "0"
@@ -56,11 +59,23 @@ _USE_ARENA = __import__("os").environ.get("TD_ZERO_ARENA", "1") != "0"
 def zeros_f32(shape, device) -> torch.Tensor:
     if not _USE_ARENA:
         return torch.zeros(shape, dtype=torch.float32, device=device)
+    shape = tuple(shape) if not isinstance(shape, int) else (shape,)
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        # inside a HIP-graph capture: an arena of its own, used for this capture only (sharing one arena between a capture's
+        # private pool and eager steps faulted on ROCm 7.0) - every chunk is ONE captured fill node, re-zeroed at every replay,
+        # instead of one fill node per LayerNorm / bias gradient (~75 per step)
+        # (one arena per capturing stream: a chunk's fill node is ordered only with the work of the stream it was captured on)
+        sp = stream_ptr()
+        if sp not in _CAPTURE_ARENAS:
+            _CAPTURE_ARENAS[sp] = _ZeroArena(256 * 1024)
+        return _CAPTURE_ARENAS[sp].take(shape, device)
+    if _CAPTURE_ARENAS:
+        _CAPTURE_ARENAS.clear()  # a capture has ended: its arenas are never touched again
     key = (str(device), stream_ptr() if device.type == "cuda" else 0)
     arena = _ARENAS.get(key)
     if arena is None:
-        arena = _ARENAS[key] = _ZeroArena()
-    return arena.take(tuple(shape) if not isinstance(shape, int) else (shape,), device)
+        arena = _ARENAS[key] = _ZeroArena(32 * 1024 * 1024)
+    return arena.take(shape, device)
 
 
 def vec_of(dt: torch.dtype) -> int:
