@@ -67,11 +67,16 @@ PMC_TRAFFIC = "r02_pmc_traffic.json"
 PMC_MFMA = "r02_pmc_mfma.json"
 
 
-def make_batch(T, res, k, L, seed, device, clips=1):
-    """SURVEY.md 8d synthetic clips, generated directly in HBM: video ~ N(0,1), slow = video[::k], fast = all frames; `clips`
-    videos of equal duration per batch (video-major frame order, like util/misc.py's collate)."""
+def make_batch(T, res, k, L, seed, device, clips=1, frames="u8"):
+    """SURVEY.md 8d synthetic clips, generated directly in HBM: slow = video[::k], fast = all frames; `clips` videos of equal
+    duration per batch (video-major frame order, like util/misc.py's collate).  frames="u8" (default): decoded uint8 pixels, what
+    the device-side input path takes (tubedetr_amd/data.py: ImageNet normalisation, NHWC and the bf16 cast happen in the trunk's
+    input kernel); frames="fp32": host-normalised fp32 frames ~ N(0,1), the reference's collate format (util/misc.py:106-178)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    video = torch.randn(clips * T, 3, res, res, generator=g, device=device)
+    if frames == "u8":
+        video = torch.randint(0, 256, (clips * T, 3, res, res), generator=g, device=device, dtype=torch.uint8)
+    else:
+        video = torch.randn(clips * T, 3, res, res, generator=g, device=device)
     ids = torch.randint(3, 50000, (clips, L), generator=torch.Generator().manual_seed(seed))  # token ids start on the host, like a tokenizer's output
     ids[:, 0], ids[:, -1] = 0, 2
     cxcy = torch.rand(clips * T, 2, generator=g, device=device) * 0.6 + 0.2
@@ -179,6 +184,9 @@ def main():
     ap.add_argument("--ddp", action="store_true", help="N>1: use torch DistributedDataParallel like main.py:372-376 instead of the flat exchange")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one flat all-reduce after the whole backward instead of the staged, overlapped exchange")
     ap.add_argument("--grad-wire-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the wire")
+    ap.add_argument("--frames", default="u8", choices=["u8", "fp32"],
+                    help="input frames: u8 = decoded uint8 pixels normalised on the device (the input path of tubedetr_amd/data.py, default); "
+                         "fp32 = host-normalised fp32 frames, the reference's collate format")
     ap.add_argument("--no-fast", action="store_true")
     ap.add_argument("--no-tsa", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: run in eval mode")
@@ -268,7 +276,7 @@ def main():
         set_split_backward(model, staged)
 
     n_batches = a.warmup + a.steps + a.roofline_steps
-    batches = [make_batch(T, res, k, L, 1000 * rank + s, dev, B) for s in range(min(n_batches, 4))]
+    batches = [make_batch(T, res, k, L, 1000 * rank + s, dev, B, a.frames) for s in range(min(n_batches, 4))]
     params = [p_ for p_ in model.parameters() if p_.requires_grad]
 
     def eager_step(i):
@@ -488,7 +496,8 @@ def main():
             "execution": execution,
             "gradient_exchange": (None if not distributed else ("torch DDP (find_unused_parameters)" if a.ddp else
                                   (f"staged flat all-reduce overlapped with the trunk backward, {a.grad_wire_dtype} on the wire" if staged else f"flat all-reduce after backward, {a.grad_wire_dtype} on the wire"))),
-            "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, {B} clip(s)/GPU/step, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}",
+            "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, {B} clip(s)/GPU/step, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}, "
+                                   f"frames={'uint8 pixels, normalised on the device' if a.frames == 'u8' else 'host-normalised fp32'}",
                        "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random init (reference scheme), seed 42+rank"},
             "flops_note": ("slow frames not recomputed in the fast pass (identical pixels): executed trunk-forward work is 100/125 of the "
                            "reference algorithm's; roofline fractions use executed FLOPs, step_frac_of_mfma_peak the reference algorithm's 6.847 TFLOP") if (model.slow_frames_are_strided_fast and not a.no_fast) else None,

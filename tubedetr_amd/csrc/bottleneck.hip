@@ -34,6 +34,14 @@ __device__ __forceinline__ uint32_t bn_cvt_pk(float lo, float hi) {
   bn_bf16x2 v = {(__bf16)lo, (__bf16)hi};
   return *(uint32_t*)&v;
 }
+typedef unsigned int bn_u32x2 __attribute__((ext_vector_type(2)));
+// 8-byte output store through a buffer descriptor: a lane whose pixel lies outside the image passes an out-of-range offset and the
+// hardware drops the store.  No branch around the stores: behind a branch the compiler cannot count them in its vmcnt bookkeeping
+// and every later wait for an OLDER load (bias, identity rows, the next tile's prefetch) also waits for the stores' write latency.
+__device__ __forceinline__ void bn_store8(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(bn_u32x2{v.x, v.y}, rs, (int)off, 0, 0);
+}
+#define TD_BN_OOB 0xFFFFFFF0u
 #define TD_BN_BARRIER()                                  \
   do {                                                   \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
@@ -71,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
   // persistent loop, kept live across all three phases and spilled (every scratch access would wait behind the phase-3 stores)
   int t = t0, lr = t0 & 15, lg = (t0 & 63) >> 4;
   const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (uint32_t)((size_t)p.N * p.H * p.W * 512), 0x00020000);
 
   // ---- input chunk loader: 192 rows x 8 chunks of 16 bytes = 6 per thread ----
   uint4 pre[6];
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
       for (int mb = 0; mb < TH; ++mb) {
         f32x4 acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{b3v[i][0], b3v[i][1], b3v[i][2], b3v[i][3]};  // the bias seeds the accumulator
         const int row = mb * 16 + lr;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -265,28 +274,211 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
           }
         }
         const int y = y0 + mb;
-        if (y < p.H && x < p.W) {
-          char* orow = p.out + ((((size_t)img * p.H + y) * p.W + x) * 256 + 64 * wave + 4 * lg) * 2;
+        const uint32_t obase = (y < p.H && x < p.W) ? (uint32_t)(((((size_t)img * p.H + y) * p.W + x) * 256 + 64 * wave + 4 * lg) * 2) : TD_BN_OOB;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float v[4];
+        for (int i = 0; i < 4; ++i) {
+          float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = acc[i][q] + b3v[i][q];
-            if constexpr (!DS) {
-              const uint2 r2 = res[mb][i];
-              v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-              v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-            }
-            uint2 o;
-            o.x = bn_cvt_pk(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
-            o.y = bn_cvt_pk(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-            *(uint2*)(orow + 32 * i) = o;
+          for (int q = 0; q < 4; ++q) v[q] = acc[i][q];  // (bias already in the accumulator)
+          if constexpr (!DS) {
+            const uint2 r2 = res[mb][i];
+            v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+            v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
           }
+          uint2 o;
+          o.x = bn_cvt_pk(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+          o.y = bn_cvt_pk(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+          bn_store8(rs_out, obase == TD_BN_OOB ? TD_BN_OOB : obase + 32 * i, o);
         }
       }
     }
     TD_BN_BARRIER();  // every wavefront is done with h2 / the input tile: the next tile's first chunk may land
     store_chunk(xbuf[0]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant for the 256-channel blocks (layer1.1, layer1.2): 8 x 8 tiles with the WHOLE input tile resident in LDS.
+// The streaming kernel above moves 220 KB per 128-pixel tile for them (input halo 92 KB + identity re-read 64 KB + output 64 KB,
+// 1.72 KB per pixel against 1.0 KB algorithmic) and runs at the HBM rate of THOSE bytes (3.8 ms per 1 000 frames, no better than
+// the layer-by-layer path).  Here the 10 x 10 halo tile of all 256 channels (51 KB) is loaded once, all four 64-channel chunks in
+// flight together, conv1 runs over it, and conv3's identity is read back from the same LDS bytes: 83 KB per 64-pixel tile
+// (1.3 KB per pixel), and 51 KB per workgroup in flight during its load phase instead of 24.  No cross-tile prefetch (no
+// registers or LDS left for it): the two workgroups of a CU alternate between their load and compute phases.
+__global__ __launch_bounds__(256, 2) void bottleneck_resident_kernel(BneckParams p) {
+  constexpr int CIN = 256, NC = 4;
+  constexpr int TH = 8, TW = 8, HW = TW + 2;
+  constexpr int NHALO = (TH + 2) * HW, HROWS = 112, MB1 = HROWS / 16;  // 100 halo pixels -> 7 blocks of 16 rows
+  constexpr int NCEN = TH * TW, MB2 = NCEN / 16;                       // 64 centre pixels -> 4 blocks
+  constexpr int LD = HROWS * 8 * NC / 256;                             // 16-byte elements per thread for the whole tile: 14
+  __shared__ __attribute__((aligned(16))) char xall[NC][HROWS * 128];
+  __shared__ __attribute__((aligned(16))) char h1[HROWS * 128];
+  char* h2 = h1;  // conv2's output overwrites conv1's (behind a barrier: every wavefront has finished reading h1)
+  const int t0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6);
+  int t = t0, lr = t0 & 15, lg = (t0 & 63) >> 4;
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (uint32_t)((size_t)p.N * p.H * p.W * 512), 0x00020000);
+  auto frag = [&](const char* buf, int row, int c16) -> uint4 { return *(const uint4*)(buf + row * 128 + ((c16 ^ (row & 7)) << 4)); };
+
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    asm volatile("" : "+v"(t), "+v"(lr), "+v"(lg));
+    const int img = tile / tiles_per_img;
+    const int trem = tile - img * tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    // ---- the whole input halo tile -> LDS: 14 branch-free 16-byte loads per thread, all in flight together ----
+    {
+      uint4 v[LD];
+      bool ok[LD];
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+        const int e = t + j * 256;            // element (row, channel chunk of 8): 32 chunks per pixel row of 256 channels
+        const int row = e >> 5, c32 = e & 31;
+        const int hy = row / HW, hx = row - hy * HW;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        ok[j] = row < NHALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const size_t off = ok[j] ? ((((size_t)img * p.H + y) * p.W + x) * CIN + c32 * 8) * 2 : (size_t)0;
+        v[j] = *(const uint4*)(p.x + off);
+      }
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+        const int e = t + j * 256;
+        const int row = e >> 5, c32 = e & 31;
+        *(uint4*)(xall[c32 >> 3] + row * 128 + (((c32 & 7) ^ (row & 7)) << 4)) = ok[j] ? v[j] : make_uint4(0, 0, 0, 0);
+      }
+    }
+    // ================= phase 1: conv1 on the halo tile, channels 16*wave .. +15 =================
+    {
+      uint4 w1r[NC][2];
+#pragma unroll
+      for (int kc = 0; kc < NC; ++kc)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w1r[kc][ks] = *(const uint4*)(p.w1 + ((size_t)(16 * wave + lr) * CIN + kc * 64 + ks * 32 + lg * 8) * 2);
+      float b1v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b1v[q] = p.b1[16 * wave + 4 * lg + q];
+      f32x4 acc[MB1];
+#pragma unroll
+      for (int mb = 0; mb < MB1; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      TD_BN_BARRIER();  // the tile is complete in LDS
+      // 8 k-steps x 7 row blocks, double-buffered groups: (k-step ks8, rows 0-3) and (ks8, rows 4-6)
+      uint4 fr[2][4];
+      auto load_g = [&](int g, uint4 (&dst)[4]) {
+        const int ks8 = g >> 1, hi = g & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (hi * 4 + j < MB1) dst[j] = frag(xall[ks8 >> 1], (hi * 4 + j) * 16 + lr, (ks8 & 1) * 4 + lg);
+      };
+      load_g(0, fr[0]);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        if (g + 1 < 16) load_g(g + 1, fr[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((g & 1) * 4 + j < MB1)
+            acc[(g & 1) * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w1r[g >> 2][(g >> 1) & 1], *(const bf16x8*)&fr[g & 1][j], acc[(g & 1) * 4 + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB1; ++mb) {
+        const int row = mb * 16 + lr;
+        const int hy = row / HW, hx = row - hy * HW;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool inside = row < NHALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;  // outside: conv2's zero padding
+        uint2 o;
+        o.x = inside ? bn_cvt_pk(fmaxf(acc[mb][0] + b1v[0], 0.f), fmaxf(acc[mb][1] + b1v[1], 0.f)) : 0u;
+        o.y = inside ? bn_cvt_pk(fmaxf(acc[mb][2] + b1v[2], 0.f), fmaxf(acc[mb][3] + b1v[3], 0.f)) : 0u;
+        *(uint2*)(h1 + row * 128 + (((2 * wave + (lg >> 1)) ^ (row & 7)) << 4) + (lg & 1) * 8) = o;
+      }
+    }
+    TD_BN_BARRIER();  // h1 complete
+    // ================= phase 2: conv2 3x3 on the 64 centre pixels, channels 16*wave .. +15 =================
+    {
+      uint4 w2r[18];
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) w2r[ks] = *(const uint4*)(p.w2 + ((size_t)(16 * wave + lr) * 576 + ks * 32 + lg * 8) * 2);
+      float b2v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b2v[q] = p.b2[16 * wave + 4 * lg + q];
+      f32x4 acc[MB2];
+#pragma unroll
+      for (int mb = 0; mb < MB2; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int cyl = lr >> 3, cxl = lr & 7;  // centre pixel of row block mb, lane lr: (2 * mb + cyl, cxl)
+      uint4 fr[2][MB2];
+      auto load_k = [&](int ks, uint4 (&dst)[MB2]) {
+        const int tap = ks >> 1, r = tap / 3, s = tap - 3 * r;
+#pragma unroll
+        for (int mb = 0; mb < MB2; ++mb) dst[mb] = frag(h1, (2 * mb + cyl + r) * HW + cxl + s, (ks & 1) * 4 + lg);
+      };
+      load_k(0, fr[0]);
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) {
+        if (ks + 1 < 18) load_k(ks + 1, fr[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < MB2; ++mb)
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w2r[ks], *(const bf16x8*)&fr[ks & 1][mb], acc[mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      TD_BN_BARRIER();  // every wavefront has read its last h1 fragment: h2 may overwrite it
+#pragma unroll
+      for (int mb = 0; mb < MB2; ++mb) {
+        const int row = mb * 16 + lr;
+        uint2 o;
+        o.x = bn_cvt_pk(fmaxf(acc[mb][0] + b2v[0], 0.f), fmaxf(acc[mb][1] + b2v[1], 0.f));
+        o.y = bn_cvt_pk(fmaxf(acc[mb][2] + b2v[2], 0.f), fmaxf(acc[mb][3] + b2v[3], 0.f));
+        *(uint2*)(h2 + row * 128 + (((2 * wave + (lg >> 1)) ^ (row & 7)) << 4) + (lg & 1) * 8) = o;
+      }
+    }
+    TD_BN_BARRIER();  // h2 complete
+    // ================= phase 3: conv3 + identity (from the LDS tile) + ReLU, channels 64*wave .. +63 =================
+    {
+      uint4 w3r[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w3r[i][ks] = *(const uint4*)(p.w3 + ((size_t)(64 * wave + 16 * i + lr) * 64 + ks * 32 + lg * 8) * 2);
+      float b3v[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b3v[i][q] = p.b3[64 * wave + 16 * i + 4 * lg + q];
+      const int cyl = lr >> 3, cxl = lr & 7;
+      const int x = x0 + cxl;
+#pragma unroll
+      for (int mb = 0; mb < MB2; ++mb) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{b3v[i][0], b3v[i][1], b3v[i][2], b3v[i][3]};  // the bias seeds the accumulator
+        const int row = mb * 16 + lr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const uint4 a = frag(h2, row, ks * 4 + lg);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w3r[i][ks], *(const bf16x8*)&a, acc[i], 0, 0, 0);
+        }
+        const int cy = 2 * mb + cyl;
+        const int hp = (cy + 1) * HW + cxl + 1;  // this pixel's row in the input tile: channels 64*wave .. of chunk `wave`
+        const int y = y0 + cy;
+        const uint32_t obase = (y < p.H && x < p.W) ? (uint32_t)(((((size_t)img * p.H + y) * p.W + x) * 256 + 64 * wave + 4 * lg) * 2) : TD_BN_OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint2 r2 = *(const uint2*)(xall[wave] + hp * 128 + (((2 * i + (lg >> 1)) ^ (hp & 7)) << 4) + (lg & 1) * 8);
+          float v[4];
+          v[0] = acc[i][0] + __uint_as_float(r2.x << 16);
+          v[1] = acc[i][1] + __uint_as_float(r2.x & 0xffff0000u);
+          v[2] = acc[i][2] + __uint_as_float(r2.y << 16);
+          v[3] = acc[i][3] + __uint_as_float(r2.y & 0xffff0000u);
+          uint2 o;
+          o.x = bn_cvt_pk(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+          o.y = bn_cvt_pk(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+          bn_store8(rs_out, obase == TD_BN_OOB ? TD_BN_OOB : obase + 32 * i, o);
+        }
+      }
+    }
+    TD_BN_BARRIER();  // every wavefront is done with the tile: the next one may overwrite it
   }
 }
 
@@ -304,8 +496,10 @@ extern "C" int td_bottleneck_fused(const void* x, void* out, const void* w1, con
   p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.w3 = (const char*)w3; p.wd = (const char*)wd;
   p.b1 = b1; p.b2 = b2; p.b3 = b3; p.bd = bd;
   p.N = N; p.H = H; p.W = W;
+  static const int resident = [] { const char* e = getenv("TD_BNECK_RESIDENT"); return e ? atoi(e) : 1; }();
+  const bool res256 = Cin == 256 && resident;  // 8 x 8 tiles, whole input tile in LDS (bottleneck_resident_kernel)
   p.tiles_y = cdiv(H, 8);
-  p.tiles_x = cdiv(W, 16);
+  p.tiles_x = cdiv(W, res256 ? 8 : 16);
   const long long nt = (long long)N * p.tiles_y * p.tiles_x;
   TD_REQUIRE(nt < 2000000000LL, "td_bottleneck_fused: too many tiles");
   p.n_tiles = (int)nt;
@@ -323,6 +517,7 @@ extern "C" int td_bottleneck_fused(const void* x, void* out, const void* w1, con
   }
   const int grid = (int)std::min<long long>(nt, 2LL * n_cu);
   if (Cin == 64) bottleneck_fused_kernel<64, true><<<grid, 256, 0, st>>>(p);
+  else if (res256) bottleneck_resident_kernel<<<grid, 256, 0, st>>>(p);
   else bottleneck_fused_kernel<256, false><<<grid, 256, 0, st>>>(p);
   if (prof) prof_end(st);
   return check_launch("td_bottleneck_fused");

@@ -23,6 +23,7 @@ namespace td {
 
 typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2_v __attribute__((ext_vector_type(2)));
+typedef unsigned int st_u32x4 __attribute__((ext_vector_type(4)));
 // two fp32 -> packed bf16 (v_cvt_pk_bf16_f32, round to nearest even)
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   bf16x2_v v = {(__bf16)lo, (__bf16)hi};
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int lr = lane & 15, lg = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (uint32_t)((size_t)p.N * p.PH * p.PW * 128), 0x00020000);
   // the weight matrix as MFMA A-operand fragments, resident for the whole launch: wreg[r][i] = rows (channels) i*16 + lr,
   // k = r*32 + lg*8 .. +8  (= filter row r, tap lg)
   uint4 wreg[7][4];
@@ -150,10 +152,13 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
     }
     TD_LDS_BARRIER();
     // (3) 3x3 stride-2 max-pool from LDS: pooled (pyl, pxl) covers convolution rows 2pyl .. 2pyl+2, columns 2pxl .. 2pxl+2 of the tile
-    for (int e = t; e < TY * TX * 8; e += 256) {
-      const int c8 = e & 7, px_ = (e >> 3) % TX, py_ = (e >> 3) / TX;
+    // (branch-free: a pooled pixel outside the map gets an out-of-range buffer offset and the hardware drops its store - stores
+    //  behind a branch cannot be counted by the compiler, and the wait for the prefetched patch below would then also wait for them)
+#pragma unroll
+    for (int it = 0; it < (TY * TX * 8 + 255) / 256; ++it) {
+      const int e = t + it * 256;
+      const int c8 = e & 7, px_ = (e >> 3) % TX, py_ = min((e >> 3) / TX, TY - 1);
       const int py = py0 + py_, px = px0 + px_;
-      if (py >= p.PH || px >= p.PW) continue;
       uint4 o = make_uint4(0, 0, 0, 0);  // non-negative bf16 values order like their bit patterns: packed unsigned maxima, two channels per operation
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
@@ -165,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
           o.z = max_pk_nonneg_bf16(o.z, v.z);
           o.w = max_pk_nonneg_bf16(o.w, v.w);
         }
-      *(uint4*)(p.y + (((size_t)img * p.PH + py) * p.PW + px) * 128 + c8 * 16) = o;
+      const bool live = e < TY * TX * 8 && py < p.PH && px < p.PW;
+      const uint32_t off = live ? (uint32_t)((((size_t)img * p.PH + py) * p.PW + px) * 128 + c8 * 16) : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_buffer_store_b128(st_u32x4{o.x, o.y, o.z, o.w}, rs_y, (int)off, 0, 0);
     }
     store_patch();    // every wavefront is done reading this tile's patch since the barrier behind the convolution
     TD_LDS_BARRIER();  // the next tile's convolution rows overwrite what the pooling just read; its patch is complete
@@ -209,7 +216,7 @@ extern "C" int td_stem_pool(const void* x_pairs, const void* w_pairs, const floa
   p.tiles_y = cdiv(p.PH, TY);
   p.tiles_x = cdiv(p.PW, TX);
   const long long nt = (long long)N * p.tiles_y * p.tiles_x;
-  TD_REQUIRE(nt < 2000000000LL, "td_stem_pool: too many tiles");
+  TD_REQUIRE(nt < 2000000000LL && (double)N * p.PH * p.PW * 128.0 < 4294967000.0, "td_stem_pool: pooled tensor exceeds the 4 GiB buffer-descriptor range");
   p.n_tiles = (int)nt;
   const int grid = (int)std::min<long long>(nt, 2LL * n_cu);
   if (wide) stem_pool_kernel<4, 22><<<grid, 256, 0, st>>>(p);
