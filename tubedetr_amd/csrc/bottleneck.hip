@@ -515,7 +515,8 @@ extern "C" int td_bottleneck_fused(const void* x, void* out, const void* w1, con
     prof_begin(TD_PROF_FUSED, dtype, 2.0 * rows * (64.0 * Cin + 64.0 * 576 + 256.0 * 64 + (wd ? 256.0 * 64 : 0.0)), st, (int)std::min(rows, 2147483647.0), 256, Cin, 3, 1, 0);
     prof_set_bytes((rows * (Cin + 256.0) + 64.0 * Cin + 64.0 * 576 + 256.0 * 64) * 2.0);
   }
-  const int grid = (int)std::min<long long>(nt, 2LL * n_cu);
+  static const int per_cu = [] { const char* e = getenv("TD_BNECK_WG_PER_CU"); return e ? std::max(1, atoi(e)) : 2; }();  // (A/B: persistent workgroups per CU)
+  const int grid = (int)std::min<long long>(nt, (long long)per_cu * n_cu);
   if (Cin == 64) bottleneck_fused_kernel<64, true><<<grid, 256, 0, st>>>(p);
   else if (res256) bottleneck_resident_kernel<<<grid, 256, 0, st>>>(p);
   else bottleneck_fused_kernel<256, false><<<grid, 256, 0, st>>>(p);

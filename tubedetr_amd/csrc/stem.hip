@@ -218,7 +218,8 @@ extern "C" int td_stem_pool(const void* x_pairs, const void* w_pairs, const floa
   const long long nt = (long long)N * p.tiles_y * p.tiles_x;
   TD_REQUIRE(nt < 2000000000LL && (double)N * p.PH * p.PW * 128.0 < 4294967000.0, "td_stem_pool: pooled tensor exceeds the 4 GiB buffer-descriptor range");
   p.n_tiles = (int)nt;
-  const int grid = (int)std::min<long long>(nt, 2LL * n_cu);
+  static const int per_cu = [] { const char* e = getenv("TD_STEM_WG_PER_CU"); return e ? std::max(1, atoi(e)) : 2; }();  // (A/B: persistent workgroups per CU)
+  const int grid = (int)std::min<long long>(nt, (long long)per_cu * n_cu);
   if (wide) stem_pool_kernel<4, 22><<<grid, 256, 0, st>>>(p);
   else stem_pool_kernel<4, 16><<<grid, 256, 0, st>>>(p);
   if (prof) prof_end(st);
