@@ -41,7 +41,15 @@ typedef unsigned int bn_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bn_store8(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint2 v) {
   __builtin_amdgcn_raw_buffer_store_b64(bn_u32x2{v.x, v.y}, rs, (int)off, 0, 0);
 }
+typedef unsigned int bn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bn_store16(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(bn_u32x4{v.x, v.y, v.z, v.w}, rs, (int)off, 0, 0);
+}
 #define TD_BN_OOB 0xFFFFFFF0u
+// Output rows leave through a wavefront-private 2-KiB LDS transposition: the MFMA layout gives a lane 4 consecutive channels of
+// one pixel (8-byte pieces, a store instruction touching 16 cache lines by 32 bytes); read back as 16 bytes per lane with 8 lanes
+// per pixel, a store instruction writes 8 whole 128-byte lines.
+#define TD_BN_STAGE_BYTES 2048
 #define TD_BN_BARRIER()                                  \
   do {                                                   \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
@@ -71,13 +79,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
   __shared__ __attribute__((aligned(16))) char xbuf[XBUFS][HROWS * 128];
   __shared__ __attribute__((aligned(16))) char h1[HROWS * 128];
   __shared__ __attribute__((aligned(16))) char h2own[NC > 1 ? 16 : NCEN * 128];
+  __shared__ __attribute__((aligned(16))) char ostage[4][TD_BN_STAGE_BYTES];
   char* h2 = NC > 1 ? xbuf[1] : h2own;  // CIN = 256: the second chunk buffer is dead after phase 1
   const int t0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6);
   // t / lr / lg are re-"defined" at the head of every tile (an empty asm the optimiser cannot see through): all the per-lane
   // address arithmetic below is then recomputed per tile - a handful of VALU operations - instead of being hoisted out of the
   // persistent loop, kept live across all three phases and spilled (every scratch access would wait behind the phase-3 stores)
-  int t = t0, lr = t0 & 15, lg = (t0 & 63) >> 4;
+  int t = t0, lr = t0 & 15, lg = (t0 & 63) >> 4, lane = t0 & 63;
   const int tiles_per_img = p.tiles_y * p.tiles_x;
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (uint32_t)((size_t)p.N * p.H * p.W * 512), 0x00020000);
 
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
   fetch_chunk(blockIdx.x, 0);
   store_chunk(xbuf[0]);
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    asm volatile("" : "+v"(t), "+v"(lr), "+v"(lg));
+    asm volatile("" : "+v"(t), "+v"(lr), "+v"(lg), "+v"(lane));
     const int img = tile / tiles_per_img;
     const int trem = tile - img * tiles_per_img;
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
@@ -273,8 +282,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&wdr[i][ks], *(const bf16x8*)&a, acc[i], 0, 0, 0);
           }
         }
-        const int y = y0 + mb;
-        const uint32_t obase = (y < p.H && x < p.W) ? (uint32_t)(((((size_t)img * p.H + y) * p.W + x) * 256 + 64 * wave + 4 * lg) * 2) : TD_BN_OOB;
+        char* stg = ostage[wave];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v[4];
@@ -288,8 +296,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(BneckParams p)
           uint2 o;
           o.x = bn_cvt_pk(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
           o.y = bn_cvt_pk(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-          bn_store8(rs_out, obase == TD_BN_OOB ? TD_BN_OOB : obase + 32 * i, o);
+          *(uint2*)(stg + lr * 128 + (((2 * i + (lg >> 1)) ^ (lr & 7)) << 4) + (lg & 1) * 8) = o;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int y = y0 + mb;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {  // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
+          const int px_ = ps * 8 + (lane >> 3), c = lane & 7;
+          const uint4 o16 = *(const uint4*)(stg + px_ * 128 + ((c ^ (px_ & 7)) << 4));
+          const int xo = x0 + px_;
+          const uint32_t off = (y < p.H && xo < p.W) ? (uint32_t)(((((size_t)img * p.H + y) * p.W + xo) * 256 + 64 * wave + 8 * c) * 2) : TD_BN_OOB;
+          bn_store16(rs_out, off, o16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next row block overwrites the region
       }
     }
     TD_BN_BARRIER();  // every wavefront is done with h2 / the input tile: the next tile's first chunk may land
@@ -313,16 +332,17 @@ __global__ __launch_bounds__(256, 2) void bottleneck_resident_kernel(BneckParams
   constexpr int LD = HROWS * 8 * NC / 256;                             // 16-byte elements per thread for the whole tile: 14
   __shared__ __attribute__((aligned(16))) char xall[NC][HROWS * 128];
   __shared__ __attribute__((aligned(16))) char h1[HROWS * 128];
+  __shared__ __attribute__((aligned(16))) char ostage[4][TD_BN_STAGE_BYTES];
   char* h2 = h1;  // conv2's output overwrites conv1's (behind a barrier: every wavefront has finished reading h1)
   const int t0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6);
-  int t = t0, lr = t0 & 15, lg = (t0 & 63) >> 4;
+  int t = t0, lr = t0 & 15, lg = (t0 & 63) >> 4, lane = t0 & 63;
   const int tiles_per_img = p.tiles_y * p.tiles_x;
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (uint32_t)((size_t)p.N * p.H * p.W * 512), 0x00020000);
   auto frag = [&](const char* buf, int row, int c16) -> uint4 { return *(const uint4*)(buf + row * 128 + ((c16 ^ (row & 7)) << 4)); };
 
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    asm volatile("" : "+v"(t), "+v"(lr), "+v"(lg));
+    asm volatile("" : "+v"(t), "+v"(lr), "+v"(lg), "+v"(lane));
     const int img = tile / tiles_per_img;
     const int trem = tile - img * tiles_per_img;
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
@@ -461,8 +481,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_resident_kernel(BneckParams
         }
         const int cy = 2 * mb + cyl;
         const int hp = (cy + 1) * HW + cxl + 1;  // this pixel's row in the input tile: channels 64*wave .. of chunk `wave`
-        const int y = y0 + cy;
-        const uint32_t obase = (y < p.H && x < p.W) ? (uint32_t)(((((size_t)img * p.H + y) * p.W + x) * 256 + 64 * wave + 4 * lg) * 2) : TD_BN_OOB;
+        char* stg = ostage[wave];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint2 r2 = *(const uint2*)(xall[wave] + hp * 128 + (((2 * i + (lg >> 1)) ^ (hp & 7)) << 4) + (lg & 1) * 8);
@@ -474,8 +493,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck_resident_kernel(BneckParams
           uint2 o;
           o.x = bn_cvt_pk(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
           o.y = bn_cvt_pk(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-          bn_store8(rs_out, obase == TD_BN_OOB ? TD_BN_OOB : obase + 32 * i, o);
+          *(uint2*)(stg + lr * 128 + (((2 * i + (lg >> 1)) ^ (lr & 7)) << 4) + (lg & 1) * 8) = o;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {  // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
+          const int px_ = ps * 8 + (lane >> 3), c = lane & 7;  // pixel px_ of the row block: tile row 2 * mb + ps, column lane >> 3
+          const uint4 o16 = *(const uint4*)(stg + px_ * 128 + ((c ^ (px_ & 7)) << 4));
+          const int yo = y0 + 2 * mb + ps, xo = x0 + (lane >> 3);
+          const uint32_t off = (yo < p.H && xo < p.W) ? (uint32_t)(((((size_t)img * p.H + yo) * p.W + xo) * 256 + 64 * wave + 8 * c) * 2) : TD_BN_OOB;
+          bn_store16(rs_out, off, o16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next row block overwrites the region
       }
     }
     TD_BN_BARRIER();  // every wavefront is done with the tile: the next one may overwrite it
