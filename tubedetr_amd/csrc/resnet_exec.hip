@@ -183,12 +183,12 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   static const int chain_on = [] { const char* e = getenv("TD_PW_CHAIN"); return e ? atoi(e) : 3; }();  // bit 0: inside layer1, bit 1: into layer2
   bool conv1_done = false;  // this block's conv1 was produced by the previous block's chained launch
   // frozen 64-plane bottlenecks (layer1: stages below first_train_stage are never back-propagated, so none of their inner
-  // tensors is needed again) can run as ONE launch each (bottleneck.hip).  Measured at 1 000 frames of 88 x 88 (tools/fused_l1_time.py):
-  // block 0 (64 input channels + downsample) 2.38 ms fused vs 4.29 ms layer by layer; the 256-channel blocks 3.80 vs 3.82 ms -
-  // their fused form re-reads the input tile for the identity and its halo for conv2 (220 KB per 128-pixel tile against 128 KB of
-  // algorithmic bytes) and loses the conv3 -> conv1 chain (td_pw_chain) of the layer-by-layer path, which is the faster one for
-  // them.  TD_L1_FUSED: 0 = never, 1 (default) = block 0 only, 2 = every frozen 64-plane block.
-  static const int l1_fused = [] { const char* e = getenv("TD_L1_FUSED"); return e ? atoi(e) : 1; }();
+  // tensors is needed again) run as ONE launch each (bottleneck.hip).  Measured at 1 000 frames of 88 x 88 (tools/fused_l1_time.py):
+  // block 0 (64 input channels + downsample) 2.09 ms fused vs 4.24 ms layer by layer; the 256-channel blocks 3.29 ms (resident-tile
+  // variant) vs 3.72 ms - the layer-by-layer path gets 0.9 ms of that back per block through its conv3 -> conv1 chain (td_pw_chain),
+  // in the network the fully fused layer1 is 0.3 ms per 8-clip step ahead.  TD_L1_FUSED: 0 = never, 1 = block 0 only,
+  // 2 (default) = every frozen 64-plane block.
+  static const int l1_fused = [] { const char* e = getenv("TD_L1_FUSED"); return e ? atoi(e) : 2; }();
   for (size_t bi = 0; bi < P.blocks.size(); ++bi) {
     auto& b = P.blocks[bi];
     const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
