@@ -158,6 +158,8 @@ typedef struct td_wgrad_job {
   float* dbias;       /* optional [Nc] fp32: column sums of g (bias gradient of a Linear / Conv2d with bias), overwritten */
   int accumulate;     /* 1: dW += (instead of =), run behind the overwriting jobs of the same call: the second operand stream of a
                        * two-source layer (td_linear_ex: dW = g^T A1 + g^T A2, the positional operand of the Q / K projections); no dbias */
+  int prezeroed;      /* 1: the caller zero-filled dW (and dbias) already - e.g. ONE fill over a flat buffer that holds the dW of all
+                       * jobs: the library then enqueues no per-job fill for jobs it splits along M (fp32 atomics into dW) */
 } td_wgrad_job;
 size_t td_conv_wgrad_batch_table_bytes(int n_jobs);
 int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev, size_t table_bytes,
@@ -233,9 +235,10 @@ size_t td_resnet_bwd_ws_bytes(int N, int H, int W, const int* nblocks, int first
 /* bytes of the weight-gradient job table (see td_conv_wgrad_batch): table_host = page-locked host memory, table_dev =
  * device memory, both caller-allocated and left untouched until the stream has passed the call. */
 size_t td_resnet_bwd_table_bytes(const int* nblocks, int first_train_stage);
+/* dW_prezeroed = 1: every dW[i] was zero-filled by the caller (one fill over the flat buffer they are views of): no per-job fills. */
 int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, const int* nblocks, int first_train_stage,
                   const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws, void* ws,
-                  size_t ws_bytes, void* table_host, void* table_dev, size_t table_bytes, int dtype, td_stream_t stream);
+                  size_t ws_bytes, void* table_host, void* table_dev, size_t table_bytes, int dW_prezeroed, int dtype, td_stream_t stream);
 
 /* Fold FrozenBatchNorm2d (models/backbone.py:60-70) into a conv: w_fwd[co][r][s][ci] = W[co][ci][r][s]*scale[co]
  * (ci zero-padded to Cpad), w_dgrad[ci][r][s][co] likewise (may be NULL), bias_out[co] = b - rm*scale,

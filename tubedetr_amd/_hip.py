@@ -28,7 +28,7 @@ class PrepItem(C.Structure):
 
 class WgradJob(C.Structure):
     """td_wgrad_job (include/tubedetr_hip.h)."""
-    _fields_ = [("g", C.c_void_p), ("src", C.c_void_p), ("dW", C.c_void_p), ("scale", C.c_void_p), ("d", ConvDesc), ("ldg", C.c_int), ("ci_real", C.c_int), ("dbias", C.c_void_p), ("accumulate", C.c_int)]
+    _fields_ = [("g", C.c_void_p), ("src", C.c_void_p), ("dW", C.c_void_p), ("scale", C.c_void_p), ("d", ConvDesc), ("ldg", C.c_int), ("ci_real", C.c_int), ("dbias", C.c_void_p), ("accumulate", C.c_int), ("prezeroed", C.c_int)]
 
 
 TD_U8 = 2
@@ -83,7 +83,7 @@ _SIGS = {
     "td_stem_pool": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "td_pw_chain": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "td_frames_to_nhwc": [C.POINTER(FrameSource), _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P],
-    "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _P, _P, _SZ, _I, _P],
+    "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _P, _P, _SZ, _I, _I, _P],
     "td_weight_prep_batch": [_P, _I, _I, _I, _P],
     "td_weight_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "td_wgrad_finalize": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

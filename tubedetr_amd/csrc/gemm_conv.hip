@@ -2170,7 +2170,7 @@ static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, vo
     p.out_mode = (splits == 1 && !accumulate) ? 2 : 1;
     TD_REQUIRE(!accumulate || !j.dbias, "td_conv_wgrad_batch: job %d: an accumulating job cannot carry a bias gradient", i);
     p.first = splits;  // (temporarily: the split count, replaced by the first workgroup index below)
-    if (splits > 1 && !accumulate &&
+    if (splits > 1 && !accumulate && !j.prezeroed &&
         (hipMemsetAsync(j.dW, 0, (size_t)j.d.Nc * j.ci_real * j.d.R * j.d.S * sizeof(float), st) != hipSuccess ||
          (j.dbias && hipMemsetAsync(j.dbias, 0, (size_t)j.d.Nc * sizeof(float), st) != hipSuccess))) {
       set_error("td_conv_wgrad_batch: memset failed");

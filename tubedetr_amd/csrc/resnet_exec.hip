@@ -295,7 +295,7 @@ extern "C" size_t td_resnet_bwd_table_bytes(const int* nblocks, int first_train_
 
 extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, const int* nblocks, int first_train_stage,
                              const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws,
-                             void* ws, size_t ws_bytes, void* table_host, void* table_dev, size_t table_bytes, int dtype,
+                             void* ws, size_t ws_bytes, void* table_host, void* table_dev, size_t table_bytes, int dW_prezeroed, int dtype,
                              td_stream_t stream) {
   TD_REQUIRE(dfeat && nblocks && w_dgrad && scale && dW && fwd_ws && ws, "td_resnet_bwd: null pointer");
   TD_REQUIRE(N >= 1 && N <= N_fwd, "td_resnet_bwd: N=%d must be in 1..N_fwd=%d", N, N_fwd);
@@ -342,6 +342,7 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
       j.ci_real = c.cin;
       j.dbias = nullptr;
       j.accumulate = 0;
+      j.prezeroed = dW_prezeroed;
       jobs.push_back(j);
       return TD_OK;
     }

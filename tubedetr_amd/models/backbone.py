@@ -285,7 +285,14 @@ class ResNetTrunkFn(Function):
                 first_stage = int(name[5]) - 1
                 break
         nb = (C.c_int * 4)(*body.layers)
-        dWs = [torch.empty_like(c.weight) if c.weight.requires_grad else None for c, _ in convs]
+        # every trainable conv's dW is a view of ONE zero-filled flat buffer: jobs that the batched launch splits along M accumulate
+        # with atomics into zeros, and one fill replaces ~85 per-job fills per step (td_resnet_bwd: dW_prezeroed)
+        sizes = [c.weight.numel() if c.weight.requires_grad else 0 for c, _ in convs]
+        offs_ = [0]
+        for n_ in sizes:
+            offs_.append(offs_[-1] + (n_ + 63) // 64 * 64)
+        flat = torch.zeros(offs_[-1], dtype=torch.float32, device=dfeat.device)
+        dWs = [flat[o : o + n_].view_as(c.weight) if n_ else None for (c, _), n_, o in zip(convs, sizes, offs_)]
         nbytes = L.td_resnet_bwd_ws_bytes(N, H, W, nb, first_stage, code)
         bws = torch.empty(nbytes, dtype=torch.uint8, device=dfeat.device)
         from .. import ops
@@ -294,7 +301,7 @@ class ResNetTrunkFn(Function):
         th, td_, done = ops.job_tables.take(tbytes, dfeat.device)  # weight-gradient job table: caller-owned staging
         _hip.check(L.td_resnet_bwd(dfeat.contiguous().data_ptr(), N, N_fwd, H, W, nb, first_stage, _ptr_array([p[1] for p in preps]),
                                    _ptr_array([p[3] for p in preps]), _ptr_array(dWs), ws.data_ptr(), bws.data_ptr(), nbytes,
-                                   th.data_ptr(), td_.data_ptr(), tbytes, code, _hip.stream_ptr()), "td_resnet_bwd")
+                                   th.data_ptr(), td_.data_ptr(), tbytes, 1, code, _hip.stream_ptr()), "td_resnet_bwd")
         done()
         ctx.ws = ctx.preps = None
         by_id = {id(c.weight): g for (c, _), g in zip(convs, dWs)}
