@@ -114,6 +114,13 @@ class ResNetBody(nn.Module):
         feat, rest = self.forward_split(x, compute_dtype, n_grad)
         return feat if rest.shape[0] == 0 else torch.cat([feat, rest])  # (callers that want both parts use forward_split: no copy)
 
+    @staticmethod
+    def max_frames(H: int, W: int, dt: torch.dtype) -> int:
+        """Frames one trunk pass can address: every activation goes through a 32-bit buffer descriptor (< 2^31 elements and < 4 GiB
+        per tensor) and the largest one has 16 * H * W elements per frame (stem output / layer1 output)."""
+        n = max(1, int(min(2**31 - 1, (2**32 - 4096) // dt.itemsize) // (16 * H * W)))
+        return int(os.environ.get("TD_TRUNK_MAX_FRAMES", n))  # (tests lower it to exercise the chunking on small frames)
+
     def forward_split(self, x, compute_dtype: torch.dtype, n_grad=None):
         """-> (features of the first n_grad frames, differentiable; features of the remaining frames, not differentiable): two views
         of the pass's own workspace.  One tensor sliced afterwards would make autograd zero-fill and copy a full-size gradient
@@ -228,9 +235,7 @@ class ResNetTrunkFn(Function):
         # The largest one has 16 * H * W elements per frame (stem output / layer1 output).  A no-grad pass over more frames than
         # that (eval / the fast frames of a large fp32 batch) is cut into equal chunks; a pass that keeps its activations
         # for backward is not (its backward walks ONE workspace): the C library reports the limit.
-        per_frame = 16 * H * W
-        n_max = max(1, int(min(2**31 - 1, (2**32 - 4096) // dt.itemsize) // per_frame))
-        n_max = int(os.environ.get("TD_TRUNK_MAX_FRAMES", n_max))  # (tests lower it to exercise the chunking on small frames)
+        n_max = ResNetBody.max_frames(H, W, dt)
         n_chunks = 1 if save else -(-N // n_max)
         if n_chunks > 1:
             step_n = -(-N // n_chunks)

@@ -167,6 +167,12 @@ class TubeDETR(nn.Module):
         # sine encoding: the transformer forms the positional operand from the (original) pad mask itself, see Joiner.forward
         want_pos = not self._sine_pos
         merged = self.fast and samples_fast is not None and torch.is_grad_enabled() and samples_fast.tensors.shape[1:] == samples.tensors.shape[1:]
+        if merged:
+            # one pass holds at most ResNetBody.max_frames frames (32-bit tensor addressing: 1 083 bf16 frames at res 352); a larger
+            # batch runs the slow frames (kept for backward) and the no-grad fast frames (cut into equal chunks) as separate passes
+            body = self.backbone[0].body
+            limit = body.max_frames(samples.tensors.shape[-2], samples.tensors.shape[-1], self.compute_dtype)
+            merged = samples.tensors.shape[0] + samples_fast.tensors.shape[0] <= limit
         if merged and self.slow_frames_are_strided_fast and sum(durations) == samples_fast.tensors.shape[0]:
             # one trunk pass over the fast frames, permuted so that the slow (= every k-th) frames come first
             n_slow = samples.tensors.shape[0]
