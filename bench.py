@@ -10,10 +10,12 @@ Workload at N=1: BASELINE.json configs[2] (the config the metric is quoted on): 
 L=30 text tokens, bf16 MFMA kernels with fp32 accumulation, random-init weights, train mode (dropout active),
 weights re-prepared every step (as after an optimizer step), all 125 trunk-forward frames of every clip executed
 (`--dedupe` skips the 25 slow frames inside the fast pass).  `--clips-per-gpu B` videos per GPU per step (the
-reference's --batch_size, main.py:63; default 8: 288 GB of HBM hold the 100 GB of activations of 8 clips, and every
-latency-bound launch of the step - the 100-row decoder, RoBERTa on 30 tokens, the 12 100-row trunk backward - then does B
-times the work; measured 42.9 / 55.8 / 67.6 / 73.0 clips/s at B = 1 / 2 / 4 / 8): `value` counts clips, not steps.  Inputs
-are generated on the device before the timed region.
+reference's --batch_size, main.py:63; default 16: 288 GB of HBM hold the 111 GB this batch needs, and every latency-bound
+launch of the step - the 100-row-per-clip decoder, RoBERTa on 30 tokens per clip, the 12 100-row trunk backward - then does B
+times the work; measured in round 3: 86.9 / 87.2 / 91.4 clips/s at B = 8 / 12 / 16, profiles/README.md): `value` counts
+clips, not steps.  Up to B = 8 the slow and the fast frames of a step share ONE trunk pass (1 000 frames); beyond that a pass
+would exceed the kernels' 32-bit tensor addressing (1 083 bf16 frames of res 352) and the slow frames (kept for backward) and
+the no-grad fast frames (two chunks of 800) run as separate passes.  Inputs are generated on the device before the timed region.
 
 Execution: the step is captured once in HIP graph(s) and replayed (`--no-graph`: eager launches; GPU-bound too from B = 4 on).
   N = 1 : one graph, RoBERTa on a forked branch (its 120-row GEMMs overlap the trunk; `--no-text-stream`: linear graph).
@@ -62,7 +64,7 @@ PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 # algorithmic TFLOP per clip fwd+bwd
 ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
-DEFAULT_CLIPS_PER_GPU = 8
+DEFAULT_CLIPS_PER_GPU = 16
 PMC_TRAFFIC = "r02_pmc_traffic.json"
 PMC_MFMA = "r02_pmc_mfma.json"
 

@@ -11,8 +11,8 @@
     norm within 15 % (measured worst cases recorded in the report; parameters whose gradient norm is below a quarter of the
     median one are judged on the absolute scale: error <= 5 % of the median norm).
 (3) exact-fp32 mode BACKWARD against the oracle's autograd at full size (cfg2, cfg1): every trainable parameter's gradient.
-(4) the BENCHMARKED batch: 8 clips per step at cfg3 (bench.py's default), fp32 forward against the oracle run per clip
-    (videos are independent: batch statistics do not exist in the model, FrozenBN), and the bf16 step at 8 clips - forward
+(4) the BENCHMARKED batch: 16 clips per step at cfg3 (bench.py's default), fp32 forward against the oracle run per clip
+    (videos are independent: batch statistics do not exist in the model, FrozenBN), and the bf16 step at 16 clips - forward
     and backward, the instances that carry the throughput number (256-row tiles, persistent / chained pointwise kernels,
     wide-tile weight gradients, lean attention) - against the exact-fp32 mode run clip by clip.
 This exercises, under an oracle, exactly what `bench.py` launches: td_resnet_fwd over 125 frames with the save layout,
@@ -266,10 +266,16 @@ def test_fp32_gradients_match_oracle_at_full_size(name):
     assert not bad, bad[:10]
 
 
-# ---- (4) the benchmarked batch: 8 clips per step ----------------------------------------------------------------------
-BENCH_CLIPS = 8
+# ---- (4) the benchmarked batch: 16 clips per step ---------------------------------------------------------------------
+BENCH_CLIPS = 16  # bench.py's DEFAULT_CLIPS_PER_GPU (asserted below)
 BENCH_SEEDS = [CLIP_SEED, CLIP_SEED + 1, CLIP_SEED + 2, CLIP_SEED + 3]
-BENCH_PATTERN = [0, 1, 2, 3, 3, 1, 0, 2]  # which distinct clip sits at each of the 8 batch positions (neighbours always differ)
+BENCH_PATTERN = [0, 1, 2, 3, 3, 1, 0, 2, 1, 3, 0, 2, 2, 0, 3, 1]  # which distinct clip sits at each batch position (neighbours always differ)
+
+
+def test_bench_clip_count_is_the_one_tested_here():
+    import bench
+
+    assert bench.DEFAULT_CLIPS_PER_GPU == BENCH_CLIPS == len(BENCH_PATTERN)
 
 
 def _stitch(batches):
@@ -286,8 +292,8 @@ def _per_clip(x, n):
 
 
 def test_bench_batch_fp32_forward_matches_oracle_per_clip():
-    """bench.py's workload (8 clips of cfg3 per step: a 1 000-frame trunk pass, M = 484 000 / 7 744 000-row GEMMs) in the
-    exact-fp32 mode against the oracle's forward of each clip."""
+    """bench.py's workload (16 clips of cfg3 per step: a 400-frame slow pass kept for backward + 1 600 no-grad fast frames in chunks,
+    M up to 6 195 200-row GEMMs) in the exact-fp32 mode against the oracle's forward of each clip."""
     from tubedetr_amd.harness import batch_to, forward_step
 
     c = FULL["cfg3"]
@@ -326,16 +332,18 @@ def test_bench_batch_fp32_forward_matches_oracle_per_clip():
         worst = max(worst, rel)
         assert rel < 1e-3, (k_, ld[k_].item(), want)
     rec["max_rel_err_losses"] = worst
-    _report("fp32_vs_oracle/cfg3_x8_clips", rec)
+    _report(f"fp32_vs_oracle/cfg3_x{BENCH_CLIPS}_clips", rec)
 
 
-def test_bench_batch_bf16_step_follows_fp32_per_clip():
-    """The benchmarked step itself - bf16, 8 clips, forward + backward - against the exact-fp32 mode run clip by clip (the
-    fp32 activations of 8 clips do not fit next to each other; the batch gradient is the mean of the per-clip gradients:
+@pytest.mark.parametrize("n_clips", [BENCH_CLIPS, 8])  # 16: the benchmark's batch (separate slow / fast trunk passes); 8: the largest batch whose
+def test_bench_batch_bf16_step_follows_fp32_per_clip(n_clips):  # frames still share ONE 1 000-frame trunk pass (forward_split at full scale)
+    """The benchmarked step itself - bf16, 16 clips, forward + backward - against the exact-fp32 mode run clip by clip (the
+    fp32 activations of 16 clips do not fit next to each other; the batch gradient is the mean of the per-clip gradients:
     every loss is normalised by the batch's box / video count)."""
     from tubedetr_amd.harness import batch_to, forward_step
 
     c = FULL["cfg3"]
+    pattern = BENCH_PATTERN[:n_clips]
     dev = torch.device("cuda:0")
     singles = [_inputs(c, s_) for s_ in BENCH_SEEDS]
     cfg, sd = singles[0][0], singles[0][1]
@@ -343,7 +351,7 @@ def test_bench_batch_bf16_step_follows_fp32_per_clip():
     model, criterion, weight_dict, Tok = _model(cfg, sd, torch.float32)
     names = [n for n, p in model.named_parameters() if p.requires_grad]
     params = [p for p in model.parameters() if p.requires_grad]
-    weight = [BENCH_PATTERN.count(i) / BENCH_CLIPS for i in range(len(BENCH_SEEDS))]
+    weight = [pattern.count(i) / n_clips for i in range(len(BENCH_SEEDS))]
     g32 = [None] * len(params)
     l32 = 0.0
     logits32 = {}
@@ -362,7 +370,7 @@ def test_bench_batch_bf16_step_follows_fp32_per_clip():
         p.grad = None
     del loss, out
     torch.cuda.empty_cache()
-    batch = _stitch([singles[i][2] for i in BENCH_PATTERN])
+    batch = _stitch([singles[i][2] for i in pattern])
     model.set_compute_dtype(torch.bfloat16)
     model.transformer.tokenizer = Tok(batch["input_ids"], batch["attention_mask"])
     loss, _, out, _ = forward_step(model, criterion, weight_dict, batch_to(batch, dev))
@@ -370,10 +378,10 @@ def test_bench_batch_bf16_step_follows_fp32_per_clip():
     torch.cuda.synchronize()
     l16 = loss.item()
     g16 = [None if p.grad is None else p.grad.detach() for p in params]
-    box16, sted16 = _per_clip(out["pred_boxes"].float(), BENCH_CLIPS), _per_clip(out["pred_sted"].float(), BENCH_CLIPS)
-    rec = {"clips": BENCH_CLIPS, "loss_fp32_per_clip_mean": l32, "loss_bf16": l16, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
-    rec["box_err"] = max((box16[pos] - logits32[ci][0].reshape(box16[pos].shape)).abs().max().item() for pos, ci in enumerate(BENCH_PATTERN))
-    rec["sted_err"] = max((sted16[pos] - logits32[ci][1].reshape(sted16[pos].shape)).abs().max().item() for pos, ci in enumerate(BENCH_PATTERN))
+    box16, sted16 = _per_clip(out["pred_boxes"].float(), n_clips), _per_clip(out["pred_sted"].float(), n_clips)
+    rec = {"clips": n_clips, "loss_fp32_per_clip_mean": l32, "loss_bf16": l16, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+    rec["box_err"] = max((box16[pos] - logits32[ci][0].reshape(box16[pos].shape)).abs().max().item() for pos, ci in enumerate(pattern))
+    rec["sted_err"] = max((sted16[pos] - logits32[ci][1].reshape(sted16[pos].shape)).abs().max().item() for pos, ci in enumerate(pattern))
     smax = max(v[1].abs().max().item() for v in logits32.values())
     assert rec["box_err"] < 0.05 and rec["sted_err"] < 0.1 * max(1.0, smax), rec
     assert abs(l16 - l32) < 0.02 * abs(l32), rec
@@ -400,7 +408,7 @@ def test_bench_batch_bf16_step_follows_fp32_per_clip():
     rec["min_cosine"] = stats[0][1]
     rec["max_abs_norm_ratio_err"] = max(abs(s_[2]) for s_ in stats)
     rec["worst_cosine"] = [(s_[0], round(s_[1], 5), round(s_[2], 4), f"{s_[4]:.3e}") for s_ in stats[:8]]
-    _report("bf16_vs_fp32/cfg3_x8_clips", rec)
+    _report(f"bf16_vs_fp32/cfg3_x{n_clips}_clips", rec)
     assert len(stats) > 300
     # same bounds as the one-clip comparison above (test_bf16_gradients_follow_fp32_mode_at_full_size)
     assert rec["global_cosine"] >= 0.995 and abs(rec["global_norm_ratio"] - 1.0) <= 0.03, rec
