@@ -19,7 +19,8 @@ the no-grad fast frames (two chunks of 800) run as separate passes.  Inputs are 
 
 Execution: the step is captured once in HIP graph(s) and replayed (`--no-graph`: eager launches; GPU-bound too from B = 4 on).
   N = 1 : one graph, RoBERTa on a forked branch (its 120-row GEMMs overlap the trunk; `--no-text-stream`: linear graph).
-  N > 1 : the step is cut at the ResNet trunk boundary (harness.backward_in_stages) and captured as TWO graphs; the
+  N > 1 : the step is cut at the ResNet trunk boundary (harness.backward_in_stages) and captured as TWO graphs (RoBERTa
+          still on a forked branch of the first); the
           all-reduce of the gradients that are final after the first one (heads, decoder, encoder, RoBERTa, input_proj:
           0.57 of 0.74 GB) is started between the two replays and overlaps the trunk backward, the trunk's own 0.17 GB
           follow (tubedetr_amd/distributed.py).  `--no-overlap`: one graph + one flat all-reduce after it; `--ddp`: torch
@@ -224,9 +225,9 @@ def main():
                 return
             print(f"[bench] child {extra} failed with exit code {r.returncode}; retrying", file=sys.stderr, flush=True)
         raise SystemExit("bench: every attempt failed")
-    a.text_stream = a.graph and world == 1 and not a.force_ddp and not a.no_text_stream
+    a.text_stream = a.graph and not a.no_text_stream and not a.ddp
     if a.graph and not a.text_stream:
-        os.environ.setdefault("TD_TEXT_STREAM", "0")  # single-stream capture (the N > 1 staged two-graph mode is built on it)
+        os.environ.setdefault("TD_TEXT_STREAM", "0")  # single-stream capture: RoBERTa stays on the main stream
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
@@ -385,7 +386,8 @@ def main():
                     reducer.all_reduce()  # the only collective of the step, outside the graph
                 return static_loss
 
-            execution = ("hip_graph (text encoder on a forked branch)" if a.text_stream else "hip_graph (linear)") if not staged else "2 hip_graphs (cut at the trunk boundary, exchange overlapped)"
+            execution = ("hip_graph (text encoder on a forked branch)" if a.text_stream else "hip_graph (linear)") if not staged else \
+                ("2 hip_graphs (cut at the trunk boundary, exchange overlapped" + ("; text encoder on a forked branch of the first)" if a.text_stream else ")"))
         except Exception as exc:  # capture not possible: measure the eager path
             ops_.set_dropout_counter(None)
             torch.cuda.synchronize()

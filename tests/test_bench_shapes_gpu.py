@@ -7,6 +7,7 @@ evaluation of the same op on the same bf16-rounded operands:
   pw_resident_kernel                layer3 conv3      M = 484 000, N = 1024, K = 256      + residual + ReLU
   pw_resident_kernel                layer1 conv3      M = 7 744 000, N = 256, K = 64      + residual + ReLU
   pw_chain_kernel                   layer1 conv3 -> next conv1, M = 7 744 000
+  conv_gemm_big_kernel / conv_gemm_kernel (tap-uniform)  the stride-2 layers of a stage's first block (3x3 and the 1x1 downsample)
   conv_wgrad_wide_batch_kernel      the trunk's batched weight-gradient table at 200 slow frames (one job per layer shape)
 
 The forward-type results are compared on sampled row ranges (first / middle / last rows of the launch: tile 0, an interior
@@ -70,6 +71,27 @@ def test_layer3_conv3x3_forward_and_dgrad_at_bench_shape():
     gs = gy[fr].float().permute(0, 3, 1, 2)
     ref = F.conv_transpose2d(gs, w, padding=1).permute(0, 2, 3, 1) * (act[fr].float() > 0)
     assert rel_err(dx[fr].float(), ref) < TOL
+
+
+@pytest.mark.parametrize("shape", [("layer3.0 downsample (strided 1x1 on the 256-row tiles)", 44, 512, 1024, 1), ("layer2.0 downsample (strided 1x1, short K)", 88, 256, 512, 1),
+                                   ("layer3.0 conv2 (strided 3x3 on the 256-row tiles)", 44, 256, 256, 3)])
+def test_stage_entry_strided_layers_at_bench_shape(shape):
+    from tubedetr_amd import ops
+
+    _, HW, C, Nc, ksz = shape
+    g = torch.Generator(device=dev()).manual_seed(11)
+    N = FRAMES_FWD
+    x = _rand((N, HW, HW, C), g, relu=True)
+    w = (torch.randn(Nc, C, ksz, ksz, generator=g, device=dev()) / math.sqrt(ksz * ksz * C)).to(torch.bfloat16).float()
+    bias = torch.randn(Nc, generator=g, device=dev())
+    wf, _, b_out, _ = ops.weight_prep(w, torch.bfloat16, bias=bias)
+    y = ops.conv_fwd(x, wf, b_out, ksz, ksz, 2, ksz // 2, relu=ksz == 3)
+    assert y.shape == (N, HW // 2, HW // 2, Nc)
+    fr = _frames_sample(N)
+    ref = F.conv2d(x[fr].float().permute(0, 3, 1, 2), w, bias, stride=2, padding=ksz // 2).permute(0, 2, 3, 1)
+    if ksz == 3:
+        ref = ref.relu()
+    assert rel_err(y[fr].float(), ref) < TOL, shape[0]
 
 
 @pytest.mark.parametrize("shape", [("layer3.conv1 (256-row tiles)", 484000, 1024, 256, False), ("layer3.conv3 (persistent)", 484000, 256, 1024, True),

@@ -176,7 +176,8 @@ def test_world_size_2_real_model_one_gpu(tmp_path):
     assert int(n) > 300 and float(worst) < 1.0, (worst, n)  # every |got - mean| <= 1e-4 * max|mean| + 1e-6
 
 
-def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step():
+@pytest.mark.parametrize("text_stream", ["0", "1"])  # "1": RoBERTa on a forked branch inside the first graph (bench.py's N > 1 default)
+def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step(text_stream):
     """The N>1 execution bench.py uses: the step is cut at the trunk boundary and captured as TWO HIP graphs (forward +
     first backward stage + gather of the early gradients | trunk backward + gather of the trunk's gradients); the
     all-reduce of the early 0.57 GB is launched between the two replays and overlaps the trunk backward.  With a 1-rank
@@ -190,7 +191,7 @@ def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
     dev = torch.device("cuda:0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    os.environ["TD_TEXT_STREAM"] = "0"
+    os.environ["TD_TEXT_STREAM"] = text_stream
     try:
         model, criterion, weight_dict = _small_model(torch.bfloat16)
         batch = _clip(4)
@@ -251,13 +252,14 @@ def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        from tubedetr_amd import ops as _ops
+
+        _ops.reset_capture_arena()
         with torch.cuda.graph(g1, capture_error_mode="thread_local"):
             invalidate_prepared()
             l_, _, _, _ = forward_step(model, criterion, weight_dict, batch)
             l_.backward()
             reducer2.gather_stage(early=True)
-        from tubedetr_amd import ops as _ops
-
         _ops.reset_capture_arena()  # (two captures back to back: the second graph gets zero-fill nodes of its own)
         with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
             model.backbone[0].body.backward_trunk()

@@ -30,7 +30,7 @@ def family(name):
     m = re.search(r"td::conv_gemm_big_kernel<\d+, (true|false)>", name)
     if m:  # the 256-row tile kernel on spatial (3x3, MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers
         return f"td::conv_gemm_big_kernel<*, {m.group(1)}>"
-    if "td::stem_pool_kernel" in name or "td::bottleneck_fused_kernel" in name:
+    if "td::stem_pool_kernel" in name or "td::bottleneck_fused_kernel" in name or "td::bottleneck_resident_kernel" in name:
         return "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>"
     if "td::conv_wgrad_wide_batch_kernel" in name or "td::conv_wgrad_batch_kernel" in name:
         return "td::conv_wgrad_*batch_kernel"

@@ -1858,7 +1858,9 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   // tap-uniform addressing (see conv_gemm_kernel): spatial convs whose channel count is a multiple of the K tile
   static const int tu_on = [] { const char* e_ = getenv("TD_CONV_TAP_UNIFORM"); return e_ ? atoi(e_) : 1; }();
   const int bk = dtype == TD_BF16 ? 64 : 32;
-  const bool tu = tu_on && !pw && !d->aniso && d->R * d->S > 1 && d->R * d->S <= 32 && d->C % bk == 0 && p.d.out_sp == 1 && (d->mode == 0 || d->stride == 1);
+  // (a strided 1x1 - the downsample branch of a stage's first block - is the one-tap case of the same addressing)
+  const bool tu = tu_on && !pw && !d->aniso && (d->R * d->S > 1 || (d->stride > 1 && d->mode == 0)) && d->R * d->S <= 32 && d->C % bk == 0 && p.d.out_sp == 1 &&
+                  (d->mode == 0 || d->stride == 1);
   {
     // 256-row tiles (conv_gemm_big_kernel): MFMA-bound bf16 layers with enough workgroups to matter
     static const int big_on = [] { const char* e_ = getenv("TD_CONV_BIG"); return e_ ? atoi(e_) : 1; }();
