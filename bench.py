@@ -225,6 +225,12 @@ def main():
                 return
             print(f"[bench] child {extra} failed with exit code {r.returncode}; retrying", file=sys.stderr, flush=True)
         raise SystemExit("bench: every attempt failed")
+    # The process's stdout carries exactly ONE line, the JSON: native libraries write there too (RCCL prints a version banner
+    # through C stdio when the first communicator is created), so file descriptor 1 is pointed at stderr for the whole run
+    # and the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     a.text_stream = a.graph and not a.no_text_stream and not a.ddp
     if a.graph and not a.text_stream:
         os.environ.setdefault("TD_TEXT_STREAM", "0")  # single-stream capture: RoBERTa stays on the main stream
@@ -508,7 +514,8 @@ def main():
             "step_frac_of_mfma_peak": round(step_tflop * value / world / PEAK_BF16_TFLOPS, 4) if (step_tflop and a.dtype == "bf16") else None,
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or a.force_ddp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -372,6 +372,26 @@ def test_pointwise_persistent_instance_matches_tiled_math(cfg):
         assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("cfg", [(21, 90, 90, 256, 512, 2), (5, 181, 179, 128, 256, 2), (40, 45, 47, 512, 1024, 2), (12, 61, 64, 1024, 256, 2), (9, 100, 100, 64, 128, 3)])
+def test_strided_pointwise_conv_on_every_route(cfg):
+    """A 1x1 convolution with stride > 1 (the downsample branch of a stage's first block) in bf16: short K and many rows take the
+    persistent instance (source pixel derived per row), K >= 512 the 256-row tiles through the one-tap form of the tap-uniform
+    addressing, the rest the tiled kernel; odd extents (the last row / column is never read), ragged last tiles."""
+    from tubedetr_amd import ops
+
+    N, H, W, C, Co, st = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, H, W, C, generator=g).to(dev(), dt)
+    w = (torch.randn(Co, C, 1, 1, generator=g) / math.sqrt(C)).to(dt).float().to(dev())
+    b = torch.randn(Co, generator=g).to(dev())
+    wf, _, b_out, _ = ops.weight_prep(w, dt, bias=b)
+    y = ops.conv_fwd(x, wf, b_out, 1, 1, st, 0)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, b, stride=st).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < TOL[dt]
+
+
 @pytest.mark.parametrize("cfg", [(41000, 512, 256, True, False, True), (41003, 1024, 128, False, True, False), (61000, 2048, 512, True, True, False),
                                  (41000, 576, 256, False, False, True)])
 def test_pointwise_256_row_tiles(cfg):

@@ -856,14 +856,29 @@ __global__ __launch_bounds__(256, 2) void pw_resident_kernel(GemmParams p, int M
   const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const int n0 = nt * 128;
+  // source row of output row m: m itself, or - strided 1x1 (the downsample branch of a stage's first block, forward) - the
+  // pixel (ho * stride, wo * stride) of its image
+  const int HoWo = d.Ho * d.Wo;
+  const bool strided = d.stride != 1;
   auto issue_A = [&](char* buf, int mt) {
     const int m0 = mt * 64;
+    uint32_t row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + (i * 4 + wave) * 8 + lrow;
+      int src_row = m;
+      if (strided) {
+        const int img = m / HoWo, rem = m - img * HoWo;
+        const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+        src_row = (img * d.Hs + ho * d.stride) * d.Ws + wo * d.stride;
+      }
+      row[i] = (mt < MT && m < p.M) ? (uint32_t)src_row * (uint32_t)p.K * ES : OOB;
+    }
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (i * 4 + wave) * 8 + lrow;
-        const uint32_t off = (mt < MT && m < p.M) ? ((uint32_t)m * (uint32_t)p.K + (uint32_t)(kt * 64 + chunk * 8)) * ES : OOB;
+        const uint32_t off = row[i] != OOB ? row[i] + (uint32_t)(kt * 64 + chunk * 8) * ES : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(buf + kt * 8192 + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
       }
   };
@@ -1809,7 +1824,10 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       return cus;
     }();
-    const bool pw0 = d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && p.d.out_sp == 1 && d->Hs == d->Ho && d->Ws == d->Wo;
+    // dense rows, or the strided 1x1 of a downsample branch in forward geometry (the kernel derives the source pixel per row)
+    const bool pw0 = d->R == 1 && d->S == 1 && d->pad == 0 && p.d.out_sp == 1 && !d->aniso &&
+                     ((d->stride == 1 && d->Hs == d->Ho && d->Ws == d->Wo) ||
+                      (d->stride > 1 && d->mode == 0 && (d->Ho - 1) * d->stride < d->Hs && (d->Wo - 1) * d->stride < d->Ws));
     const int NTp = d->Nc / 128, Pp = 2 * n_cu / 8;
     const bool shape_ok = pw0 && dtype == TD_BF16 && p.K % 64 == 0 && p.K <= 256 && d->Nc % 128 == 0 &&
                           (NTp == 1 || NTp == 2 || NTp == 4 || NTp == 8 || NTp == 16) && Pp >= NTp && d->ldc % 8 == 0 && !p.sigmoid &&
