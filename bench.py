@@ -443,9 +443,10 @@ def main():
             fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128, *, *>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128, *, *>",
                     1: f"td::conv_gemm_kernel<{tname}, 128, 64, *, *>", 2: "td::conv_wgrad_*batch_kernel", 4: "td::pw_resident_kernel<*>",
                     5: "td::conv_gemm_big_kernel<*, true>", 6: "td::conv_gemm_big_kernel<*, false>",
-                    7: "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>"}
+                    7: "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>", 8: "td::cross_q1_*_kernel"}
             # * = all pipeline depths, pointwise and generic instances; 2 = wide-tile + 128x128 batched weight-gradient launches; 5 / 6 = the 256-row
-            # tile kernel on spatial (MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers; 7 = the LDS-resident fused stem / layer1 blocks
+            # tile kernel on spatial (MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers; 7 = the LDS-resident fused stem / layer1 blocks;
+            # 8 = the decoder's time-aligned cross-attention frame core (fp32 VALU arithmetic: its FLOPs are not MFMA FLOPs, bound = HBM)
             pmc, mfma = _load_profile_json(PMC_TRAFFIC), _load_profile_json(PMC_MFMA)
             # an (event, event) pair around nothing: what the bracketing itself adds to every launch (reported, NOT subtracted)
             cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]

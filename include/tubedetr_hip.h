@@ -52,7 +52,8 @@ int td_abi_version(void);
 #define TD_PROF_GEMM_256 5    /* 256-row tiles, eight wavefronts (conv_gemm_big_kernel), spatial (3x3) layers: the MFMA-bound members */
 #define TD_PROF_GEMM_256_PW 6 /* the same kernel on pointwise layers with K >= 512: HBM-bound (4.2 TB/s of algorithmic bytes) */
 #define TD_PROF_FUSED 7       /* LDS-resident chains: fused stem (stem.hip), fused frozen bottlenecks (bottleneck.hip) */
-#define TD_PROF_FAMILIES 8
+#define TD_PROF_CROSS_Q1 8    /* time-aligned cross-attention frame core (cross_attn.hip): HBM-bound by the memory rows */
+#define TD_PROF_FAMILIES 9
 int td_prof_enable(int on);
 int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
 /* Sum of the ALGORITHMIC HBM bytes of the same launches (each operand / result tensor counted once per launch). */
@@ -340,6 +341,33 @@ int td_mha_bwd(const void* q, const void* k, const void* v, const void* dout, co
                void* dq, void* dk, void* dv, float* ds_ws, int B, int H, int Lq, int Lk, int hd, int ldq, int ldk,
                int ldv, int ldo, float scale, float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter,
                int dtype, td_stream_t stream);
+
+/* Time-aligned cross-attention of the decoder (models/transformer.py:725-745; nn.MultiheadAttention with ONE query per
+ * frame, E = 256 channels in H = 8 heads) with both memory-side projections moved to the query side:
+ *   score[h][s] = u[f][h] . (mem[f*S+s] + pos[f*S+s])      u[f][h] = scale * W_k,h^T q[f],  q.b_k is constant over s and cancels
+ *   out[f]      = W_v,blk zext[f],  zext[f] = [ z[f][0..H) | sum_s pd[f][h][s] ],  z[f][h] = sum_s pd[f][h][s] mem[f*S+s]
+ * (pd = probabilities after dropout; same mask index and the same `probs` / `wavg` outputs as td_mha_fwd with Lq = 1).  The key
+ * and value projections of the memory rows, 93 % of the decoder's FLOPs in the reference formulation, do not exist; the two
+ * remaining products with W_k / W_v are GEMMs over the F query rows against the block-structured weights below.
+ * u [F][H*E] T, mem / pos [F*S][E] T (pos may be NULL), key_pad [F][S] uint8 or NULL, probs [F][H][S] fp32, wavg [F][S] fp32 or
+ * NULL, zext [F][ldz] T with ldz >= H*E + H (a multiple of 8). */
+int td_cross_q1_fwd(const void* u, const void* mem, const void* pos, const uint8_t* key_pad, float* probs, float* wavg, void* zext,
+                    int F, int S, int H, int E, int ldz, float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter,
+                    int dtype, td_stream_t stream);
+/* Backward: d_zext [F][ldz] T, dwavg [F][S] fp32 or NULL  ->  d_u [F][H*E] T and d_mem [F*S][E] FP32, overwritten when
+ * accumulate == 0, else added to (the memory is shared by the six layers: the first layer to run writes, the others add).
+ * pos receives no gradient here (sine encodings; learned ones use the projected-memory path). */
+int td_cross_q1_bwd(const void* u, const void* mem, const void* pos, const float* probs, const void* d_zext, const float* dwavg,
+                    void* d_u, float* d_mem, int accumulate, int F, int S, int H, int E, int ldz, float dropout_p, uint32_t dropout_seed,
+                    const uint32_t* dropout_counter, int dtype, td_stream_t stream);
+/* Block-structured forms of one [E][E] slice of nn.MultiheadAttention.in_proj_weight (fp32, [out][in]; out channel j belongs to
+ * head j / (E/H)) for those GEMMs: w_n [E][H*E + nb] holds W[j][:] * alpha in column block head(j) of row j (zeros elsewhere)
+ * and, if bias != NULL (nb = H, else 0), bias[j] in column H*E + head(j); w_t [H*E + nb][E] is its transpose.  Both in `dtype`.
+ *   keys:   u = q w_t^T (alpha = 1/sqrt(E/H)),  d_q = d_u w_n^T          values: out = zext w_n^T,  d_zext = d_out w_t^T */
+int td_head_blocks_expand(const float* W, const float* bias, float alpha, void* w_n, void* w_t, int E, int H, int dtype, td_stream_t stream);
+/* ...and back: from the dense fp32 gradient G [E][H*E + nb] of w_n, dW[j][c] = G[j][head(j)*E + c] * alpha and (db != NULL: nb = H)
+ * db[j] = G[j][H*E + head(j)]. */
+int td_head_blocks_extract(const float* G, float alpha, float* dW, float* db, int E, int H, td_stream_t stream);
 
 /* Lean form of the same attention core for callers that do not need the weights (the per-frame visual-text encoder,
  * models/transformer.py:638-640: `weights` is dead there, SURVEY.md 8a'): nothing of size Lq x Lk is stored.  The forward

@@ -846,3 +846,107 @@ def test_replication_and_slow_fast_aggregation_match_indexing(dt):
     rep.backward(gy.to(dvc, dt))
     rep_ref.backward(gy)
     assert rel_err(m3.grad.float().cpu(), mr2.grad) < TOL[dt]
+
+
+def _torch_cross_attention(tgt, qpos, mem, pos, W_in, b_in, W_out, b_out, key_pad, F_, S, H):
+    """nn.MultiheadAttention's arithmetic for one query per frame (models/transformer.py:725-745), plain fp32 torch."""
+    E = tgt.shape[1]
+    hd = E // H
+    q = (tgt + qpos) @ W_in[:E].t() + b_in[:E]
+    k = ((mem + pos) @ W_in[E : 2 * E].t() + b_in[E : 2 * E]).view(F_, S, H, hd)
+    v = (mem @ W_in[2 * E :].t() + b_in[2 * E :]).view(F_, S, H, hd)
+    sc = torch.einsum("fhd,fshd->fhs", q.view(F_, H, hd) / math.sqrt(hd), k)
+    sc = sc.masked_fill(key_pad[:, None, :], float("-inf"))
+    pr = sc.softmax(-1)
+    ctxv = torch.einsum("fhs,fshd->fhd", pr, v).reshape(F_, E)
+    return ctxv @ W_out.t() + b_out, pr.mean(1).view(F_, 1, S)
+
+
+@pytest.mark.parametrize("cfg", [(40, 151), (7, 69), (3, 13), (130, 36)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_cross_attention_with_query_side_projections(cfg, dt):
+    """functional.CrossQ1Fn (the decoder's time-aligned cross-attention without key / value projections of the memory, csrc/cross_attn.hip)
+    against nn.MultiheadAttention's own formulation in fp32 torch: output, head-averaged weights, and the gradients of the query
+    input, the memory, and every parameter - with a loss on the weights too (the guided-attention term), key padding, three layers
+    sharing one memory (the d(memory) accumulation across layers)."""
+    from tubedetr_amd import functional as Fk
+
+    F_, S = cfg
+    E, H, nl = 256, 8, 3
+    g = torch.Generator().manual_seed(5 + S)
+    r = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).to(dt).float().to(dev())
+    tgt, qpos, mem, pos = r(F_, E), r(F_, E), r(F_ * S, E), r(F_ * S, E)
+    key_pad = (torch.rand(F_, S, generator=g) < 0.2).to(dev())
+    key_pad[:, 0] = False
+    params = [[r(3 * E, E, s=1 / 16), r(3 * E, s=0.5), r(E, E, s=1 / 16), r(E, s=0.5)] for _ in range(nl)]
+    wo, ww = r(nl, F_, E), r(nl, F_, 1, S)
+
+    def run(fn, leafs_dtype):
+        t_, m_ = tgt.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+        ps = [[p.clone().requires_grad_(True) for p in layer] for layer in params]
+        loss = fn(t_.to(leafs_dtype), m_.to(leafs_dtype), ps)
+        loss.backward()
+        return loss.detach(), [t_.grad, m_.grad] + [p.grad for layer in ps for p in layer]
+
+    mag = [0.0]  # sum of the magnitudes of the loss terms: what a relative bound on the (cancelling) sum refers to
+
+    def ref(t_, m_, ps):
+        loss = 0.0
+        x = t_
+        for l in range(nl):
+            o, w = _torch_cross_attention(x, qpos, m_.view(F_ * S, E), pos, *ps[l], key_pad, F_, S, H)
+            loss = loss + (o * wo[l]).sum() + (w * ww[l]).sum() * 30
+            mag[0] += ((o * wo[l]).abs().sum() + (w * ww[l]).abs().sum() * 30).item()
+            x = t_ + 0.1 * o  # the next layer's query depends on this layer's output
+        return loss
+
+    def new(t_, m_, ps):
+        loss = 0.0
+        anchor = Fk.cross_q1_memory(m_, pos.to(dt))
+        x = t_
+        for l in range(nl):
+            o, w = Fk.multihead_attention_q1(x, anchor, *ps[l], key_pad, F_, S, H, need_weights=True, q_pos=qpos.to(dt))
+            loss = loss + (o.float() * wo[l]).sum() + (w * ww[l]).sum() * 30
+            x = t_ + (0.1 * o.float()).to(dt)
+        return loss
+
+    l_ref, g_ref = run(ref, torch.float32)
+    l_new, g_new = run(new, dt)
+    tol = 2e-4 if dt == torch.float32 else 3e-2
+    assert abs(l_new - l_ref).item() <= (2e-5 if dt == torch.float32 else 2e-3) * mag[0]
+    names = ["tgt", "mem"] + [f"layer{l}.{n}" for l in range(nl) for n in ("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias")]
+    for n, a, b in zip(names, g_new, g_ref):
+        if n.endswith("in_proj_bias"):  # the key bias shifts every score of a row equally: zero gradient (fp32 noise in the reference)
+            assert a[E : 2 * E].abs().max().item() == 0.0 and b[E : 2 * E].abs().max().item() < 1e-3 * b.abs().max().item()
+        assert rel_err(a, b) < tol, n
+
+
+def test_cross_attention_query_side_draws_the_same_dropout_mask_as_the_projected_path():
+    """Same (seed, element index) dropout keys as td_mha_fwd with Lq = 1: with dropout on, the query-side formulation and the
+    projected-memory path (functional.MHAFn) agree on outputs, returned weights and gradients."""
+    from tubedetr_amd import functional as Fk
+
+    F_, S, E, H = 24, 151, 256, 8
+    dt = torch.float32
+    g = torch.Generator().manual_seed(11)
+    r = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).to(dev())
+    tgt, mem = r(F_, E), r(F_ * S, E)
+    W_in, b_in, W_out, b_out = r(3 * E, E, s=1 / 16), r(3 * E, s=0.5), r(E, E, s=1 / 16), r(E, s=0.5)
+    key_pad = (torch.rand(F_, S, generator=g) < 0.2).to(dev())
+    key_pad[:, 0] = False
+    wo, ww = r(F_, E), r(F_, 1, S)
+    res = []
+    for which in ("q1", "projected"):
+        torch.manual_seed(77)  # both paths draw their dropout seeds from the generator keyed by torch's seed
+        Fk._SEED_STATE["torch_seed"] = None
+        t_, m_ = tgt.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+        ps = [p.clone().requires_grad_(True) for p in (W_in, b_in, W_out, b_out)]
+        if which == "q1":
+            o, w = Fk.multihead_attention_q1(t_, Fk.cross_q1_memory(m_, None), *ps, key_pad, F_, S, H, need_weights=True, attn_dropout=0.3, training=True)
+        else:
+            o, w = Fk.multihead_attention(t_, m_, m_, *ps, key_pad, F_, 1, S, H, True, attn_dropout=0.3, training=True)
+        ((o * wo).sum() + (w * ww).sum() * 30).backward()
+        res.append([o.detach(), w.detach(), t_.grad, m_.grad] + [p.grad for p in ps])
+    assert (res[0][1] == 0).float().mean().item() < 0.35 and rel_err(res[0][1], res[1][1]) < 1e-4  # same dropped entries
+    for a, b in zip(res[0], res[1]):
+        assert rel_err(a, b) < 5e-4

@@ -32,6 +32,8 @@ def family(name):
         return f"td::conv_gemm_big_kernel<*, {m.group(1)}>"
     if "td::stem_pool_kernel" in name or "td::bottleneck_fused_kernel" in name or "td::bottleneck_resident_kernel" in name:
         return "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>"
+    if "td::cross_q1_" in name:
+        return "td::cross_q1_*_kernel"
     if "td::conv_wgrad_wide_batch_kernel" in name or "td::conv_wgrad_batch_kernel" in name:
         return "td::conv_wgrad_*batch_kernel"
     m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)
@@ -152,11 +154,14 @@ def mfma(src, dst, command=""):
 
         is_att = lambda r: re.search(r"td::mha_(fwd_mfma_kernel<\d+, false>|bwd_dq_mfma_kernel|bwd_dkv_mfma_kernel)", r["kernel"]) is not None
         is_kv = lambda r: bool(kv_grid) and "td::conv_gemm_kernel" in r["kernel"] and r["grid"] == kv_grid
+        is_q1 = lambda r: "td::cross_q1_" in r["kernel"]
         res["decoder_attention_group_precise"] = {
-            "definition": "decoder temporal self-attention + time-aligned cross-attention kernels (mha_*_mfma_kernel, probabilities-based instances) "
-                          "+ the hoisted key / value projection GEMMs (launches of td::conv_gemm_kernel with grid " + (kv_grid or "<TD_KV_GRID unset>") + ")",
-            "target": 0.40, "attention_kernels": util_rows(is_att), "kv_projections": util_rows(is_kv),
-            "group": util_rows(lambda r: is_att(r) or is_kv(r))}
+            "definition": "decoder temporal self-attention kernels (mha_*_mfma_kernel, probabilities-based instances) + the time-aligned cross-attention: "
+                          "its frame core td::cross_q1_*_kernel (key / value projections moved to the query side: the memory rows are not projected, "
+                          "the core is fp32 VALU arithmetic bound by the HBM read of the memory rows), or - TD_CROSS_Q1=0 - the hoisted key / value "
+                          "projection GEMMs (launches of td::conv_gemm_kernel with grid " + (kv_grid or "<TD_KV_GRID unset>") + ")",
+            "target": 0.40, "attention_kernels": util_rows(is_att), "cross_q1_frame_core": util_rows(is_q1), "kv_projections": util_rows(is_kv),
+            "group": util_rows(lambda r: is_att(r) or is_kv(r) or is_q1(r))}
     json.dump(res, open(dst, "w"), indent=1)
     for f, v in res.items():
         if isinstance(v, dict) and "mfma_util" in v:

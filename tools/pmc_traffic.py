@@ -18,6 +18,8 @@ def family(name):
         return f"td::conv_gemm_big_kernel<*, {m.group(1)}>"
     if "td::stem_pool_kernel" in name or "td::bottleneck_fused_kernel" in name or "td::bottleneck_resident_kernel" in name:
         return "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>"
+    if "td::cross_q1_" in name:
+        return "td::cross_q1_*_kernel"
     if "td::conv_wgrad_wide_batch_kernel" in name or "td::conv_wgrad_batch_kernel" in name:
         return "td::conv_wgrad_*batch_kernel"
     m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)

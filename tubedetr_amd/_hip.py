@@ -11,7 +11,7 @@ import os
 import torch
 
 TD_F32, TD_BF16 = 0, 1
-EXPECTED_ABI = 5  # td_abi_version() of the library these signatures were written against
+EXPECTED_ABI = 6  # td_abi_version() of the library these signatures were written against
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtubedetr_hip.so")
 _lib = None
 
@@ -110,6 +110,10 @@ _SIGS = {
     "td_adamw_ema_step": [_P, _P, _P, _P, _P, _SZ, C.POINTER(OptimSegment), _I, _P, _P, _P, _F, _F, _F, _F, _F, _P],
     "td_mha_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
     "td_mha_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
+    "td_cross_q1_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U32, _P, _I, _P],
+    "td_cross_q1_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _U32, _P, _I, _P],
+    "td_head_blocks_expand": [_P, _P, _F, _P, _P, _I, _I, _I, _P],
+    "td_head_blocks_extract": [_P, _F, _P, _P, _I, _I, _P],
     "td_mha_lean_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
     "td_mha_lean_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
 }

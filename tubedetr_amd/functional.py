@@ -636,6 +636,126 @@ class MHAPreKVFn(Function):
         return (d_q_in if ctx.needs_input_grad[0] else None, d_q_in if need_pos else None, None, None, dW_in, db_in, dW_out, db_out) + (None,) * 12
 
 
+class _CrossQ1Shared:
+    """What the six time-aligned cross-attention nodes share: the memory rows they all read and the ONE fp32 buffer their
+    backward kernels accumulate d(memory) in (first layer to run writes, the others add)."""
+
+    def __init__(self, mem, pos):
+        self.mem, self.pos = mem, pos
+        self.dmem = None
+
+
+class CrossMemFn(Function):
+    """Graph anchor of the decoder's shared memory for CrossQ1Fn: forward hands out an empty token the six layer nodes take as an
+    input (so this node runs after all of them), backward returns the d(memory) they accumulated in the shared buffer."""
+
+    @staticmethod
+    def forward(ctx, mem, shared):
+        ctx.shared = shared
+        ctx.set_materialize_grads(False)
+        return mem.new_empty(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        sh = ctx.shared
+        assert g is None, "the consumers of CrossMemFn hand their gradient over through the shared buffer"
+        if sh.dmem is None:
+            return None, None
+        d = sh.dmem if sh.mem.dtype == torch.float32 else ops.cast(sh.dmem, sh.mem.dtype)
+        sh.dmem = None
+        return d, None
+
+
+class CrossQ1Fn(Function):
+    """nn.MultiheadAttention of the decoder's time-aligned cross-attention (transformer.py:725-745: one query per frame, keys =
+    memory + pos, values = memory) with the key and value projections moved to the query side (csrc/cross_attn.hip):
+
+        q      = (tgt + query_pos) W_q^T + b_q                       [F, E]         (two operand streams, as in MHAFn)
+        u      = q Wk_blk^T,  u[f, h] = scale * W_k,h^T q[f, head h]   [F, H*E]       (block-structured W_k, td_head_blocks_expand)
+        probs, weights, zext = frame core(u, memory, pos, key padding)               (td_cross_q1_fwd; zext [F, H*E + H])
+        ctx    = zext Wv_blk^T = W_v,h z[f, h] + b_v,h sum_s pd                  [F, E]
+        out    = dropout(ctx W_o^T + b_o)
+
+    No key / value projection of the F*S memory rows exists in either direction.  The layer keeps ownership of its whole packed
+    in_proj gradient: rows [0, E) from the deferred batch, rows [E, 3E) from the diagonal blocks of two dense [E, H*E (+H)]
+    weight gradients (launched here: the extraction has to follow them); the key bias gets zeros (q . b_k shifts every score of
+    a row by the same amount)."""
+
+    @staticmethod
+    def forward(ctx, q_in, q_pos, token, W_in, b_in, W_out, b_out, key_pad, shared, F, S, H, need_w, p_attn, seed_attn, p_out, seed_out):
+        _note_use(ctx.needs_input_grad[3], W_in, b_in, W_out, b_out)
+        E = q_in.shape[1]
+        dt = q_in.dtype
+        scale = 1.0 / math.sqrt(E // H)
+        wq_f, wq_d, _, _ = prepared(W_in[:E], dt)
+        bq = b_in.detach()[:E]
+        q = ops.linear_ex(q_in, wq_f, bq, a2=q_pos, w_shared=True) if q_pos is not None else ops.linear_fwd(q_in, wq_f, bq)
+        Wd, bd = W_in.detach(), b_in.detach()
+        wk_n, wk_t = ops.head_blocks_expand(Wd[E : 2 * E], None, scale, H, dt)
+        wv_n, wv_t = ops.head_blocks_expand(Wd[2 * E :], bd[2 * E :], 1.0, H, dt)
+        u = ops.linear_fwd(q, wk_t)
+        probs, wavg, zext = ops.cross_q1_fwd(u, shared.mem, shared.pos, key_pad, F, S, H, need_wavg=need_w, dropout_p=p_attn, seed=seed_attn)
+        ctxv = ops.linear_fwd(zext, wv_n)
+        wo_f, wo_d, _, _ = prepared(W_out, dt)
+        out = ops.linear_fwd(ctxv, wo_f, b_out.detach(), dropout_p=p_out, seed=seed_out)
+        ctx.save_for_backward(q_in, q_pos, q, u, probs, zext, ctxv, wq_d, wo_d, wk_n, wv_t)
+        ctx.cfg = (F, S, H, E, scale, p_attn, seed_attn, p_out, seed_out)
+        ctx.params = (W_in, b_in, W_out, b_out)
+        ctx.shared = shared
+        return out, (wavg if need_w else None)
+
+    @staticmethod
+    def backward(ctx, dout, dwavg):
+        _arm()
+        q_in, q_pos, q, u, probs, zext, ctxv, wq_d, wo_d, wk_n, wv_t = ctx.saved_tensors
+        F, S, H, E, scale, p_attn, seed_attn, p_out, seed_out = ctx.cfg
+        sh = ctx.shared
+        dt, dev = q_in.dtype, q_in.device
+        defer = _can_defer(*ctx.params)
+        g = ops.dropout(dout.contiguous(), p_out, seed_out) if p_out > 0 else dout.contiguous()
+        dW_in = torch.empty((3 * E, E), dtype=torch.float32, device=dev)
+        db_in = torch.empty(3 * E, dtype=torch.float32, device=dev)
+        dW_out, db_out = _wgrad(g, ctxv, defer, want_bias=True)
+        dctx = ops.linear_fwd(g, wo_d)
+        d_zext = ops.linear_fwd(dctx, wv_t)
+        Gv = ops.linear_wgrad(dctx, zext)  # dense [E, H*E + H]; (not through the batched launch: its job-table ring is sized for a few calls per step)
+        ops.head_blocks_extract(Gv, 1.0, dW_in[2 * E :], db_in[2 * E :], H)
+        first = sh.dmem is None
+        if first:
+            sh.dmem = torch.empty((F * S, E), dtype=torch.float32, device=dev)
+        dwa = dwavg.contiguous().float() if dwavg is not None else None
+        d_u = ops.cross_q1_bwd(u, sh.mem, sh.pos, probs, d_zext, dwa, sh.dmem, not first, F, S, H, dropout_p=p_attn, seed=seed_attn)
+        dq = ops.linear_fwd(d_u, wk_n)
+        Gk = ops.linear_wgrad(q, d_u)
+        ops.head_blocks_extract(Gk, scale, dW_in[E : 2 * E], None, H)
+        db_in[E : 2 * E].zero_()
+        if defer:
+            _wgrad(dq, q_in, True, want_bias=True, out=dW_in[:E], dbias=db_in[:E], x2=q_pos)
+        else:  # the immediate kernels add into their output
+            dW_in[:E].zero_()
+            db_in[:E].zero_()
+            _wgrad(dq, q_in, False, want_bias=True, out=dW_in[:E], dbias=db_in[:E], x2=q_pos)
+        need_pos = q_pos is not None and ctx.needs_input_grad[1]
+        d_q_in = ops.linear_fwd(dq, wq_d) if (ctx.needs_input_grad[0] or need_pos) else None
+        return (d_q_in if ctx.needs_input_grad[0] else None, d_q_in if need_pos else None, None, dW_in, db_in, dW_out, db_out) + (None,) * 10
+
+
+def cross_q1_memory(mem, pos):
+    """-> (token, shared) for ``multihead_attention_q1``: the decoder memory rows [F*S, E] (and their positional rows or None) shared
+    by the layers' time-aligned cross-attention."""
+    shared = _CrossQ1Shared(mem.detach(), None if pos is None else pos.detach())
+    return CrossMemFn.apply(mem, shared), shared
+
+
+def multihead_attention_q1(q_in, anchor, W_in, b_in, W_out, b_out, key_pad, F, S, H, need_weights=True, attn_dropout=0.0, out_dropout=0.0,
+                           training=False, q_pos=None):
+    pa = attn_dropout if training else 0.0
+    po = out_dropout if training else 0.0
+    token, shared = anchor
+    return CrossQ1Fn.apply(q_in, q_pos, token, W_in, b_in, W_out, b_out, key_pad, shared, F, S, H, need_weights,
+                           pa, _seed() if pa > 0 else 0, po, _seed() if po > 0 else 0)
+
+
 def cross_kv(mem, pos, attn_modules):
     """-> (K_all, V_all, shared) for ``multihead_attention_prekv``: keys from mem + pos (pos: rows like mem, or None), values from
     mem; attn_modules: the layers' cross-attention parameter holders."""

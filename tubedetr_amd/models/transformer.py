@@ -52,6 +52,12 @@ class MultiheadAttention(nn.Module):
                                             B, Lq, Lk, self.num_heads, need_weights, attn_dropout=self.dropout, out_dropout=out_dropout, training=training,
                                             q_pos=q_pos)
 
+    def run_q1(self, q_in, anchor, key_pad, F, S, need_weights, out_dropout, training, q_pos=None):
+        """One query per frame against that frame's S memory rows, key / value projections on the query side (functional.CrossQ1Fn)."""
+        return Fk.multihead_attention_q1(q_in, anchor, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight, self.out_proj.bias, key_pad,
+                                         F, S, self.num_heads, need_weights, attn_dropout=self.dropout, out_dropout=out_dropout, training=training,
+                                         q_pos=q_pos)
+
     def run(self, q_in, k_in, v_in, key_pad, B, Lq, Lk, need_weights, out_dropout, training, q_pos=None):
         """q_pos: the positional operand of the query (self-attention: query and key) projection - with_pos_embed() of the
         reference layers as a second operand stream of the projection GEMM, never added in memory (functional.MHAFn)."""
@@ -123,7 +129,9 @@ class TransformerDecoderLayer(nn.Module):
         else:
             a, w = self.self_attn.run(tgt, None, tgt, query_mask, b, t, t, True, self.p, self.training, q_pos=query_pos)
         tgt = Fk.add_layernorm(a, tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        if kv is not None:
+        if isinstance(kv, tuple) and len(kv) == 2:  # (token, shared) of functional.cross_q1_memory: no key / value projection of the memory
+            a, cw = self.cross_attn_image.run_q1(tgt, kv, memory_mask, b * t, S, True, self.p, self.training, q_pos=query_pos)
+        elif kv is not None:
             a, cw = self.cross_attn_image.run_prekv(tgt, kv, index, memory_mask, b * t, 1, S, True, self.p, self.training, q_pos=query_pos)
         else:  # (TD_KV_HOIST=0, A/B only: per-layer key / value projections over a materialised memory + pos)
             mem_k = Fk.AddFn.apply(mem, pos) if pos is not None else mem
@@ -148,7 +156,14 @@ class TransformerDecoder(nn.Module):
         out = tgt
         # one key and one value projection GEMM for the six layers' shared memory (functional.CrossKVFn); keys = memory + pos
         # with pos as the GEMM's second operand stream
-        kv = Fk.cross_kv(mem, pos, [l.cross_attn_image for l in self.layers]) if os.environ.get("TD_KV_HOIST", "1") != "0" else None
+        # Default: the time-aligned cross-attention has ONE query per frame, so its key / value projections move to the query side
+        # and the memory rows are never projected (functional.CrossQ1Fn).  TD_CROSS_Q1=0 (A/B), learned position embeddings (pos
+        # needs a gradient) or another width / head count: the projected-memory path, hoisted over the layers (TD_KV_HOIST=0: per layer).
+        att = self.layers[0].cross_attn_image
+        if os.environ.get("TD_CROSS_Q1", "1") != "0" and att.embed_dim == 256 and att.num_heads == 8 and not (pos is not None and pos.requires_grad):
+            kv = Fk.cross_q1_memory(mem, pos)
+        else:
+            kv = Fk.cross_kv(mem, pos, [l.cross_attn_image for l in self.layers]) if os.environ.get("TD_KV_HOIST", "1") != "0" else None
         for i, layer in enumerate(self.layers):
             out, w, cw = layer(out, query_pos, mem, pos, query_mask, memory_mask, b, t, S, kv=kv, index=i)
             if self.return_intermediate:

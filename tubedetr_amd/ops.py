@@ -534,6 +534,58 @@ def mha_lean_bwd(q: Tensor, k: Tensor, v: Tensor, kp: Optional[Tensor], out: Ten
     return dq, dk, dv
 
 
+def head_blocks_expand(W: Tensor, bias: Optional[Tensor], alpha: float, H: int, dtype: torch.dtype):
+    """One [E,E] slice of a packed in_proj weight (fp32, [out][in]) -> (w_n [E, H*E + nb], w_t [H*E + nb, E]) in ``dtype``: row j of
+    w_n holds W[j] * alpha in column block head(j) and, with a bias (nb = H), bias[j] in column H*E + head(j)."""
+    E = W.shape[0]
+    assert W.shape == (E, E) and W.dtype == torch.float32 and W.is_contiguous() and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))
+    ld = H * E + (H if bias is not None else 0)
+    w_n = torch.empty((E, ld), dtype=dtype, device=W.device)
+    w_t = torch.empty((ld, E), dtype=dtype, device=W.device)
+    check(_hip.lib().td_head_blocks_expand(ptr(W), ptr(bias), float(alpha), ptr(w_n), ptr(w_t), E, H, dtype_code(dtype), stream_ptr()), "td_head_blocks_expand")
+    return w_n, w_t
+
+
+def head_blocks_extract(G: Tensor, alpha: float, dW: Tensor, db: Optional[Tensor], H: int) -> None:
+    """dW [E,E] fp32 (a row slice of a packed gradient is fine) and optionally db [E] from the dense gradient G [E, H*E (+ H)] of w_n."""
+    E = dW.shape[0]
+    assert G.dtype == torch.float32 and G.is_contiguous() and G.shape == (E, H * E + (H if db is not None else 0))
+    assert dW.shape == (E, E) and dW.dtype == torch.float32 and dW.is_contiguous() and (db is None or (db.is_contiguous() and db.dtype == torch.float32))
+    check(_hip.lib().td_head_blocks_extract(ptr(G), float(alpha), ptr(dW), ptr(db), E, H, stream_ptr()), "td_head_blocks_extract")
+
+
+def cross_q1_fwd(u: Tensor, mem: Tensor, pos: Optional[Tensor], key_pad: Optional[Tensor], F: int, S: int, H: int, *, need_wavg: bool = True,
+                 dropout_p: float = 0.0, seed: int = 0):
+    """Frame core of the time-aligned cross-attention with the projections on the query side (csrc/cross_attn.hip):
+    u [F, H*E] (scaled W_k,h^T q), mem / pos [F*S, E]  ->  probs [F,H,S] fp32, wavg [F,1,S] fp32 | None, zext [F, H*E + H]."""
+    E = mem.shape[1]
+    assert u.shape == (F, H * E) and mem.shape == (F * S, E) and u.is_contiguous() and mem.is_contiguous() and u.dtype == mem.dtype
+    assert pos is None or (pos.shape == mem.shape and pos.is_contiguous() and pos.dtype == mem.dtype)
+    kp = key_pad.to(torch.uint8).contiguous() if key_pad is not None else None
+    assert kp is None or kp.numel() == F * S
+    ldz = H * E + H
+    probs = torch.empty((F, H, S), dtype=torch.float32, device=u.device)
+    wavg = torch.empty((F, 1, S), dtype=torch.float32, device=u.device) if need_wavg else None  # nn.MultiheadAttention's [B, Lq, Lk]
+    zext = torch.empty((F, ldz), dtype=u.dtype, device=u.device)
+    check(_hip.lib().td_cross_q1_fwd(ptr(u), ptr(mem), ptr(pos), ptr(kp), ptr(probs), ptr(wavg), ptr(zext), F, S, H, E, ldz, dropout_p, seed & 0xFFFFFFFF,
+                                     _ctr() if dropout_p > 0 else None, dtype_code(u.dtype), stream_ptr()), "td_cross_q1_fwd")
+    return probs, wavg, zext
+
+
+def cross_q1_bwd(u: Tensor, mem: Tensor, pos: Optional[Tensor], probs: Tensor, d_zext: Tensor, dwavg: Optional[Tensor], d_mem: Tensor, accumulate: bool,
+                 F: int, S: int, H: int, *, dropout_p: float = 0.0, seed: int = 0) -> Tensor:
+    """-> d_u [F, H*E]; d_mem [F*S, E] fp32 is overwritten (accumulate=False) or added to."""
+    E = mem.shape[1]
+    assert d_zext.shape == (F, H * E + H) and d_zext.is_contiguous() and d_zext.dtype == u.dtype and probs.is_contiguous()
+    assert d_mem.shape == (F * S, E) and d_mem.dtype == torch.float32 and d_mem.is_contiguous()
+    assert dwavg is None or (dwavg.dtype == torch.float32 and dwavg.is_contiguous() and dwavg.numel() == F * S)
+    d_u = torch.empty((F, H * E), dtype=u.dtype, device=u.device)
+    check(_hip.lib().td_cross_q1_bwd(ptr(u), ptr(mem), ptr(pos), ptr(probs), ptr(d_zext), ptr(dwavg), ptr(d_u), ptr(d_mem), int(bool(accumulate)), F, S, H, E,
+                                     H * E + H, dropout_p, seed & 0xFFFFFFFF, _ctr() if dropout_p > 0 else None, dtype_code(u.dtype), stream_ptr()),
+          "td_cross_q1_bwd")
+    return d_u
+
+
 def mha_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, probs: Tensor, dwavg: Optional[Tensor], H: int, scale: float,
             dq: Tensor, dk: Tensor, dv: Tensor, *, dropout_p: float = 0.0, seed: int = 0):
     """dq/dk/dv must be allocated by the caller with exactly the strides of q/k/v (e.g. views of a packed buffer)."""
