@@ -429,6 +429,13 @@ def main():
     assert math.isfinite(loss.item()), "non-finite loss"
 
     roofline, cpu = None, None
+    if a.roofline_steps > 0 and rank != 0 and distributed:
+        # N > 1: the eager step holds collectives (num_boxes, the gradient exchange), so every rank runs the roofline steps that
+        # rank 0 times - a rank that skipped them would leave rank 0's collectives unmatched
+        ops_.set_dropout_counter(None)
+        for i in range(a.roofline_steps):
+            eager_step(a.warmup + a.steps + i)
+        torch.cuda.synchronize()
     if rank == 0:
         if a.roofline_steps > 0:
             L_ = _hip.lib()

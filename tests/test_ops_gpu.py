@@ -941,11 +941,15 @@ def test_cross_attention_query_side_draws_the_same_dropout_mask_as_the_projected
         Fk._SEED_STATE["torch_seed"] = None
         t_, m_ = tgt.clone().requires_grad_(True), mem.clone().requires_grad_(True)
         ps = [p.clone().requires_grad_(True) for p in (W_in, b_in, W_out, b_out)]
-        if which == "q1":
-            o, w = Fk.multihead_attention_q1(t_, Fk.cross_q1_memory(m_, None), *ps, key_pad, F_, S, H, need_weights=True, attn_dropout=0.3, training=True)
-        else:
-            o, w = Fk.multihead_attention(t_, m_, m_, *ps, key_pad, F_, 1, S, H, True, attn_dropout=0.3, training=True)
-        ((o * wo).sum() + (w * ww).sum() * 30).backward()
+        Fk.set_wgrad_deferral(which != "q1")  # ...and the immediate (not deferred) weight-gradient branch of the new node, as under torch DDP
+        try:
+            if which == "q1":
+                o, w = Fk.multihead_attention_q1(t_, Fk.cross_q1_memory(m_, None), *ps, key_pad, F_, S, H, need_weights=True, attn_dropout=0.3, training=True)
+            else:
+                o, w = Fk.multihead_attention(t_, m_, m_, *ps, key_pad, F_, 1, S, H, True, attn_dropout=0.3, training=True)
+            ((o * wo).sum() + (w * ww).sum() * 30).backward()
+        finally:
+            Fk.set_wgrad_deferral(True)
         res.append([o.detach(), w.detach(), t_.grad, m_.grad] + [p.grad for p in ps])
     assert (res[0][1] == 0).float().mean().item() < 0.35 and rel_err(res[0][1], res[1][1]) < 1e-4  # same dropped entries
     for a, b in zip(res[0], res[1]):
