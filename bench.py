@@ -66,8 +66,8 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 # algorithmic TFLOP per clip fwd+bwd
 ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
 DEFAULT_CLIPS_PER_GPU = 16
-PMC_TRAFFIC = "r02_pmc_traffic.json"
-PMC_MFMA = "r02_pmc_mfma.json"
+PMC_TRAFFIC = "r03_pmc_traffic.json"
+PMC_MFMA = "r03_pmc_mfma.json"
 
 
 def make_batch(T, res, k, L, seed, device, clips=1, frames="u8"):
@@ -450,7 +450,7 @@ def main():
             fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128, *, *>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128, *, *>",
                     1: f"td::conv_gemm_kernel<{tname}, 128, 64, *, *>", 2: "td::conv_wgrad_*batch_kernel", 4: "td::pw_resident_kernel<*>",
                     5: "td::conv_gemm_big_kernel<*, true>", 6: "td::conv_gemm_big_kernel<*, false>",
-                    7: "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>", 8: "td::cross_q1_*_kernel"}
+                    7: "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>", 8: "td::cross_q1_*_kernel", 9: "td::conv_wgrad_kernel<unsigned short>"}
             # * = all pipeline depths, pointwise and generic instances; 2 = wide-tile + 128x128 batched weight-gradient launches; 5 / 6 = the 256-row
             # tile kernel on spatial (MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers; 7 = the LDS-resident fused stem / layer1 blocks;
             # 8 = the decoder's time-aligned cross-attention frame core (fp32 VALU arithmetic: its FLOPs are not MFMA FLOPs, bound = HBM)

@@ -53,7 +53,8 @@ int td_abi_version(void);
 #define TD_PROF_GEMM_256_PW 6 /* the same kernel on pointwise layers with K >= 512: HBM-bound (4.2 TB/s of algorithmic bytes) */
 #define TD_PROF_FUSED 7       /* LDS-resident chains: fused stem (stem.hip), fused frozen bottlenecks (bottleneck.hip) */
 #define TD_PROF_CROSS_Q1 8    /* time-aligned cross-attention frame core (cross_attn.hip): HBM-bound by the memory rows */
-#define TD_PROF_FAMILIES 9
+#define TD_PROF_WGRAD_SINGLE 9 /* one weight gradient per launch (td_conv_wgrad[_bias]); TD_PROF_WGRAD = the batched launches */
+#define TD_PROF_FAMILIES 10
 int td_prof_enable(int on);
 int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
 /* Sum of the ALGORITHMIC HBM bytes of the same launches (each operand / result tensor counted once per launch). */

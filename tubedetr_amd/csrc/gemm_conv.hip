@@ -49,6 +49,7 @@ struct GemmParams {
   const int* a2_map;
   const int* out_map;
   const int* res_map;
+  int tap_inner;  // 256-row tile kernel, spatial layers: walk the K axis channel-chunk-major (all taps of one 64-channel chunk, then the next chunk)
 };
 
 template <typename T>
@@ -575,6 +576,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
 // The epilogue walks the wavefront's rows in chunks of 16: transposed through a private 4-KiB LDS region (no workgroup
 // barrier between chunks), residual / mask operands of chunk c+1 requested while chunk c is stored.
 // TU / pointwise addressing exactly as in conv_gemm_kernel.
+// (Measured and dropped: FOUR wavefronts with 128 x 128 sub-tiles and 256 AGPR-pinned accumulators each - 192 instead of 256 KiB of
+// LDS traffic per K tile - ran the layer3 3x3 forward in 602 us against 493 us: one wavefront per SIMD cannot cover its own LDS
+// and barrier latencies with this schedule.)
 template <int BN, bool TU>
 __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
   using T = u16;
@@ -634,39 +638,59 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
   uint32_t b_off[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) b_off[i] = (uint32_t)(n0 + (i * NW + wave) * 8 + lrow) * (uint32_t)p.K * ES;  // Nc % BN == 0: always inside
-  int kk = chunk * VEC;
-  int t_tap = 0, t_ks = 0, t_kc = 0, t_pix = 0;
   const int lane_c = chunk * VEC;
+  // Position of the K walk: wave-uniform scalars, advanced once per tile WITHOUT control flow and handed from call to call by
+  // value.  (As ints captured by reference and updated under nested ifs they lived in scratch memory: a scratch load + s_waitcnt
+  // vmcnt(0) per update made the wavefront wait for the DMA loads it had just issued - 17 scratch accesses and 13 vmcnt waits
+  // per K tile of the 3x3 layers; the second resident wavefront of the SIMD covered most of it: 499 -> 493 us on the layer3 3x3.)
+  struct Walk { int kk, tap, ks, kc, pix; };  // kk: first column of the tile on the linear K axis; the rest: tap walk (TU)
+  const int step_s = d.mode == 0 ? 1 : -1, step_r = d.mode == 0 ? d.Ws - (d.S - 1) : -(d.Ws - (d.S - 1));
+  const bool tap_inner = TU && p.tap_inner;
 
-  auto issue_tile = [&](char* stage) {
+  auto issue_tile = [&](char* stage, Walk w) -> Walk {
     char* stA = stage;
     char* stB = stage + BM * 128;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       uint32_t off;
       if constexpr (TU) {
-        const bool ok = (a_mask[i] >> (t_tap & 31)) & 1u;
-        off = ok ? (uint32_t)((a_base[i] + t_pix) * d.C + t_kc + lane_c) * ES : OOB;
+        const bool ok = (a_mask[i] >> (w.tap & 31)) & 1u;
+        off = ok ? (uint32_t)((a_base[i] + w.pix) * d.C + w.kc + lane_c) * ES : OOB;
       } else {
-        off = a_off[i] != OOB ? a_off[i] + (uint32_t)kk * ES : OOB;
+        off = a_off[i] != OOB ? a_off[i] + (uint32_t)(w.kk + lane_c) * ES : OOB;
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stA + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
     }
+    // weight columns of this tile: the K axis is [tap][channel]; in tap-inner order the walk is not linear
+    const uint32_t kw = (uint32_t)((tap_inner ? w.tap * d.C + w.kc : w.kk) + lane_c);
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const uint32_t off = b_off[i] + (uint32_t)kk * ES;
+      const uint32_t off = b_off[i] + kw * ES;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(stB + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
     }
-    kk += BK;
+    w.kk += BK;
     if constexpr (TU) {
-      t_kc += BK;
-      if (t_kc >= d.C) {
-        t_kc = 0;
-        ++t_tap;
-        if (++t_ks == d.S) { t_ks = 0; t_pix += d.mode == 0 ? d.Ws - (d.S - 1) : -(d.Ws - (d.S - 1)); }
-        else t_pix += d.mode == 0 ? 1 : -1;
-      }
+      // tap-inner order: all R*S taps of one 64-channel chunk back to back - the workgroup re-reads the SAME 128-byte line of every
+      // pixel of its window nine times within nine K tiles (32 KiB of activations per workgroup, 1 MiB per XCD: L2-resident)
+      // instead of coming back to a pixel's 512-byte row after four tiles of another tap (128 KiB per workgroup, 4 MiB per XCD =
+      // the whole L2: PMC FETCH_SIZE was 4.4x the source tensor).  tap-outer: all channel chunks of one tap, then the next tap.
+      const int kc1 = w.kc + BK;
+      const bool next_tap = tap_inner || kc1 >= d.C;       // this tile was the last one of its (tap, chunk run)
+      const int ks1 = w.ks + 1;
+      const bool wrap_s = ks1 == d.S;
+      const int tap1 = w.tap + 1;
+      const bool wrap_t = tap_inner && tap1 == RS;         // tap-inner: back to tap 0, next channel chunk
+      const int pix1 = w.pix + (wrap_s ? step_r : step_s);
+      w.kc = tap_inner ? (wrap_t ? kc1 : w.kc) : (next_tap ? 0 : kc1);
+      w.pix = next_tap ? (wrap_t ? 0 : pix1) : w.pix;
+      w.ks = next_tap ? ((wrap_s || wrap_t) ? 0 : ks1) : w.ks;
+      w.tap = next_tap ? (wrap_t ? 0 : tap1) : w.tap;
+      w.kc = __builtin_amdgcn_readfirstlane(w.kc);
+      w.pix = __builtin_amdgcn_readfirstlane(w.pix);
+      w.ks = __builtin_amdgcn_readfirstlane(w.ks);
+      w.tap = __builtin_amdgcn_readfirstlane(w.tap);
     }
+    return w;
   };
 
   const int wy = wave / WGN, wx = wave - wy * WGN;
@@ -707,10 +731,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
     }
   };
   // tile in `cur` (its group-0 fragments already requested into wf[0] / af[0]); `nxt` receives tile kt + 1
-  auto tile_body = [&](char* cur, char* nxt, bool has_next) {
+  auto tile_body = [&](char* cur, char* nxt, bool has_next, Walk w) -> Walk {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      if (g == 0 && has_next) issue_tile(nxt);  // every wavefront finished reading `nxt` (tile kt - 1) before the last barrier
+      if (g == 0 && has_next) w = issue_tile(nxt, w);  // every wavefront finished reading `nxt` (tile kt - 1) before the last barrier
       if (g + 1 < NG) {
         if ((g + 1) % GPK == 0) load_w(cur, (g + 1) / GPK, wf[((g + 1) / GPK) & 1]);
         load_a(cur, g + 1, af[(g + 1) & 1]);
@@ -731,6 +755,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
         for (int i = 0; i < TN; ++i) Mfma<T>::run(wf[ks & 1][i], af[g & 1][j], acc[i][jh + j]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    return w;
   };
 
   // ---- epilogue bookkeeping: chunks of 16 rows, 8 lanes x 16 bytes per 64-channel row segment ----
@@ -754,16 +779,16 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
   const int nk = p.K / BK;
 #define TD_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
   TD_STAMP(0);
-  issue_tile(smem0);
+  Walk walk = issue_tile(smem0, Walk{0, 0, 0, 0, 0});
   __syncthreads();  // tile 0 landed
   TD_STAMP(1);
   load_w(smem0, 0, wf[0]);
   load_a(smem0, 0, af[0]);
 #pragma unroll 1
   for (int kt = 0; kt < nk; kt += 2) {
-    tile_body(smem0, smem1, kt + 1 < nk);
+    walk = tile_body(smem0, smem1, kt + 1 < nk, walk);
     if (kt + 1 >= nk) break;
-    tile_body(smem1, smem0, kt + 2 < nk);
+    walk = tile_body(smem1, smem0, kt + 2 < nk, walk);
   }
   TD_STAMP(2);
   fetch_chunk(0, 0);
@@ -1894,6 +1919,8 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
         if (p.mask_src) by += (double)p.M * d->Nc * 2.0;
         prof_set_bytes(by);
       }
+      static const int tap_inner = [] { const char* e_ = getenv("TD_CONV_TAP_INNER"); return e_ ? atoi(e_) : 1; }();
+      p.tap_inner = tu && tap_inner && d->R * d->S > 1;
       dim3 gb(8 * cdiv(cdiv(p.M, 256), 8) * (d->Nc / bnb));
       if (bnb == 256) {
         if (tu) conv_gemm_big_kernel<256, true><<<gb, 512, 0, st>>>(p);
@@ -2106,7 +2133,7 @@ extern "C" int td_conv_wgrad_bias(const void* g, const void* src, float* dw, flo
   dim3 grid(p.tn, p.tk, splits);
   hipStream_t st = (hipStream_t)stream;
   const bool prof = prof_on();
-  if (prof) prof_begin(TD_PROF_WGRAD, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, splits);
+  if (prof) prof_begin(TD_PROF_WGRAD_SINGLE, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, splits);
   if (prof) prof_set_bytes(((double)p.M * ldg + (double)d->N * d->Hs * d->Ws * d->C) * (dtype == TD_BF16 ? 2.0 : 4.0) + (double)d->Nc * p.K * 4.0);
   const bool pw = (d->R * d->S == 1) && d->stride == 1 && d->pad == 0;
   const int nstg = wgrad_stages();
