@@ -473,6 +473,10 @@ def main():
                     hbm_bound = gbs / PEAK_HBM_GBS > tfl / peak  # the roof this family sits closer to
                     t_ = pmc.get(kname)
                     traffic = (t_["fetch_bytes_per_launch"] + t_["write_bytes_per_launch"]) if (t_ and t_.get("fetch_bytes_per_launch") and t_.get("write_bytes_per_launch")) else None
+                    if traffic and pmc.get("_steps"):
+                        # per launch of THIS run's launch count: the PMC pass and the event-timed step may split a family's work into a
+                        # different number of launches (the batched weight gradients: an accumulating phase is a launch of its own)
+                        traffic = round(traffic * (t_["dispatches"] / pmc["_steps"]) / (n.value / a.roofline_steps))
                     mu = mfma.get(kname, {}).get("mfma_util") if isinstance(mfma.get(kname), dict) else None
                     rec = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
                            "achieved": round(gbs if hbm_bound else tfl, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,

@@ -46,7 +46,8 @@ def main():
     F, W = load(fetch), load(write)
     res = {"_doc": "bytes per launch = counter sum (KiB) * 1024 / dispatches; fetch doubled (gfx950 16-B/lane streaming-read correction); "
                    "Infinity-Cache hits are counted by these memory-side counters",
-           "_command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --no-graph --steps 1 --warmup 1 --cpu-frames 0 --roofline-steps 0"}
+           "_command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --no-graph --steps 1 --warmup 1 --cpu-frames 0 --roofline-steps 0",
+           "_steps": 2}  # warm-up + timed step: `dispatches` / _steps = launches per step
     for f in sorted(set(F) | set(W)):
         nf, sf = F.get(f, [0, 0.0])
         nw, sw = W.get(f, [0, 0.0])
@@ -55,7 +56,7 @@ def main():
                   "write_bytes_per_launch": round(sw * 1024 / nw) if nw else None}
     json.dump(res, open(dst, "w"), indent=1)
     for f, v in res.items():
-        if isinstance(v, dict) and v["fetch_bytes_per_launch"]:
+        if isinstance(v, dict) and v.get("fetch_bytes_per_launch"):
             print(f"{f:70s} n={v['dispatches']:5d} fetch {v['fetch_bytes_per_launch']/1e6:9.2f} MB  write {(v['write_bytes_per_launch'] or 0)/1e6:9.2f} MB per launch")
 
 
