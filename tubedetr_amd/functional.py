@@ -640,9 +640,10 @@ class _CrossQ1Shared:
     """What the six time-aligned cross-attention nodes share: the memory rows they all read and the ONE fp32 buffer their
     backward kernels accumulate d(memory) in (first layer to run writes, the others add)."""
 
-    def __init__(self, mem, pos):
+    def __init__(self, mem, pos, want_dmem=True):
         self.mem, self.pos = mem, pos
         self.dmem = None
+        self.want_dmem = want_dmem  # False: the memory needs no gradient (nothing will collect the buffer)
 
 
 class CrossMemFn(Function):
@@ -721,10 +722,13 @@ class CrossQ1Fn(Function):
         Gv = ops.linear_wgrad(dctx, zext)  # dense [E, H*E + H]; (not through the batched launch: its job-table ring is sized for a few calls per step)
         ops.head_blocks_extract(Gv, 1.0, dW_in[2 * E :], db_in[2 * E :], H)
         first = sh.dmem is None
-        if first:
-            sh.dmem = torch.empty((F * S, E), dtype=torch.float32, device=dev)
+        if first or not sh.want_dmem:
+            dmem = torch.empty((F * S, E), dtype=torch.float32, device=dev)
+            sh.dmem = dmem if sh.want_dmem else None
+        else:
+            dmem = sh.dmem
         dwa = dwavg.contiguous().float() if dwavg is not None else None
-        d_u = ops.cross_q1_bwd(u, sh.mem, sh.pos, probs, d_zext, dwa, sh.dmem, not first, F, S, H, dropout_p=p_attn, seed=seed_attn)
+        d_u = ops.cross_q1_bwd(u, sh.mem, sh.pos, probs, d_zext, dwa, dmem, sh.want_dmem and not first, F, S, H, dropout_p=p_attn, seed=seed_attn)
         dq = ops.linear_fwd(d_u, wk_n)
         Gk = ops.linear_wgrad(q, d_u)
         ops.head_blocks_extract(Gk, scale, dW_in[E : 2 * E], None, H)
@@ -743,7 +747,7 @@ class CrossQ1Fn(Function):
 def cross_q1_memory(mem, pos):
     """-> (token, shared) for ``multihead_attention_q1``: the decoder memory rows [F*S, E] (and their positional rows or None) shared
     by the layers' time-aligned cross-attention."""
-    shared = _CrossQ1Shared(mem.detach(), None if pos is None else pos.detach())
+    shared = _CrossQ1Shared(mem.detach(), None if pos is None else pos.detach(), want_dmem=mem.requires_grad and torch.is_grad_enabled())
     return CrossMemFn.apply(mem, shared), shared
 
 

@@ -160,7 +160,8 @@ class TransformerDecoder(nn.Module):
         # and the memory rows are never projected (functional.CrossQ1Fn).  TD_CROSS_Q1=0 (A/B), learned position embeddings (pos
         # needs a gradient) or another width / head count: the projected-memory path, hoisted over the layers (TD_KV_HOIST=0: per layer).
         att = self.layers[0].cross_attn_image
-        if os.environ.get("TD_CROSS_Q1", "1") != "0" and att.embed_dim == 256 and att.num_heads == 8 and not (pos is not None and pos.requires_grad):
+        if (os.environ.get("TD_CROSS_Q1", "1") != "0" and att.embed_dim == 256 and att.num_heads == 8 and S <= 320  # (S: the frame core's LDS budget)
+                and not (pos is not None and pos.requires_grad)):
             kv = Fk.cross_q1_memory(mem, pos)
         else:
             kv = Fk.cross_kv(mem, pos, [l.cross_attn_image for l in self.layers]) if os.environ.get("TD_KV_HOIST", "1") != "0" else None
