@@ -260,6 +260,8 @@ def main():
     args = tubedetr_amd.default_args(stride=k, fast=not a.no_fast, no_tsa=a.no_tsa, compute_dtype=cdt, video_max_len_train=max(200, T))
     model, criterion, weight_dict = build_model(args)
     model.to(dev)
+    if a.dedupe and B * (T + (T + k - 1) // k) > 1083 * (352 * 352) // (res * res):
+        raise SystemExit("bench: --dedupe is implemented for steps whose slow + fast frames share one trunk pass (<= 8 clips of cfg3 per step)")
     model.slow_frames_are_strided_fast = bool(a.dedupe)  # legal because the synthetic clip has slow = video[::k]
     model.train(not a.eval_dropout_off)
     tok = BatchTokenizer()
@@ -495,7 +497,8 @@ def main():
                 per.sort(key=lambda r: -r["kernel_ms_per_step"])
                 roofline = dict(per[0])  # the dominant kernel (largest share of the step)
                 roofline["other_mfma_kernels"] = per[1:]
-                grp = mfma.get("decoder_attention_group") if isinstance(mfma, dict) else None
+                # north_star's decoder-attention group from per-dispatch PMC rows (profiles/README.md), the coarse family view as fallback
+                grp = (mfma.get("decoder_attention_group_precise") or mfma.get("decoder_attention_group")) if isinstance(mfma, dict) else None
                 if grp:
                     roofline["decoder_attention_group"] = grp  # north_star's sub-target, static from profiles/
         if world == 1 and a.cpu_frames > 0:

@@ -130,3 +130,32 @@ def test_ablation_variants_keep_the_reference_parameter_names():
 
     with _pytest.raises(TypeError):
         model.transformer(encode_and_save=False)
+
+
+def test_cross_attention_projections_commute_to_the_query_side():
+    """The identity csrc/cross_attn.hip is built on, in float64 on the CPU against torch's own nn.MultiheadAttention: with ONE query
+    per frame, softmax(q . (W_k (x + pos) + b_k)) (W_v x + b_v) = W_v,h (sum_s p[h,s] x_s) + b_v with scores u_h . (x_s + pos_s),
+    u_h = W_k,h^T q_h / sqrt(d_h) - the key bias shifts every score of a row equally and drops out."""
+    torch.manual_seed(3)
+    F_, S, E, H = 5, 37, 256, 8
+    hd = E // H
+    mha = torch.nn.MultiheadAttention(E, H, dropout=0.0).double()
+    with torch.no_grad():
+        mha.in_proj_bias.normal_()
+        mha.out_proj.bias.normal_()
+    tgt, qpos = torch.randn(F_, E).double(), torch.randn(F_, E).double()
+    mem, pos = torch.randn(F_, S, E).double(), torch.randn(F_, S, E).double()
+    key_pad = torch.rand(F_, S) < 0.3
+    key_pad[:, 0] = False
+    # reference: (L = 1, N = F_, E) query, (S, F_, E) keys / values - transformer.py:727-740
+    ref, ref_w = mha((tgt + qpos)[None], (mem + pos).transpose(0, 1), mem.transpose(0, 1), key_padding_mask=key_pad)
+    W, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
+    q = (tgt + qpos) @ W[:E].t() + b[:E]
+    u = torch.einsum("fhj,hjc->fhc", q.view(F_, H, hd) / hd**0.5, W[E : 2 * E].view(H, hd, E))          # W_k,h^T q_h
+    sc = torch.einsum("fhc,fsc->fhs", u, mem + pos).masked_fill(key_pad[:, None, :], float("-inf"))   # no key bias
+    p = sc.softmax(-1)
+    z = torch.einsum("fhs,fsc->fhc", p, mem)                                                           # weighted memory rows
+    ctx = torch.einsum("fhc,hjc->fhj", z, W[2 * E :].view(H, hd, E)).reshape(F_, E) + b[2 * E :] * p.sum(-1).repeat_interleave(hd, 1)
+    out = ctx @ mha.out_proj.weight.detach().t() + mha.out_proj.bias.detach()
+    assert torch.allclose(out, ref[0].detach(), atol=1e-10)
+    assert torch.allclose(p.mean(1), ref_w[:, 0].detach(), atol=1e-12)
