@@ -366,6 +366,12 @@ def test_pointwise_persistent_instance_matches_tiled_math(cfg):
         ref = ref * (msk.float() > 0)
     y = ops.linear_fwd(x, w, b, residual=res, relu=relu, mask_src=msk)
     assert rel_err(y, ref) < TOL[dt]
+    # dropout in the epilogue (the encoder's FFN in train mode): the mask of td_dropout over the same element indices
+    yd = ops.linear_fwd(x, w, b, residual=res, relu=relu, mask_src=msk, dropout_p=0.1, seed=4321)
+    ref_d = ops.dropout(ref.contiguous(), 0.1, 4321)
+    sure = ref.abs() > 1e-3  # (an exact 0.0 of the fp32 reference can be a 1e-7 of another summation order)
+    assert torch.equal((yd == 0)[sure], (ref_d == 0)[sure]) and 0.05 < ((yd == 0) & sure).float().mean().item() / max(sure.float().mean().item(), 1e-6) < 0.15
+    assert rel_err(yd, ref_d) < TOL[dt]
     # in place on the residual (the dgrad chain accumulates into dx this way)
     if use_res:
         y2 = ops.linear_fwd(x, w, b, residual=res, relu=relu, mask_src=msk, out=res)

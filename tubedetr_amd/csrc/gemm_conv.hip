@@ -926,6 +926,7 @@ __global__ __launch_bounds__(256, 2) void pw_resident_kernel(GemmParams p, int M
         wfr[kt][ks][i] = *(const uint4*)(p.w + ((size_t)(n0 + wx * WN + i * 16 + lr) * p.K + kt * 64 + ks * 32 + lg * 8) * ES);
   int mt = gid;
   issue_A(sA0, mt);
+  const uint32_t drop_seed = p.drop_thresh ? effective_seed(p.seed, p.seed_dev) : 0u;
 
   auto step = [&](char* cur, char* nxt, int mt) {
     // (1) epilogue operands of this tile (rows clamped: every lane always issues, the wait counts below are constants)
@@ -1007,6 +1008,10 @@ __global__ __launch_bounds__(256, 2) void pw_resident_kernel(GemmParams p, int M
         unpack16<T>(msk[it], m8);
 #pragma unroll
         for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
+      }
+      if (p.drop_thresh) {  // (same element index as conv_gemm_kernel's epilogue and td_dropout: the backward regenerates this mask)
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = dropout_keep(drop_seed, (uint32_t)(offs[it] + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
       }
       if (live[it]) st16(p.out + offs[it] * ES, pack16<T>(v));
     }
@@ -1844,6 +1849,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   {
     // persistent weight-stationary instance (see pw_resident_kernel): bf16 pointwise layers with short K and many rows
     static const int persist = [] { const char* e_ = getenv("TD_PW_PERSIST"); return e_ ? atoi(e_) : 1; }();
+    static const int persist_dropout = [] { const char* e_ = getenv("TD_PW_PERSIST_DROPOUT"); return e_ ? atoi(e_) : 1; }();  // (A/B: 0 = dropout epilogues on the tiled kernel)
     static const int n_cu = [] {
       int dev = 0, cus = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1856,7 +1862,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
     const int NTp = d->Nc / 128, Pp = 2 * n_cu / 8;
     const bool shape_ok = pw0 && dtype == TD_BF16 && p.K % 64 == 0 && p.K <= 256 && d->Nc % 128 == 0 &&
                           (NTp == 1 || NTp == 2 || NTp == 4 || NTp == 8 || NTp == 16) && Pp >= NTp && d->ldc % 8 == 0 && !p.sigmoid &&
-                          !p.drop_thresh && p.alpha == 1.f && n_cu % 8 == 0;
+                          p.alpha == 1.f && n_cu % 8 == 0 && (!p.drop_thresh || persist_dropout);
     const int MTp = cdiv(p.M, 64);
     const int groups = shape_ok ? 8 * (Pp / NTp) : 1;
     if (persist && shape_ok && MTp >= persist_min_tiles() * groups && !(persist == 2 && p.mask_src) && !(persist == 3 && d->mode != 0)) {
