@@ -155,6 +155,41 @@ def cpu_baseline(T_sample, res, k, L, T_full):
                       f"({', '.join(f'{t_:.1f}' for t_ in times)}) after one warm-up pass, scaled x{T_full}/{T_sample} to T={T_full}"}
 
 
+def launcher_argv(n_gpus, bench_args, port):
+    """Command line that starts `n_gpus` ranks of this script on this node: one process per GPU under torch.distributed.run, rendezvous on
+    127.0.0.1 (the container hostname may not resolve).  Same shape as the driver's own N > 1 command."""
+    rest = [x for x in bench_args if x != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + rest
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def self_launch(n_gpus, bench_args, dry=False):
+    import subprocess
+
+    argv = launcher_argv(n_gpus, bench_args, free_port())
+    if dry:
+        print(json.dumps({"launch": argv}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    r = subprocess.run(argv, stdout=subprocess.PIPE, text=True, env=env)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+    if line:
+        print(line, flush=True)
+    elif r.returncode == 0:
+        print("[bench] the ranks exited cleanly without a JSON line", file=sys.stderr, flush=True)
+        return 1
+    return r.returncode
+
+
 def _trace(msg):
     if os.environ.get("TD_BENCH_TRACE"):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
@@ -194,6 +229,7 @@ def main():
     ap.add_argument("--no-tsa", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: run in eval mode")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without a launcher: print the launcher command line as JSON and exit")
     ap.add_argument("--text-stream", action="store_true", help="(default at N=1; accepted for older command lines)")
     ap.add_argument("--no-text-stream", action="store_true",
                     help="graph mode: capture RoBERTa on the main stream (a linear graph) instead of its own stream (a forked graph branch: "
@@ -207,6 +243,10 @@ def main():
         efence_install.install()
         a.graph, a.child = False, True
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.child:
+        # `python bench.py --gpus N` without an external launcher: start the N ranks ourselves (what util/dist.py:210-247 gets from
+        # torch.distributed.run's environment), pass rank 0's single JSON line through and propagate the exit code
+        sys.exit(self_launch(a.gpus, sys.argv[1:], dry=a.dry_launch))
     if world == 1 and not a.child and not a.force_ddp and a.graph and os.environ.get("TD_BENCH_ISOLATE", "1") != "0":
         # Single-GPU run: the measurement happens in a child process; should it die, the parent re-measures with eager
         # launches instead of losing the bench line.
@@ -236,7 +276,12 @@ def main():
         os.environ.setdefault("TD_TEXT_STREAM", "0")  # single-stream capture: RoBERTa stays on the main stream
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if world != a.gpus:
+        raise SystemExit(f"bench: --gpus {a.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus {a.gpus}` (self-launching) or under "
+                         f"torch.distributed.run --nproc-per-node {a.gpus}")
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        raise SystemExit(f"bench: rank {rank} (local rank {local_rank}) has no device: --gpus {a.gpus} needs {a.gpus} GPUs on this node, {n_dev} visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or a.force_ddp:

@@ -250,3 +250,27 @@ def test_bench_batches_are_sharded_by_rank():
     assert torch.equal(c["frames"].materialize(), torch.cat([c["frames_fast"][0:4:2], c["frames_fast"][4:8:2]])) and c["durations"] == [4, 4]
     assert not torch.equal(a["frames_fast"], b["frames_fast"])       # different clip per rank
     assert a["durations"] == [4] and a["inter_idx"] == [[0, 3]] and a["target_boxes"].shape == (4, 4)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus N` without torchrun starts its own ranks (one per GPU, rendezvous on 127.0.0.1) and keeps the one-line
+    contract; on a box without N devices every rank says so instead of dying in an assert (util/dist.py:210-247 is the reference's side)."""
+    import json
+    import subprocess
+    import sys
+
+    import bench
+
+    argv = bench.launcher_argv(4, ["--gpus", "4", "--steps", "7", "--dry-launch", "--warmup", "2"], 29777)
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in argv and "--nnodes=1" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29777"
+    i = argv.index(os.path.abspath(bench.__file__))
+    assert argv[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]  # the ranks get the caller's flags, minus the launcher's own
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "3", "--dry-launch"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "--nproc-per-node=2" in json.loads(lines[0])["launch"]
+    if not torch.cuda.is_available():  # no device here: the launched ranks must explain themselves and the exit code must propagate
+        r = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "needs 2 GPUs on this node" in r.stderr and r.stdout.strip() == ""

@@ -4,13 +4,15 @@
   cfg5  cfg3 with --no_fast, and cfg3 with --no_tsa   cfg1  T=8 k=5 res=224 L=20 (the reference's CPU-runnable case)
 
 (1) exact-fp32 mode of the HIP path against the CPU oracle's forward on the same seeded clip and weights: box / start-end
-    logits and attention weights of all six decoder layers within 1e-3, attention argmax indices exact, the 24 losses.
+    logits and attention weights of all six decoder layers within 1e-3, attention argmax indices exact (a differing row must
+    be a recorded fp32 tie between the oracle's top two), the 24 losses.
     The oracle forward runs once per config on the GPU box's host cores (tens of seconds at T=100).
 (2) bf16 (the mode every throughput number uses) against the fp32 mode of the same kernels at the same sizes: logits
     bound, the whole gradient's cosine >= 0.995 and length within 3 %, and for EVERY trainable parameter cosine >= 0.97 and
     norm within 15 % (measured worst cases recorded in the report; parameters whose gradient norm is below a quarter of the
     median one are judged on the absolute scale: error <= 5 % of the median norm).
-(3) exact-fp32 mode BACKWARD against the oracle's autograd at full size (cfg2, cfg1): every trainable parameter's gradient.
+(3) exact-fp32 mode BACKWARD against the oracle's autograd at full size (cfg3 = the headline, both cfg5 ablations, cfg2, cfg1):
+    every trainable parameter's gradient.
 (4) the BENCHMARKED batch: 16 clips per step at cfg3 (bench.py's default), fp32 forward against the oracle run per clip
     (videos are independent: batch statistics do not exist in the model, FrozenBN), and the bf16 step at 16 clips - forward
     and backward, the instances that carry the throughput number (256-row tiles, persistent / chained pointwise kernels,
@@ -117,19 +119,27 @@ def test_fp32_mode_matches_oracle_at_full_size(name):
         err = max((a[key].float().cpu() - b[key]).abs().max().item() for a, b in zip(layers, layers_ref))
         rec["max_err_" + key] = err
         assert err < LOGIT_TOL, (name, key, err)
-    # attention indices bit-exact: every row whose top-2 gap in the oracle exceeds the fp32 error bound must agree (rows
-    # below the bound are exact ties for any fp32 implementation; their count is recorded and must stay marginal)
+    # attention indices bit-exact: the HIP argmax equals the oracle's on every row; on a row where it does not, the index it picked
+    # must be the oracle's RUNNER-UP and the oracle's own top-2 gap must lie inside the fp32 error measured above (an exact tie
+    # for any fp32 implementation).  Such rows are not skipped: their count and their gaps are recorded in the report.
     for key in ("weights", "ca_weights"):
-        rows = ties = 0
+        rows, flips, gaps = 0, 0, []
         for a, b in zip(layers, layers_ref):
-            top2 = b[key].topk(2, dim=-1).values if b[key].shape[-1] > 1 else None
-            decided = (top2[..., 0] - top2[..., 1]) > 4 * rec["max_err_" + key] if top2 is not None else torch.ones(b[key].shape[:-1], dtype=torch.bool)
-            same = a[key].float().cpu().argmax(-1) == b[key].argmax(-1)
-            assert bool(same[decided].all()), (name, key)
-            rows += decided.numel()
-            ties += int((~decided).sum())
-        rec["argmax_rows_" + key], rec["argmax_undecided_" + key] = rows, ties
-        assert ties <= 0.01 * rows, (name, key, ties, rows)
+            am = a[key].float().cpu().argmax(-1)
+            rows += am.numel()
+            if b[key].shape[-1] == 1:
+                assert bool((am == 0).all())
+                continue
+            top2 = b[key].topk(2, dim=-1)
+            differ = am != top2.indices[..., 0]
+            if bool(differ.any()):
+                assert bool((am[differ] == top2.indices[..., 1][differ]).all()), (name, key, "argmax outside the oracle's top-2")
+                gap = (top2.values[..., 0] - top2.values[..., 1])[differ]
+                assert bool((gap <= 4 * rec["max_err_" + key]).all()), (name, key, gap.max().item(), rec["max_err_" + key])
+                flips += int(differ.sum())
+                gaps += [float(g_) for g_ in gap.flatten()]
+        rec["argmax_rows_" + key], rec["argmax_tied_rows_" + key], rec["argmax_tied_gaps_" + key] = rows, flips, sorted(gaps)[-8:]
+        assert flips <= 0.01 * rows, (name, key, flips, rows)
     assert sorted(ld) == sorted(ld_ref) and len(ld) == 24
     worst = 0.0
     for k_ in ld_ref:
@@ -216,7 +226,7 @@ def test_bf16_gradients_follow_fp32_mode_at_full_size(name):
 
 
 # ---- (3) full-size backward against the oracle's autograd ----------------------------------------------------------
-@pytest.mark.parametrize("name", ["cfg2", "cfg1"])
+@pytest.mark.parametrize("name", ["cfg3", "cfg5_no_fast", "cfg5_no_tsa", "cfg2", "cfg1"])
 def test_fp32_gradients_match_oracle_at_full_size(name):
     """loss.backward() of the exact-fp32 HIP path against the CPU oracle's autograd on the same clip and weights, at a
     BASELINE size: every trainable parameter's gradient (cosine and length), not a self-comparison."""

@@ -12,7 +12,7 @@ import torch
 
 TD_F32, TD_BF16 = 0, 1
 EXPECTED_ABI = 6  # td_abi_version() of the library these signatures were written against
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtubedetr_hip.so")
+_LIB_PATH = os.environ.get("TD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtubedetr_hip.so")  # (TD_HIP_LIB: an A/B build of the same ABI, tools/build_variant.sh)
 _lib = None
 
 

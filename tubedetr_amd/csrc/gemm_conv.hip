@@ -851,6 +851,333 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The 256 x 256 tile again, on a PHASED main loop (round 4).  conv_gemm_big_kernel above keeps its eight wavefronts in lock
+// step: once per K tile every wavefront issues its 8 DMA pieces and their address arithmetic back to back, then drains its own
+// DMA (vmcnt(0)) in front of the tile's one barrier - both SIMD-resident wavefronts are away from the matrix pipe at the same
+// moment (2840 cycles per K tile measured against 2 x 64 MFMAs x 17 = 2176).  Here
+//   * the wavefronts form two groups (0-3 / 4-7: one wavefront of each group per SIMD) that run the same instruction stream ONE
+//     BARRIER APART: a K tile is four phases of { load section | barrier | 16 MFMAs | barrier }, so while one group multiplies the
+//     other one reads its fragments and issues DMA - matrix beside memory on every SIMD, never matrix beside matrix;
+//   * DMA pieces are spread over the phases, two per wavefront and phase, and run 4-6 phases (about two K tiles) ahead of their
+//     first use; a load section ends with a COUNTED s_waitcnt vmcnt(7..10) that retires exactly the pieces the next phase reads
+//     and leaves everything younger in flight across the barriers - vmcnt(0) does not occur in the loop;
+//   * what is in flight lands in LDS regions whose last reader finished at least two barrier intervals earlier: the weight
+//     fragments of a tile are read once (phase 0) into 32 registers, so the weight half of a stage is free for tile kt + 2 from
+//     phase 2 of tile kt on; the activation rows are consumed a quarter per phase (the wavefront's M fragments 2q, 2q + 1), and
+//     tile kt + 1's quarters go into the other stage during phases 0 and 1;
+//   * s_setprio(1) around each MFMA cluster (the groups are in different roles at any time, so the arbiter has something to prefer).
+// Fragment reads are inline asm: the compiler's wait-count pass would put a vmcnt in front of any LDS read that may alias an
+// LDS-DMA in flight (here: always), i.e. re-serialise the loop; with asm reads it sees no LDS read in the loop and the
+// ordering is the counted waits + barriers written out below.  Ordering rules used (MI355X_MICROARCH.md, "Two waves per SIMD" 7):
+// RAW - the issuing wavefront's vmcnt, then a barrier, then the read (one phase later for either group); WAR - a region is
+// re-staged no earlier than two barrier intervals after its last read was issued (the reads are retired by the lgkmcnt(0) right
+// behind the next barrier).  Tiles past the end of K are issued with out-of-range offsets (zero fill, no traffic) so that the
+// counts are the same in every iteration.  Addressing (tap-uniform / pointwise), tile order and epilogue as in conv_gemm_big_kernel.
+#ifndef TD_ABL
+#define TD_ABL 0  // timing ablations of conv_gemm_big8_kernel (tools/build_variant.sh; results are WRONG with any bit set): 1 (was: no K walk), 2 no DMA, 4 no fragment reads, 8 no s_setprio
+#endif
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_read16(uint32_t addr) {
+  u32x4_t r;
+#if TD_ABL & 4
+  asm volatile("" : "=v"(r) : "v"(addr));
+#else
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+#endif
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int I>
+using ic = std::integral_constant<int, I>;
+
+template <bool TU>
+__global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
+  using T = u16;
+  constexpr int ES = 2, BM = 256, BN = 256, BK = 64, NW = 8, VEC = 8;
+  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
+  constexpr int STAGE = (BM + BN) * 128, WREG = BM * 128;  // one stage: activation rows, then weight rows (128 B per row)
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  constexpr int MAXT = 160;  // K tiles + 4 look-ahead / round-up entries (host: K <= 64 * (MAXT - 4))
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) uint4 ktab[MAXT];  // per K tile: {activation byte offset of the tile's tap / columns, tap, weight byte offset, in-range mask}
+
+  const td_conv_desc& d = p.d;
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int NT = d.Nc / BN;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mt = (seq / NT) * 8 + xcd, nt = seq - (seq / NT) * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (m0 >= p.M) return;
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;
+  const int HoWo = d.Ho * d.Wo;
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const int wy = wave >> 2, wx = wave & 3;  // wy is also the wavefront's group
+
+  // DMA piece q (0..3) of this wavefront on the activation side: tile rows xrow(q) .. + 8 = the part of QUARTER q (the rows the
+  // readers consume in phase q: M fragments 2q, 2q + 1 of both row groups) that this wavefront stages
+  uint32_t a_off[4];   // byte offset of the row (pointwise) / of tap (0, 0) of the row (TU; modulo 2^32)
+  uint32_t a_mask[4];  // bit (tap) set = the tap lies inside the image (pointwise: bit 0 = row below M)
+  const int RS = d.R * d.S;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + (wave >> 2) * WM + q * 32 + (wave & 3) * 8 + lrow;
+    const bool ok = m < p.M;
+    if constexpr (!TU) {
+      a_off[q] = (uint32_t)m * (uint32_t)p.K * ES;
+      a_mask[q] = ok ? 1u : 0u;  // (the table's tap is 0 for pointwise tiles)
+    } else {
+      const int mm = ok ? m : 0;
+      const int n = mm / HoWo;
+      const int rem = mm - n * HoWo;
+      const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+      const int hb = d.mode == 0 ? ho * d.stride - d.pad : ho + d.pad;
+      const int wb = d.mode == 0 ? wo * d.stride - d.pad : wo + d.pad;
+      a_off[q] = (uint32_t)(n * d.Hs * d.Ws + hb * d.Ws + wb) * (uint32_t)d.C * ES;
+      uint32_t msk = 0;
+      for (int r = 0; r < d.R; ++r) {
+        const int hs = d.mode == 0 ? hb + r : hb - r;
+        for (int sx = 0; sx < d.S; ++sx) {
+          const int ws = d.mode == 0 ? wb + sx : wb - sx;
+          const bool in = (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
+          msk |= (in ? 1u : 0u) << (r * d.S + sx);
+        }
+      }
+      a_mask[q] = ok ? msk : 0u;
+    }
+  }
+  const int lane_c = chunk * VEC;
+  uint32_t b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b_off[i] = ((uint32_t)(n0 + (i * NW + wave) * 8 + lrow) * (uint32_t)p.K + (uint32_t)lane_c) * ES;  // Nc % BN == 0: always inside
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a_off[q] += (uint32_t)lane_c * ES;
+  // The K walk is a TABLE in LDS, built once per workgroup: entry t = where tile t's 64 columns come from.  (As a running
+  // (tap, channel, pixel) state advanced in the loop it was ~35 dependent scalar instructions per advance, two advances per tile:
+  // 2697 -> 2239 cycles per K tile with the advance compiled out, tools/build_variant.sh abl1 - the scalar unit issues into the
+  // same in-order stream as the wavefront's MFMAs.)  Tile order: tap-inner = all R*S taps of one 64-channel chunk back to back
+  // (the workgroup's window stays L2-resident), else tap-major; pointwise: columns t*64.  Entries past K are marked invalid.
+  const int nk = p.K / BK;
+  const bool tap_inner = TU && p.tap_inner;
+  if (t < nk + 4) {  // (the loop runs an even number of tiles and looks two ahead)
+    uint32_t xo, tap = 0, wo;
+    if constexpr (TU) {
+      const int cpt = d.C / BK;
+      const int chunkc = tap_inner ? t / RS : t % cpt;
+      tap = tap_inner ? t - chunkc * RS : t / cpt;
+      const int r = (int)tap / d.S, sx = (int)tap - r * d.S;
+      const int pix = d.mode == 0 ? r * d.Ws + sx : -(r * d.Ws + sx);
+      xo = (uint32_t)(pix * d.C + chunkc * BK) * ES;
+      wo = (uint32_t)((int)tap * d.C + chunkc * BK) * ES;
+    } else {
+      xo = wo = (uint32_t)t * BK * ES;
+    }
+    ktab[t] = make_uint4(xo, t < nk ? tap : 0u, wo, t < nk ? 0xFFFFFFFFu : 0u);
+  }
+  // one activation piece (quarter q) / one weight piece (i) of the tile described by table entry e into `stage`; branch-free: an
+  // out-of-image tap, a row past M or a tile past K becomes the out-of-range offset through an all-ones / all-zeros mask
+  auto issue_x = [&](char* stage, int q, const u32x4_t& e) {
+    const uint32_t ok = (0u - ((a_mask[q] >> (e.y & 31)) & 1u)) & e.w;
+    uint32_t off = a_off[q] + e.x;  // a_off (TU) = byte offset of tap (0, 0) of the row (mod 2^32: may be "negative")
+    off = (off & ok) | (OOB & ~ok);
+#if TD_ABL & 2
+    asm volatile("" ::"v"(off));
+    return;
+#endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stage + ((wave >> 2) * WM + q * 32 + (wave & 3) * 8) * 128), 16, off, 0, 0, 0);
+  };
+  auto issue_w = [&](char* stage, int i, const u32x4_t& e) {
+    const uint32_t off = ((b_off[i] + e.z) & e.w) | (OOB & ~e.w);
+#if TD_ABL & 2
+    asm volatile("" ::"v"(off));
+    return;
+#endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(stage + WREG + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
+  };
+
+  const int lr = lane & 15, lg = lane >> 4;
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read addresses (LDS byte offsets; the 16-byte chunk index is XOR-swizzled by row & 7 = lr & 7, the k-step flips bit 6)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+  const uint32_t xa0 = lds0 + (uint32_t)((wy * WM + lr) * 128 + ((lg ^ (lr & 7)) << 4));
+  const uint32_t wa0 = lds0 + (uint32_t)(WREG + (wx * WN + lr) * 128 + ((lg ^ (lr & 7)) << 4));
+  const uint32_t xa[2][2] = {{xa0, xa0 ^ 64u}, {xa0 + STAGE, (xa0 ^ 64u) + STAGE}};  // [stage][k-step]: the offset field of a DS instruction holds 16 bits
+  const uint32_t wa[2][2] = {{wa0, wa0 ^ 64u}, {wa0 + STAGE, (wa0 ^ 64u) + STAGE}};
+  u32x4_t wreg[2][TN], xreg[2][2];  // [k-step][N fragment], [M fragment of the phase][k-step]
+
+  // table entries: tile kt in stage 0 -> ea = entry kt + 1 (its activations are staged in phases 0, 1), eb = entry kt + 2 (its weights in
+  // phases 2, 3; eb is read in phase 0 of the same tile and returns with that phase's fragments); tile kt + 1 in stage 1 swaps the roles
+  const uint32_t tab0 = (uint32_t)(uintptr_t)(lds_ptr_t)ktab;
+  uint32_t taddr = tab0 + 2 * 16;  // entry the next tile reads
+  u32x4_t ea, eb;
+  // one phase of the tile in stage S
+  auto phase = [&](auto S_, auto P_) {
+    constexpr int S = decltype(S_)::value, P = decltype(P_)::value;
+    u32x4_t& ex = S == 0 ? ea : eb;  // entry kt + 1
+    u32x4_t& ew = S == 0 ? eb : ea;  // entry kt + 2
+    char* const cur = smem + S * STAGE;
+    char* const oth = smem + (1 - S) * STAGE;
+    // ---- load section ----
+    if constexpr (P == 0) {
+      wreg[0][0] = lds_read16<0 * 2048>(wa[S][0]); wreg[0][1] = lds_read16<1 * 2048>(wa[S][0]);
+      wreg[0][2] = lds_read16<2 * 2048>(wa[S][0]); wreg[0][3] = lds_read16<3 * 2048>(wa[S][0]);
+    }
+    xreg[0][0] = lds_read16<(2 * P + 0) * 2048>(xa[S][0]);
+    xreg[1][0] = lds_read16<(2 * P + 1) * 2048>(xa[S][0]);
+    if constexpr (P == 0) {
+      wreg[1][0] = lds_read16<0 * 2048>(wa[S][1]); wreg[1][1] = lds_read16<1 * 2048>(wa[S][1]);
+      wreg[1][2] = lds_read16<2 * 2048>(wa[S][1]); wreg[1][3] = lds_read16<3 * 2048>(wa[S][1]);
+    }
+    xreg[0][1] = lds_read16<(2 * P + 0) * 2048>(xa[S][1]);
+    xreg[1][1] = lds_read16<(2 * P + 1) * 2048>(xa[S][1]);
+    if constexpr (P == 0) { ew = lds_read16<0>(taddr); taddr += 16; issue_x(oth, 0, ex); issue_x(oth, 1, ex); wait_vmcnt<8>(); }
+    if constexpr (P == 1) { issue_x(oth, 2, ex); issue_x(oth, 3, ex); wait_vmcnt<9>(); }
+    if constexpr (P == 2) { issue_w(cur, 0, ew); issue_w(cur, 1, ew); wait_vmcnt<10>(); }
+    if constexpr (P == 3) { issue_w(cur, 2, ew); issue_w(cur, 3, ew); wait_vmcnt<7>(); }
+    __builtin_amdgcn_s_barrier();
+    // ---- MFMA section ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#if !(TD_ABL & 8)
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][2 * P + j]) : "v"(wreg[ks][i]), "v"(xreg[j][ks]));  // accumulate in place
+#if !(TD_ABL & 8)
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- epilogue bookkeeping (as conv_gemm_big_kernel) ----
+  constexpr int CR = 16, NCH = WM / CR, EPL = 8, LPR = WN / EPL, RPI = 64 / LPR, NIT = CR / RPI, CPRW = WN / 4;
+  const int cc = lane % LPR, rsub = lane / LPR;
+  const int n = n0 + wx * WN + cc * EPL;
+  uint32_t offs[2][NIT];
+  bool live[2][NIT];
+  uint4 res[2][NIT], msk[2][NIT];
+  auto fetch_chunk = [&](int c, int b) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wy * WM + c * CR + it * RPI + rsub;
+      live[b][it] = m < p.M;
+      offs[b][it] = (uint32_t)min(m, p.M - 1) * (uint32_t)d.ldc + (uint32_t)n;
+      if (p.residual) res[b][it] = ld16(p.residual + offs[b][it] * ES);
+      if (p.mask_src) msk[b][it] = ld16(p.mask_src + offs[b][it] * ES);
+    }
+  };
+
+#define TD_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+  TD_STAMP(0);
+  __syncthreads();  // the K table is complete
+  // prologue = the issue order of the steady state: weights of tile 0, activations of tile 0, weights of tile 1
+  {
+    const u32x4_t e0 = lds_read16<0>(tab0);
+    ea = lds_read16<16>(tab0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_w(smem, i, e0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_x(smem, q, e0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_w(smem + STAGE, i, ea);
+  }
+  wait_vmcnt<7>();  // weights of tile 0 and activation quarter 0 have landed
+  __builtin_amdgcn_s_barrier();
+  if (wy == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind the first from here on
+  TD_STAMP(1);
+  // ONE loop over tile pairs and nothing else (an odd tile count is rounded up: the extra tile is zero fill without traffic) - an
+  // exit in the middle of the body makes the register allocator rename the accumulators across the two halves and spill them
+  const int npair = (nk + 1) / 2;
+#pragma unroll 1
+  for (int it = 0; it < npair; ++it) {
+    phase(ic<0>{}, ic<0>{}); phase(ic<0>{}, ic<1>{}); phase(ic<0>{}, ic<2>{}); phase(ic<0>{}, ic<3>{});
+    phase(ic<1>{}, ic<0>{}); phase(ic<1>{}, ic<1>{}); phase(ic<1>{}, ic<2>{}); phase(ic<1>{}, ic<3>{});
+  }
+  if (wy == 0) __builtin_amdgcn_s_barrier();  // pairs with the second group's last barrier
+  TD_STAMP(2);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // trailing zero-fill DMAs must not land in the staging regions below
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the asm MFMAs' results are read below: the hazard the compiler would pad for
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(acc[i][j]));
+  fetch_chunk(0, 0);
+  __builtin_amdgcn_s_barrier();  // every wavefront is done with the stage buffers: they become the staging regions
+  TD_STAMP(3);
+  float* stg = (float*)(smem + (wave < 4 ? 0 : STAGE) + (wave & 3) * (CR * WN * 4));
+  const float alpha = p.alpha;
+  float bias[EPL];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) bias[r] = p.bias ? p.bias[n + r] : 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int b = c & 1;
+#pragma unroll
+    for (int jj = 0; jj < CR / 16; ++jj) {
+      const int row = jj * 16 + lr;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int cx = (i * 4 + lg) ^ (row & (CPRW - 1));
+        const f32x4 a = acc[i][c * (CR / 16) + jj];
+        *(float4*)(stg + row * WN + cx * 4) = make_float4(a[0] * alpha, a[1] * alpha, a[2] * alpha, a[3] * alpha);
+      }
+    }
+    if (c + 1 < NCH) fetch_chunk(c + 1, b ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + rsub;
+      const int sw = row & (CPRW - 1);
+      float v[EPL];
+#pragma unroll
+      for (int q = 0; q < EPL / 4; ++q) {
+        const float4 f = *(const float4*)(stg + row * WN + (((cc * (EPL / 4) + q) ^ sw) * 4));
+        v[4 * q + 0] = f.x + bias[4 * q + 0]; v[4 * q + 1] = f.y + bias[4 * q + 1];
+        v[4 * q + 2] = f.z + bias[4 * q + 2]; v[4 * q + 3] = f.w + bias[4 * q + 3];
+      }
+      if (p.residual) {
+        float r8[EPL];
+        unpack16<T>(res[b][it], r8);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] += r8[r];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.mask_src) {
+        float m8[EPL];
+        unpack16<T>(msk[b][it], m8);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
+      }
+      if (live[b][it]) st16(p.out + offs[b][it] * ES, pack16<T>(v));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next chunk overwrites the region
+  }
+  TD_STAMP(5);
+#undef TD_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent, weight-stationary instance for the HBM-bound pointwise layers with K <= 256 (bottleneck conv3 forward,
 // conv1 dgrad: [M][K] x [Nc][K]^T with M in the 10^4..10^6 range).  In the tiled kernel above two thirds of such a
 // workgroup's HBM->LDS traffic is the weight tile it re-reads for every 64 rows, and with one K tile in flight per
@@ -1928,7 +2255,11 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
       static const int tap_inner = [] { const char* e_ = getenv("TD_CONV_TAP_INNER"); return e_ ? atoi(e_) : 1; }();
       p.tap_inner = tu && tap_inner && d->R * d->S > 1;
       dim3 gb(8 * cdiv(cdiv(p.M, 256), 8) * (d->Nc / bnb));
-      if (bnb == 256) {
+      static const int phased = [] { const char* e_ = getenv("TD_CONV_BIG_PHASED"); return e_ ? atoi(e_) : 1; }();  // (A/B: 0 = the lock-step main loop)
+      if (bnb == 256 && phased && p.K <= 64 * 156) {
+        if (tu) conv_gemm_big8_kernel<true><<<gb, 512, 0, st>>>(p);
+        else conv_gemm_big8_kernel<false><<<gb, 512, 0, st>>>(p);
+      } else if (bnb == 256) {
         if (tu) conv_gemm_big_kernel<256, true><<<gb, 512, 0, st>>>(p);
         else conv_gemm_big_kernel<256, false><<<gb, 512, 0, st>>>(p);
       } else {
