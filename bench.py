@@ -12,7 +12,7 @@ weights re-prepared every step (as after an optimizer step), all 125 trunk-forwa
 (`--dedupe` skips the 25 slow frames inside the fast pass).  `--clips-per-gpu B` videos per GPU per step (the
 reference's --batch_size, main.py:63; default 16: 288 GB of HBM hold the 111 GB this batch needs, and every latency-bound
 launch of the step - the 100-row-per-clip decoder, RoBERTa on 30 tokens per clip, the 12 100-row trunk backward - then does B
-times the work; measured in round 3: 86.9 / 87.2 / 91.4 clips/s at B = 8 / 12 / 16, profiles/README.md): `value` counts
+times the work; measured in round 3: 88.9 / 95.1 clips/s at B = 8 / 16 on one box, profiles/README.md): `value` counts
 clips, not steps.  Up to B = 8 the slow and the fast frames of a step share ONE trunk pass (1 000 frames); beyond that a pass
 would exceed the kernels' 32-bit tensor addressing (1 083 bf16 frames of res 352) and the slow frames (kept for backward) and
 the no-grad fast frames (two chunks of 800) run as separate passes.  Inputs are generated on the device before the timed region.
@@ -150,7 +150,8 @@ def cpu_baseline(T_sample, res, k, L, T_full):
     times.sort()
     med = times[len(times) // 2]
     per_clip = med * (T_full / T_sample)
-    return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": cores, "cpu": cpu_model_name(), "host_logical_cpus": os.cpu_count(), "kind": "port",
+    return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": cores, "cpu": cpu_model_name(), "host_logical_cpus": os.cpu_count(),
+            "kind": "port", "kind_detail": f"port, scaled from T={T_sample} to T={T_full} (not a measured T={T_full} pass)",
             "sample": f"fwd+bwd of a T={T_sample} clip (k={k}, res={res}, L={L}) by the CPU oracle, median {med:.1f}s of {len(times)} passes "
                       f"({', '.join(f'{t_:.1f}' for t_ in times)}) after one warm-up pass, scaled x{T_full}/{T_sample} to T={T_full}"}
 
@@ -463,12 +464,16 @@ def main():
             _trace(f"warm-up step {i} done")
     fence()
     _trace("timed region starts")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # one event per step boundary (no sync): the spread of the K steps
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         loss = step(a.warmup + i)
+        marks[i + 1].record()
     host_elapsed = time.perf_counter() - t0  # host-side enqueue time of the K steps (before waiting for the GPU)
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -520,15 +525,25 @@ def main():
                     hbm_bound = gbs / PEAK_HBM_GBS > tfl / peak  # the roof this family sits closer to
                     t_ = pmc.get(kname)
                     traffic = (t_["fetch_bytes_per_launch"] + t_["write_bytes_per_launch"]) if (t_ and t_.get("fetch_bytes_per_launch") and t_.get("write_bytes_per_launch")) else None
+                    traffic_why = None if traffic else "no committed PMC pass names this kernel family"
                     if traffic and pmc.get("_steps"):
-                        # per launch of THIS run's launch count: the PMC pass and the event-timed step may split a family's work into a
-                        # different number of launches (the batched weight gradients: an accumulating phase is a launch of its own)
-                        traffic = round(traffic * (t_["dispatches"] / pmc["_steps"]) / (n.value / a.roofline_steps))
+                        # The committed counters describe THIS run only if the family is launched as often per step here as in the PMC pass
+                        # (a kernel change that re-routes layers without re-taking profiles/ would otherwise report stale bytes).  The
+                        # batched weight gradients are exempt from equality - an accumulating phase is a launch of its own - and are
+                        # re-scaled to this run's launch count instead.
+                        pmc_per_step, here_per_step = t_["dispatches"] / pmc["_steps"], n.value / a.roofline_steps
+                        if fam in (2, 9) or abs(pmc_per_step - here_per_step) < 0.5:
+                            traffic = round(traffic * pmc_per_step / here_per_step)
+                        else:
+                            traffic, traffic_why = None, (f"stale: profiles/{PMC_TRAFFIC} saw {pmc_per_step:g} launches of this family per step, this run {here_per_step:g} "
+                                                          f"- re-take the PMC passes (tools/final_profile.sh)")
                     mu = mfma.get(kname, {}).get("mfma_util") if isinstance(mfma.get(kname), dict) else None
+                    if mu is not None and traffic is None and traffic_why and traffic_why.startswith("stale"):
+                        mu = None  # the same passes: stale with the traffic figure
                     rec = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
                            "achieved": round(gbs if hbm_bound else tfl, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tfl / peak), 4),
-                           "traffic": traffic,
+                           "traffic": traffic, "traffic_null_reason": traffic_why,
                            "traffic_source": (f"STATIC, not measured by this run: HBM bytes per launch from the committed rocprofv3 PMC passes of the same command "
                                               f"(FETCH_SIZE x2 + WRITE_SIZE, profiles/{PMC_TRAFFIC})") if traffic else None,
                            "mfma_util": mu, "mfma_util_source": (f"STATIC: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) over the family's launches, profiles/{PMC_MFMA}") if mu is not None else None,
@@ -560,7 +575,9 @@ def main():
         step_tflop = ALGO_TFLOP_PER_CLIP.get(a.workload)
         out = {
             "metric": ("training clips/sec (fwd+bwd) at T=100 k=4 res=352, 1/2/4/8 MI355X" if a.workload == "cfg3" else "training clips/sec (fwd+bwd)"), "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "clips_per_step_per_gpu": B, "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2),
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
+            "ms_per_step_min": round(step_ms[0], 2), "ms_per_step_median": round(step_ms[len(step_ms) // 2], 2), "ms_per_step_max": round(step_ms[-1], 2),
+            "clips_per_step_per_gpu": B, "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2),
             "peak_hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "execution": execution,

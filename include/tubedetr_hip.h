@@ -356,7 +356,8 @@ int td_cross_q1_fwd(const void* u, const void* mem, const void* pos, const uint8
                     int F, int S, int H, int E, int ldz, float dropout_p, uint32_t dropout_seed, const uint32_t* dropout_counter,
                     int dtype, td_stream_t stream);
 /* Backward: d_zext [F][ldz] T, dwavg [F][S] fp32 or NULL  ->  d_u [F][H*E] T and d_mem [F*S][E] FP32, overwritten when
- * accumulate == 0, else added to (the memory is shared by the six layers: the first layer to run writes, the others add).
+ * accumulate == 0, else added to (the memory is shared by the six layers: the first layer to run writes, the others add);
+ * d_mem == NULL: the memory needs no gradient, nothing is formed or stored.
  * pos receives no gradient here (sine encodings; learned ones use the projected-memory path). */
 int td_cross_q1_bwd(const void* u, const void* mem, const void* pos, const float* probs, const void* d_zext, const float* dwavg,
                     void* d_u, float* d_mem, int accumulate, int F, int S, int H, int E, int ldz, float dropout_p, uint32_t dropout_seed,

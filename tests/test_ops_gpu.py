@@ -927,6 +927,40 @@ def test_cross_attention_with_query_side_projections(cfg, dt):
         assert rel_err(a, b) < tol, n
 
 
+def test_cross_attention_query_side_with_a_memory_that_needs_no_gradient():
+    """memory.requires_grad = False (a frozen encoder): td_cross_q1_bwd gets d_mem = NULL - no [F*S, E] fp32 buffer is formed per
+    layer - and the query / parameter gradients equal those of the run that does differentiate the memory."""
+    from tubedetr_amd import functional as Fk
+
+    F_, S, E, H = 24, 151, 256, 8
+    g = torch.Generator().manual_seed(9)
+    r = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).to(dev())
+    tgt, qpos, mem, pos = r(F_, E), r(F_, E), r(F_ * S, E), r(F_ * S, E)
+    ps0 = [r(3 * E, E, s=1 / 16), r(3 * E, s=0.5), r(E, E, s=1 / 16), r(E, s=0.5)]
+    wo = r(F_, E)
+    out = []
+    for mem_grad in (True, False):
+        t_ = tgt.clone().requires_grad_(True)
+        m_ = mem.clone().requires_grad_(mem_grad)
+        ps = [p.clone().requires_grad_(True) for p in ps0]
+        anchor = Fk.cross_q1_memory(m_, pos)
+        x = t_
+        loss = 0.0
+        for _ in range(2):
+            o, _w = Fk.multihead_attention_q1(x, anchor, *ps, None, F_, S, H, need_weights=False, q_pos=qpos)
+            loss = loss + (o * wo).sum()
+            x = t_ + 0.1 * o
+        before = torch.cuda.memory_allocated()
+        torch.cuda.reset_peak_memory_stats()
+        loss.backward()
+        out.append(([t_.grad] + [p.grad for p in ps], torch.cuda.max_memory_allocated() - before, m_.grad))
+    (g1, peak1, mg1), (g0, peak0, mg0) = out
+    assert mg1 is not None and mg0 is None
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    assert peak1 - peak0 >= F_ * S * E * 4  # the fp32 d(memory) buffer exists only when the memory wants it
+
+
 def test_cross_attention_query_side_draws_the_same_dropout_mask_as_the_projected_path():
     """Same (seed, element index) dropout keys as td_mha_fwd with Lq = 1: with dropout on, the query-side formulation and the
     projected-memory path (functional.MHAFn) agree on outputs, returned weights and gradients."""

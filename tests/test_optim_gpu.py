@@ -137,6 +137,11 @@ def test_optimizer_checkpoint_is_torch_adamw_layout_and_ema_resumes():
     o3 = FusedAdamWEMA(m3, max_norm=0.0)
     o3.load_state_dict(sd_torch)
     assert o3.step_dev.item() == 2
+    # a save straight after the resume (before any step) writes back what was loaded: no state for the pooler, no zero moments
+    sd_again = o3.state_dict()
+    assert set(sd_again["state"]) == set(sd_torch["state"])
+    for i, st in sd_torch["state"].items():
+        assert float(sd_again["state"][i]["step"]) == 2.0 and torch.equal(sd_again["state"][i]["exp_avg"].cpu(), st["exp_avg"].cpu())
     grads()
     p2, p3 = dict(m2.named_parameters()), dict(m3.named_parameters())
     for n in names:

@@ -46,6 +46,9 @@ __device__ __forceinline__ void bn_store16(__amdgpu_buffer_rsrc_t rs, uint32_t o
   __builtin_amdgcn_raw_buffer_store_b128(bn_u32x4{v.x, v.y, v.z, v.w}, rs, (int)off, 0, 0);
 }
 #define TD_BN_OOB 0xFFFFFFF0u
+#ifndef TD_BN_ABL
+#define TD_BN_ABL 0  // timing ablations of bottleneck_resident_kernel (tools/build_variant.sh; wrong results): 1 no input loads, 2 no output stores
+#endif
 // Output rows leave through a wavefront-private 2-KiB LDS transposition: the MFMA layout gives a lane 4 consecutive channels of
 // one pixel (8-byte pieces, a store instruction touching 16 cache lines by 32 bytes); read back as 16 bytes per lane with 8 lanes
 // per pixel, a store instruction writes 8 whole 128-byte lines.
@@ -359,7 +362,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_resident_kernel(BneckParams
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         ok[j] = row < NHALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         const size_t off = ok[j] ? ((((size_t)img * p.H + y) * p.W + x) * CIN + c32 * 8) * 2 : (size_t)0;
+#if TD_BN_ABL & 1
+        v[j] = make_uint4(e, off, 0, 0);
+#else
         v[j] = *(const uint4*)(p.x + off);
+#endif
       }
 #pragma unroll
       for (int j = 0; j < LD; ++j) {
@@ -502,7 +509,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_resident_kernel(BneckParams
           const uint4 o16 = *(const uint4*)(stg + px_ * 128 + ((c ^ (px_ & 7)) << 4));
           const int yo = y0 + 2 * mb + ps, xo = x0 + (lane >> 3);
           const uint32_t off = (yo < p.H && xo < p.W) ? (uint32_t)(((((size_t)img * p.H + yo) * p.W + xo) * 256 + 64 * wave + 8 * c) * 2) : TD_BN_OOB;
+#if TD_BN_ABL & 2
+          asm volatile("" ::"v"(off), "v"(o16.x), "v"(o16.y), "v"(o16.z), "v"(o16.w));
+#else
           bn_store16(rs_out, off, o16);
+#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next row block overwrites the region
       }

@@ -315,6 +315,10 @@ __global__ __launch_bounds__(256) void cross_q1_bwd_kernel(CrossQ1Params p) {
 #pragma unroll
       for (int h = 0; h < QH; ++h) {
         du[h][0] += ds[h] * m[j].x; du[h][1] += ds[h] * m[j].y; du[h][2] += ds[h] * m[j].z; du[h][3] += ds[h] * m[j].w;
+      }
+      if (!p.dmem) continue;  // the memory needs no gradient (frozen encoder / no-grad memory): nothing is formed or stored
+#pragma unroll
+      for (int h = 0; h < QH; ++h) {
         g.x += ds[h] * ur[h][0] + pd[h] * dzr[h][0];
         g.y += ds[h] * ur[h][1] + pd[h] * dzr[h][1];
         g.z += ds[h] * ur[h][2] + pd[h] * dzr[h][2];
@@ -414,7 +418,8 @@ extern "C" int td_cross_q1_fwd(const void* u, const void* mem, const void* pos, 
 extern "C" int td_cross_q1_bwd(const void* u, const void* mem, const void* pos, const float* probs, const void* d_zext, const float* dwavg,
                                void* d_u, float* d_mem, int accumulate, int F, int S, int H, int E, int ldz, float dropout_p,
                                uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream) {
-  TD_REQUIRE(u && mem && probs && d_zext && d_u && d_mem, "td_cross_q1_bwd: null pointer");
+  TD_REQUIRE(u && mem && probs && d_zext && d_u, "td_cross_q1_bwd: null pointer");
+  TD_REQUIRE(d_mem || !accumulate, "td_cross_q1_bwd: accumulate without d_mem");
   TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "td_cross_q1_bwd: bad dtype %d", dtype);
   TD_REQUIRE(al16(u) && al16(mem) && al16(pos) && al16(d_zext) && al16(d_u) && al16(d_mem), "td_cross_q1_bwd: rows must be 16-byte aligned");
   CrossQ1Params p;
@@ -422,7 +427,7 @@ extern "C" int td_cross_q1_bwd(const void* u, const void* mem, const void* pos, 
   int rc = fill_q1(p, F, S, H, E, ldz, dropout_p, dropout_seed, dropout_counter, "td_cross_q1_bwd");
   if (rc) return rc;
   p.u = u; p.mem = mem; p.pos = pos; p.probs = (float*)probs; p.dz = d_zext; p.dwavg = dwavg; p.du = d_u; p.dmem = d_mem;
-  p.accumulate = accumulate ? 1 : 0;
+  p.accumulate = (accumulate && d_mem) ? 1 : 0;
   const int SP = (S + 3) & ~3;
   const size_t lds = (size_t)(3 * QH * SP + 4 * QH * QE) * sizeof(float);
   TD_REQUIRE(lds <= 64 * 1024, "td_cross_q1_bwd: S=%d too large for LDS", S);
@@ -431,7 +436,7 @@ extern "C" int td_cross_q1_bwd(const void* u, const void* mem, const void* pos, 
   if (prof) {
     prof_begin(TD_PROF_CROSS_Q1, dtype, 8.0 * F * S * QH * QE, st, F, S, QE, 0, 0, 1);
     const double es = dtype == TD_BF16 ? 2.0 : 4.0;
-    prof_set_bytes((double)F * S * QE * es * (pos ? 2.0 : 1.0) + (double)F * S * QE * 4.0 * (accumulate ? 2.0 : 1.0) + (double)F * QH * S * 4.0 +
+    prof_set_bytes((double)F * S * QE * es * (pos ? 2.0 : 1.0) + (d_mem ? (double)F * S * QE * 4.0 * (accumulate ? 2.0 : 1.0) : 0.0) + (double)F * QH * S * 4.0 +
                    (double)F * (2 * QH * QE + ldz) * es);
   }
   if (dtype == TD_BF16) cross_q1_bwd_kernel<u16><<<F, 256, lds, st>>>(p);

@@ -1358,6 +1358,213 @@ __global__ __launch_bounds__(256, 2) void pw_resident_kernel(GemmParams p, int M
 }
 
 // ------------------------------------------------------------------------------------------------
+// pw_resident_kernel again (round 4), re-pipelined.  What bounded the first form (5.0 - 5.4 TB/s of its algorithmic bytes) was
+// not bytes but requests in flight: per step a workgroup issued one activation tile + this tile's residual / mask rows, then
+// spent the rest of the step - MFMAs, an accumulator transposition through the activation buffer itself, three more barriers,
+// the stores - with nothing new on its way.  Here
+//   * the accumulator transposition has its own 4 KiB per wavefront (16 rows at a time; 2 x 32 KiB slots + 16 KiB = 80 KiB: still
+//     two workgroups per CU), so the activation slot of tile t is free right after the barrier that follows its MFMAs: tile t + 2
+//     is requested into it BEFORE the epilogue of tile t - two activation tiles in flight on a two-slot ring;
+//   * residual / mask rows are requested ONE TILE AHEAD into a second register set (inline-asm loads with counted waits; the
+//     compiler's own bookkeeping across the loop back edge would drain the queue), except for the residual + mask instances with
+//     K = 256, whose 128 weight-fragment registers leave no room: they request this tile's rows before the MFMAs, as before;
+//   * two barriers per step instead of four.
+// (Measured and dropped: the LDS-free epilogue of v_permlane16_swap - it stores 16 rows x 64 bytes per instruction instead of
+// 8 rows x 128: 4.0 instead of 5.3 TB/s on the layer3 conv3 shape.  Half-line requests are what an HBM-bound kernel cannot afford.)
+// Counted waits are derived from LOADS only (loads retire in issue order among themselves; stores in flight can only make a
+// wait stricter).  Same tile order, same arithmetic and rounding as pw_resident_kernel: bit-identical results.
+template <int NKT, bool RES, bool MSK>
+__global__ __launch_bounds__(256, 2) void pw_resident2_kernel(GemmParams p, int MT, int P) {
+  using T = u16;
+  constexpr int ES = 2;
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  constexpr int WM = 32, WN = 64, TM = 2, TN = 4;
+  constexpr int CPRW = WN / 4, EPL = 8, LPR = WN / EPL, RPI = 64 / LPR, NIT = WM / RPI;   // row-contiguous epilogue: 8 lanes x 16 bytes per 64-channel row segment
+  constexpr int NOPS = NIT * ((RES ? 1 : 0) + (MSK ? 1 : 0));      // operand loads per lane and step
+  constexpr bool AHEAD = NOPS > 0 && !(RES && MSK && NKT == 4);    // operand rows requested one tile ahead (register budget)
+  constexpr int NA = 2 * NKT;                                      // DMA pieces per wavefront and activation tile
+  constexpr int AUX_NT = (TD_NT & 2) ? 2 : 0;
+  __shared__ __attribute__((aligned(16))) char sA0[32768];
+  __shared__ __attribute__((aligned(16))) char sA1[32768];
+  __shared__ __attribute__((aligned(16))) char sT[4 * 16 * WN * 4];  // transposition staging: 16 rows x 64 fp32 per wavefront
+  const td_conv_desc& d = p.d;
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int NT = d.Nc >> 7;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int GPX = P / NT;                      // M-tile groups per XCD
+  const int nt = local % NT, gl = local / NT;
+  if (gl >= GPX) return;
+  const int gid = xcd * GPX + gl, G = 8 * GPX;
+  const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+  const uint32_t out_bytes = (uint32_t)p.M * (uint32_t)d.ldc * ES;  // (host: M * ldc < 2^31)
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.residual : p.out), 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)(MSK ? p.mask_src : p.out), 0, out_bytes, 0x00020000);
+  const int n0 = nt * 128;
+  const int HoWo = d.Ho * d.Wo;
+  const bool strided = d.stride != 1;
+  auto issue_A = [&](char* buf, int mt) {
+    const int m0 = mt * 64;
+    uint32_t row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + (i * 4 + wave) * 8 + lrow;
+      int src_row = m;
+      if (strided) {
+        const int img = m / HoWo, rem = m - img * HoWo;
+        const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+        src_row = (img * d.Hs + ho * d.stride) * d.Ws + wo * d.stride;
+      }
+      row[i] = (mt < MT && m < p.M) ? (uint32_t)src_row * (uint32_t)p.K * ES : OOB;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t off = row[i] != OOB ? row[i] + (uint32_t)(kt * 64 + chunk * 8) * ES : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(buf + kt * 8192 + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+      }
+  };
+  const int wy = wave >> 1, wx = wave & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int cc = lane % LPR, rsub = lane / LPR;
+  const int n = n0 + wx * WN + cc * EPL;
+  float bias[EPL];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) bias[r] = p.bias ? p.bias[n + r] : 0.f;
+  uint4 wfr[NKT][2][TN];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        wfr[kt][ks][i] = *(const uint4*)(p.w + ((size_t)(n0 + wx * WN + i * 16 + lr) * p.K + kt * 64 + ks * 32 + lg * 8) * ES);
+  const uint32_t drop_seed = p.drop_thresh ? effective_seed(p.seed, p.seed_dev) : 0u;
+  float* const stg = (float*)(sT + wave * (16 * WN * 4));
+
+  // byte offset of this lane's 16-byte segment of row-iteration `it` of tile mt; rows past M / tiles past MT: out of range
+  auto seg_off = [&](int mt, int it) -> uint32_t {
+    const int m = mt * 64 + wy * WM + it * RPI + rsub;
+    return (mt < MT && m < p.M) ? ((uint32_t)m * (uint32_t)d.ldc + (uint32_t)n) * ES : OOB;
+  };
+  u32x4_t res[2][NIT], msk[2][NIT];  // [register set][row iteration]
+  auto fetch_ops = [&](int mt, int b) {  // inline asm: invisible to the compiler's wait-count pass, waited for by count below
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const uint32_t off = seg_off(mt, it);
+      if constexpr (RES) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(res[b][it]) : "v"(off), "s"(rs_res) : "memory");
+      if constexpr (MSK) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(msk[b][it]) : "v"(off), "s"(rs_msk) : "memory");
+    }
+  };
+
+  // One step = tile mt in `cur`.  On entry: A(mt) and A(mt + G) are requested (in that order, into cur / nxt); with AHEAD the
+  // operand rows of tile mt sit behind A(mt + G) in the queue, in register set B.
+  auto step = [&](char* cur, char* nxt, int mt, auto B_) {
+    constexpr int B = decltype(B_)::value;
+    if constexpr (NOPS > 0 && !AHEAD) fetch_ops(mt, 0);
+    // A(mt) has landed: loads younger than its last piece = A(mt + G) [NA], + the operand rows requested since
+    wait_vmcnt<NA + NOPS>();
+    __builtin_amdgcn_s_barrier();
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int cidx = ks * 4 + lg;
+        uint4 af[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int row = wy * WM + j * 16 + lr;
+          af[j] = *(const uint4*)(cur + kt * 8192 + row * 128 + ((cidx ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) Mfma<T>::run(wfr[kt][ks][i], af[j], acc[i][j]);
+      }
+    // every wavefront is done with the activation tile: its slot takes tile mt + 2G now, ahead of this tile's epilogue
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_A(cur, mt + 2 * G);
+    if constexpr (AHEAD) fetch_ops(mt + G, B ^ 1);
+    // this tile's operand rows: younger loads = A(mt + 2G) [NA] (+ the rows of tile mt + G [NOPS]); without AHEAD they were
+    // requested at the top of the step, ahead of nothing but A(mt + 2G)
+    if constexpr (NOPS > 0) {
+      wait_vmcnt<NA + (AHEAD ? NOPS : 0)>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int RB = AHEAD ? B : 0;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {  // 16 rows at a time through the wavefront's private staging region (no workgroup barrier)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int c = (i * 4 + lg) ^ (lr & (CPRW - 1));
+        const f32x4 a = acc[i][j];
+        *(float4*)(stg + lr * WN + c * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < 16 / RPI; ++h) {
+        const int it = j * (16 / RPI) + h;
+        const int row = h * RPI + rsub;
+        const int sw = row & (CPRW - 1);
+        float v[EPL];
+#pragma unroll
+        for (int q = 0; q < EPL / 4; ++q) {
+          const float4 f = *(const float4*)(stg + row * WN + (((cc * (EPL / 4) + q) ^ sw) * 4));
+          v[4 * q + 0] = f.x + bias[4 * q + 0]; v[4 * q + 1] = f.y + bias[4 * q + 1];
+          v[4 * q + 2] = f.z + bias[4 * q + 2]; v[4 * q + 3] = f.w + bias[4 * q + 3];
+        }
+        const uint32_t off = seg_off(mt, it);
+        if constexpr (RES) {
+          float r8[EPL];
+          unpack16<T>(make_uint4(res[RB][it].x, res[RB][it].y, res[RB][it].z, res[RB][it].w), r8);
+#pragma unroll
+          for (int r = 0; r < EPL; ++r) v[r] += r8[r];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if constexpr (MSK) {
+          float m8[EPL];
+          unpack16<T>(make_uint4(msk[RB][it].x, msk[RB][it].y, msk[RB][it].z, msk[RB][it].w), m8);
+#pragma unroll
+          for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
+        }
+        if (p.drop_thresh) {  // (same element index as conv_gemm_kernel's epilogue and td_dropout: the backward regenerates this mask)
+#pragma unroll
+          for (int r = 0; r < EPL; ++r) v[r] = dropout_keep(drop_seed, off / ES + (uint32_t)r, p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
+        }
+        const uint4 o = pack16<T>(v);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o.x, o.y, o.z, o.w}, rs_out, (int)off, 0, AUX_NT);  // rows past M: discarded
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next 16 rows overwrite the region
+    }
+  };
+
+  int mt = gid;
+  issue_A(sA0, mt);
+  issue_A(sA1, mt + G);
+  if constexpr (AHEAD) fetch_ops(mt, 0);
+  while (mt < MT) {
+    step(sA0, sA1, mt, ic<0>{});
+    mt += G;
+    if (mt >= MT) break;
+    step(sA1, sA0, mt, ic<1>{});
+    mt += G;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (out-of-range) requests must not outlive the workgroup's LDS / registers
+}
+
+// ------------------------------------------------------------------------------------------------
 // Two chained pointwise layers in one persistent launch: out1 = relu(x W1^T + b1 + residual) (the conv3 + identity of a
 // layer1 bottleneck: K1 = 64 -> N1 = 256) and out2 = relu(out1 W2^T + b2) (conv1 of the NEXT bottleneck: 256 -> 64 / 128).
 // Both are HBM-bound and out1 (4 GB at 8 clips) is their dominant stream: run apart, the second layer reads all of it
@@ -2205,9 +2412,16 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
       const int nkt = p.K / 64;
       const bool hr = p.residual != nullptr, hm = p.mask_src != nullptr;
       dim3 g2(2 * n_cu);  // two resident workgroups per CU (64 KiB of LDS each)
+      static const int v2 = [] { const char* e_ = getenv("TD_PW_PERSIST_V2"); return e_ ? atoi(e_) : 1; }();  // (A/B: 0 = the first form)
+      const bool use2 = v2 && (double)p.M * d->ldc < 2147483647.0 && p.alpha == 1.f;
 #define TD_PWR(NK)                                                                                      \
   do {                                                                                                  \
-    if (hr && hm) pw_resident_kernel<NK, true, true><<<g2, 256, 0, st>>>(p, MTp, Pp);                  \
+    if (use2) {                                                                                         \
+      if (hr && hm) pw_resident2_kernel<NK, true, true><<<g2, 256, 0, st>>>(p, MTp, Pp);               \
+      else if (hr) pw_resident2_kernel<NK, true, false><<<g2, 256, 0, st>>>(p, MTp, Pp);               \
+      else if (hm) pw_resident2_kernel<NK, false, true><<<g2, 256, 0, st>>>(p, MTp, Pp);               \
+      else pw_resident2_kernel<NK, false, false><<<g2, 256, 0, st>>>(p, MTp, Pp);                      \
+    } else if (hr && hm) pw_resident_kernel<NK, true, true><<<g2, 256, 0, st>>>(p, MTp, Pp);           \
     else if (hr) pw_resident_kernel<NK, true, false><<<g2, 256, 0, st>>>(p, MTp, Pp);                  \
     else if (hm) pw_resident_kernel<NK, false, true><<<g2, 256, 0, st>>>(p, MTp, Pp);                  \
     else pw_resident_kernel<NK, false, false><<<g2, 256, 0, st>>>(p, MTp, Pp);                         \

@@ -722,9 +722,10 @@ class CrossQ1Fn(Function):
         Gv = ops.linear_wgrad(dctx, zext)  # dense [E, H*E + H]; (not through the batched launch: its job-table ring is sized for a few calls per step)
         ops.head_blocks_extract(Gv, 1.0, dW_in[2 * E :], db_in[2 * E :], H)
         first = sh.dmem is None
-        if first or not sh.want_dmem:
-            dmem = torch.empty((F * S, E), dtype=torch.float32, device=dev)
-            sh.dmem = dmem if sh.want_dmem else None
+        if not sh.want_dmem:
+            dmem = None  # the memory needs no gradient: the kernel neither forms nor stores it
+        elif first:
+            dmem = sh.dmem = torch.empty((F * S, E), dtype=torch.float32, device=dev)
         else:
             dmem = sh.dmem
         dwa = dwavg.contiguous().float() if dwavg is not None else None

@@ -79,7 +79,12 @@ class TubeDETR(nn.Module):
         self._idx_cache = LRUCache()
         from .position_encoding import PositionEmbeddingSine
 
-        pe = backbone[1] if hasattr(backbone, "__getitem__") else None
+        from .backbone import Joiner
+
+        # the sine fast path (encoding generated per clip by td_pos_sine, forward_split, want_pos=) needs THIS package's Joiner; any
+        # other backbone object is driven through the reference's plain forward(tensor_list) -> (features, pos) protocol
+        self._joiner = isinstance(backbone, Joiner)
+        pe = backbone[1] if self._joiner else None
         self._sine_pos = isinstance(pe, PositionEmbeddingSine)
         if self._sine_pos:
             transformer.sine_pos = (pe.num_pos_feats, float(pe.temperature))
@@ -166,7 +171,7 @@ class TubeDETR(nn.Module):
         b, t, k = len(durations), max(durations), self.stride
         # sine encoding: the transformer forms the positional operand from the (original) pad mask itself, see Joiner.forward
         want_pos = not self._sine_pos
-        merged = self.fast and samples_fast is not None and torch.is_grad_enabled() and samples_fast.tensors.shape[1:] == samples.tensors.shape[1:]
+        merged = self._joiner and self.fast and samples_fast is not None and torch.is_grad_enabled() and samples_fast.tensors.shape[1:] == samples.tensors.shape[1:]
         if merged:
             # one pass holds at most ResNetBody.max_frames frames (32-bit tensor addressing: 1 083 bf16 frames at res 352); a larger
             # batch runs the slow frames (kept for backward) and the no-grad fast frames (cut into equal chunks) as separate passes
@@ -193,7 +198,7 @@ class TubeDETR(nn.Module):
             (src, mask), pos = slow.decompose(), [pos_slow]
             src_fast_feat, mask_fast = fast.decompose()
         else:
-            features, pos = self.backbone(samples, want_pos=want_pos)
+            features, pos = self.backbone(samples, want_pos=want_pos) if self._joiner else self.backbone(samples)  # (a foreign backbone: the reference's protocol)
             src, mask = features[-1].decompose()
         dev = src.device
         dest = self._frame_index(durations, dev)
@@ -202,7 +207,7 @@ class TubeDETR(nn.Module):
         if self.fast:
             if not merged:
                 with torch.no_grad():  # the fast branch does not back-propagate into the backbone (tubedetr.py:128-129)
-                    features_fast, _ = self.backbone(samples_fast)
+                    features_fast, _ = self.backbone(samples_fast, want_pos=False) if self._joiner else self.backbone(samples_fast)  # its encoding is never used
                 src_fast_feat, mask_fast = features_fast[-1].decompose()
             src_fast = self._project(src_fast_feat)
         src = self._project(src)
@@ -419,7 +424,7 @@ class SetCriterion(nn.Module):
     def weight_matrix(self, weight_dict, nl: int, device) -> torch.Tensor:
         """[layers, 4] coefficients of ``weight_dict`` in the layout of ``forward_fused``'s loss matrix (0 where a loss has
         no weight), cached on the device: the weighted total is then one multiply + one sum."""
-        key = ("wm", tuple(sorted(weight_dict.items())), nl, str(device))
+        key = ("wm", tuple(sorted(weight_dict.items())), nl, str(device), frozenset(self._fused_keys))  # (the fused key set follows forward_fused's aux flag)
         m = self._pm_cache.get(key)
         if m is None:
             rows = []

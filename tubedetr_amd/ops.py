@@ -572,12 +572,12 @@ def cross_q1_fwd(u: Tensor, mem: Tensor, pos: Optional[Tensor], key_pad: Optiona
     return probs, wavg, zext
 
 
-def cross_q1_bwd(u: Tensor, mem: Tensor, pos: Optional[Tensor], probs: Tensor, d_zext: Tensor, dwavg: Optional[Tensor], d_mem: Tensor, accumulate: bool,
+def cross_q1_bwd(u: Tensor, mem: Tensor, pos: Optional[Tensor], probs: Tensor, d_zext: Tensor, dwavg: Optional[Tensor], d_mem: Optional[Tensor], accumulate: bool,
                  F: int, S: int, H: int, *, dropout_p: float = 0.0, seed: int = 0) -> Tensor:
-    """-> d_u [F, H*E]; d_mem [F*S, E] fp32 is overwritten (accumulate=False) or added to."""
+    """-> d_u [F, H*E]; d_mem [F*S, E] fp32 is overwritten (accumulate=False) or added to; None: the memory needs no gradient."""
     E = mem.shape[1]
     assert d_zext.shape == (F, H * E + H) and d_zext.is_contiguous() and d_zext.dtype == u.dtype and probs.is_contiguous()
-    assert d_mem.shape == (F * S, E) and d_mem.dtype == torch.float32 and d_mem.is_contiguous()
+    assert d_mem is None or (d_mem.shape == (F * S, E) and d_mem.dtype == torch.float32 and d_mem.is_contiguous())
     assert dwavg is None or (dwavg.dtype == torch.float32 and dwavg.is_contiguous() and dwavg.numel() == F * S)
     d_u = torch.empty((F, H * E), dtype=u.dtype, device=u.device)
     check(_hip.lib().td_cross_q1_bwd(ptr(u), ptr(mem), ptr(pos), ptr(probs), ptr(d_zext), ptr(dwavg), ptr(d_u), ptr(d_mem), int(bool(accumulate)), F, S, H, E,

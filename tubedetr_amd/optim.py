@@ -127,6 +127,7 @@ class FusedAdamWEMA:
         self.norm_clip = torch.zeros(2, dtype=torch.float32, device=dev)  # [total gradient norm, clip coefficient] of the last step
         self._ws = torch.empty(_hip.lib().td_grad_norm_ws_bytes(), dtype=torch.uint8, device=dev)
         self._active = None
+        self._loaded_active = None  # load_state_dict: which parameters the checkpoint held state for (until the first step decides)
         self._segs = None
 
     # ---- segments: maximal runs of parameters with the same (group, has-gradient) ----
@@ -192,7 +193,9 @@ class FusedAdamWEMA:
         (The EMA weights are not optimizer state: they live in ``ema_model.state_dict()``, checkpoint["model_ema"].)"""
         order = self._torch_order()
         step = float(self.step_dev.item())
-        active = self._active if self._active is not None else [True] * len(self.params)
+        # which parameters have state: those the step has updated; before the first step after a resume, those the loaded
+        # checkpoint held state for (a parameter without a gradient - RoBERTa's pooler - has none in torch's checkpoint either)
+        active = self._active if self._active is not None else (self._loaded_active if self._loaded_active is not None else [True] * len(self.params))
         state = {}
         for ti, pi in enumerate(order):
             if step == 0 or not active[pi]:
@@ -230,15 +233,18 @@ class FusedAdamWEMA:
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         step = 0.0
+        loaded = [False] * len(self.params)
         for ti, pi in zip(flat_ids, order):
             st = sd["state"].get(ti)
             if st is None:
                 continue
+            loaded[pi] = True
             o, p = self.offsets[pi], self.params[pi]
             self.exp_avg[o : o + p.numel()].view_as(p).copy_(st["exp_avg"])
             self.exp_avg_sq[o : o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
             step = max(step, float(st["step"]))
-        self.step_dev.fill_(int(step))
+        self.step_dev.fill_(int(step))  # (one step counter: torch's per-parameter steps are equal for every parameter that has state)
+        self._loaded_active = loaded if any(loaded) else None
         for g, saved in zip(self.param_groups, groups):
             g["lr"] = float(saved["lr"])
         self._lr_last = None
