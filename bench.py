@@ -223,6 +223,8 @@ def main():
     ap.add_argument("--ddp", action="store_true", help="N>1: use torch DistributedDataParallel like main.py:372-376 instead of the flat exchange")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one flat all-reduce after the whole backward instead of the staged, overlapped exchange")
     ap.add_argument("--grad-wire-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the wire")
+    ap.add_argument("--grad-collective", default="all_reduce", choices=["all_reduce", "rs_ag"],
+                    help="N>1: how the flat gradient buffer is averaged: one all-reduce per stage, or reduce-scatter + all-gather on the flat buffer (same result)")
     ap.add_argument("--frames", default="u8", choices=["u8", "fp32"],
                     help="input frames: u8 = decoded uint8 pixels normalised on the device (the input path of tubedetr_amd/data.py, default); "
                          "fp32 = host-normalised fp32 frames, the reference's collate format")
@@ -327,7 +329,7 @@ def main():
         for t_ in list(model.parameters()) + list(model.buffers()):
             torch.distributed.broadcast(t_.data, 0)
         late = [p_ for n_, p_ in model.named_parameters() if n_.startswith("backbone.") and p_.requires_grad] if staged else None
-        reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32, late=late)
+        reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32, late=late, collective=a.grad_collective)
         criterion.external_num_boxes = torch.ones(1, dtype=torch.float32, device=dev)
         reducer.always_communicate = a.force_ddp  # exercise the RCCL call in the 1-rank diagnostic
         set_split_backward(model, staged)
@@ -582,7 +584,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "execution": execution,
             "gradient_exchange": (None if not distributed else ("torch DDP (find_unused_parameters)" if a.ddp else
-                                  (f"staged flat all-reduce overlapped with the trunk backward, {a.grad_wire_dtype} on the wire" if staged else f"flat all-reduce after backward, {a.grad_wire_dtype} on the wire"))),
+                                  (f"staged flat {a.grad_collective} overlapped with the trunk backward, {a.grad_wire_dtype} on the wire" if staged else f"flat {a.grad_collective} after backward, {a.grad_wire_dtype} on the wire"))),
             "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, {B} clip(s)/GPU/step, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}, "
                                    f"frames={'uint8 pixels, normalised on the device' if a.frames == 'u8' else 'host-normalised fp32'}",
                        "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random init (reference scheme), seed 42+rank"},

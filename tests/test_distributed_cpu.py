@@ -226,8 +226,45 @@ def _eval_collectives(rank, world):
     assert all(torch.equal(d[k], torch.tensor(float(keys.index(k) + 1) * (rank + 1))) for k in keys)  # inputs untouched
 
 
+def _flat_rs_ag(rank, world):
+    """collective="rs_ag" (reduce-scatter + all-gather on the flat buffer, the remainder that does not divide by the world size
+    through a small all-reduce) gives bit for bit what the single all-reduce gives - plain and staged, fp32 and bf16 wire, a total
+    length that is odd."""
+    from tubedetr_amd.distributed import FlatGradAllReducer
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.head, self.trunk, self.tail = torch.nn.Linear(5, 3), torch.nn.Linear(7, 5), torch.nn.Linear(5, 3, bias=False)
+
+    def grads(m):
+        g = torch.Generator().manual_seed(77 + rank)
+        for p_ in m.parameters():
+            p_.grad = torch.randn(p_.shape, generator=g)
+
+    for wire in (torch.float32, torch.bfloat16):
+        res = {}
+        for coll in ("all_reduce", "rs_ag"):
+            m = M()
+            assert sum(p_.numel() for p_ in m.parameters()) % 2 == 1
+            grads(m)
+            red = FlatGradAllReducer(m.parameters(), wire, collective=coll)
+            red.reduce(attach=True)
+            m2 = M()
+            grads(m2)
+            red2 = FlatGradAllReducer(m2.parameters(), wire, late=list(m2.trunk.parameters()), collective=coll)
+            red2.launch(early=True)
+            red2.launch(early=False)
+            red2.finish(attach=True)
+            res[coll] = (red.flat.clone(), red2.flat.clone())
+        for a, b in zip(res["all_reduce"], res["rs_ag"]):
+            assert torch.equal(a, b), (wire, (a - b).abs().max())
+        assert torch.equal(res["rs_ag"][0], res["rs_ag"][1])  # staged == plain
+
+
 @pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce, _flat_rank_dependent_usage, _flat_staged_overlap,
-                                _eval_collectives])
+                                _flat_rs_ag, _eval_collectives])
 def test_world_size_2_gloo(fn):
     _run(fn)
 

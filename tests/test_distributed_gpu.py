@@ -284,3 +284,43 @@ def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step(te
         except Exception:
             pass
         dist.destroy_process_group()
+
+
+def test_reduce_scatter_all_gather_exchange_on_rccl():
+    """collective="rs_ag" through RCCL itself (a 1-rank group: the averaged buffer equals the input): the asynchronous
+    reduce-scatter / all-gather pair of the staged exchange, an odd buffer length (the remainder goes through an all-reduce),
+    fp32 and bf16 wire.  Bit-equality with the single all-reduce at world size 2 is the gloo test's (tests/test_distributed_cpu.py)."""
+    import torch.distributed as dist
+
+    from tubedetr_amd.distributed import FlatGradAllReducer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Linear(33, 65), torch.nn.Linear(65, 17), torch.nn.Linear(17, 3, bias=False)).to(dev)
+        assert sum(p.numel() for p in m.parameters()) % 2 == 1
+        for wire in (torch.float32, torch.bfloat16):
+            g = torch.Generator(device=dev).manual_seed(5)
+            for p in m.parameters():
+                p.grad = torch.randn(p.shape, generator=g, device=dev)
+            want = torch.cat([p.grad.flatten() for p in m.parameters()])
+            if wire == torch.bfloat16:
+                want = want.to(torch.bfloat16).float()
+            red = FlatGradAllReducer(m.parameters(), wire, late=list(m[1].parameters()), collective="rs_ag")
+            red.always_communicate = True
+            red.launch(early=True)
+            red.launch(early=False)
+            red.finish(attach=True)
+            torch.cuda.synchronize()
+            assert torch.equal(red.flat, want)
+            red2 = FlatGradAllReducer(m.parameters(), wire, collective="rs_ag")
+            red2.always_communicate = True
+            for p, v in zip(m.parameters(), torch.split(want, [p.numel() for p in m.parameters()])):
+                p.grad = v.view_as(p).clone()
+            red2.reduce(attach=False)
+            torch.cuda.synchronize()
+            assert torch.equal(red2.flat, want)
+    finally:
+        dist.destroy_process_group()

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "td_common.h"
 
@@ -45,9 +46,17 @@ typedef unsigned int bn_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void bn_store16(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(bn_u32x4{v.x, v.y, v.z, v.w}, rs, (int)off, 0, 0);
 }
+// 8-byte LDS store as inline asm.  A DS WRITE the compiler can see is preceded by s_waitcnt vmcnt(0) whenever an LDS-DMA may be in
+// flight (its wait-count pass applies alias information to DS reads only) - in the double-buffered kernel that would wait for the
+// NEXT tile's pieces at the first result written.  Ordering is what the surrounding code provides anyway: DS operations of a wavefront
+// execute in order, and every cross-wavefront hand-over goes through TD_BN_BARRIER (lgkmcnt(0) + s_barrier).
+__device__ __forceinline__ void bn_lds_store8(char* p, uint2 v) {
+  const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)p;
+  asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
 #define TD_BN_OOB 0xFFFFFFF0u
 #ifndef TD_BN_ABL
-#define TD_BN_ABL 0  // timing ablations of bottleneck_resident_kernel (tools/build_variant.sh; wrong results): 1 no input loads, 2 no output stores
+#define TD_BN_ABL 0  // timing ablations of the bottleneck_resident kernels (tools/build_variant.sh; wrong results): 1 no input loads, 2 no output stores
 #endif
 // Output rows leave through a wavefront-private 2-KiB LDS transposition: the MFMA layout gives a lane 4 consecutive channels of
 // one pixel (8-byte pieces, a store instruction touching 16 cache lines by 32 bytes); read back as 16 bytes per lane with 8 lanes
@@ -522,6 +531,281 @@ __global__ __launch_bounds__(256, 2) void bottleneck_resident_kernel(BneckParams
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bottleneck_resident_kernel again (round 4): 3.30 -> 2.68 ms per 1 000 frames.  With its loads AND its stores compiled out the
+// kernel above still needs 2.57 of its 3.29 ms (tools/build_variant.sh, TD_BN_ABL): it is bound by ~1 700 VALU instructions per
+// wavefront and 64-pixel tile around 160 MFMAs - per-element index arithmetic of the register-staged input pass (a division by 10
+// per 16-byte element), a swizzle recomputed for each of the 72 conv2 fragment reads (the halo row changes with tap and row
+// block), `inside` tests with another division per row block, 35 weight-fragment loads per tile, the identity unpacked and added
+// on the VALU - and each of a CU's two 80-KiB workgroups waits out its own load phase.  Same tiling and phases, but:
+//   * ONE workgroup of eight wavefronts per CU with the input tile DOUBLE-BUFFERED (2 x 56 KiB + 16 KiB h1 / h2 + 16 KiB output
+//     staging = 144 KiB): the DMA pieces of tile t + 1 (7 x 1 KiB per wavefront: 8 halo rows x one 64-channel chunk each, the
+//     XOR swizzle applied on the source side, out-of-image rows = out-of-range offset = zero fill) are issued before tile t is
+//     computed and waited for by count; no staging registers, no ds_write pass;
+//   * conv1 / conv2 outputs use a PADDED row pitch (144 bytes) instead of the XOR swizzle: every fragment address of phase 2 is
+//     "lane base + compile-time constant" (ds_read immediates), no per-read arithmetic;
+//   * every weight fragment and bias of the block lives in registers for the whole launch (136 + 24): nothing but DMA pieces and
+//     output stores is ever in the vector-memory queue; each phase's work is split eight ways: wavefront w -> channel group
+//     cg = w & 3 (16 / 16 / 64 channels in the three phases) x row-block half w >> 2;
+//   * biases seed the accumulators, and the identity is one more MFMA per fragment against a unit-matrix block;
+//   * tiles whose halo lies inside the image (81 of 121 per frame at res 352) take a path without any validity arithmetic.
+// What is left (ablations of this kernel): 1.83 ms with no memory operation at all, +0.1 for the stores, +0.5 for the loads -
+// a tile's compute (3.9 us) does not cover the landing time of the next tile's 51 KiB under load, and there is no LDS for a
+// third tile.  Measured and dropped: touching tile t + 2's lines a tile earlier to pull them into L2 (2.98 instead of 2.69 ms:
+// the extra requests cost more than the latency they hide); the same restructuring with two 4-wavefront workgroups per CU and a
+// single input buffer (2.74 ms).
+__global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParams p) {
+  constexpr int CIN = 256, NC = 4;
+  constexpr int TH = 8, TW = 8, HW = TW + 2;
+  constexpr int HROWS = 112;   // 100 halo pixels -> 7 blocks of 16 rows
+  constexpr int NP = 7;        // DMA pieces per wavefront and tile: row groups half*7 .. half*7 + 6 of channel chunk cg
+  constexpr int HP = 144;      // row pitch of h1 / h2: 128 bytes + 16 (bank spread without a swizzle)
+  constexpr int XBUF = NC * HROWS * 128;
+  // two distinct LDS objects: the compiler's wait-count pass then knows that a fragment read of one buffer cannot alias the DMA that
+  // is filling the other (one array would put a vmcnt(0) in front of the first read of every phase)
+  __shared__ __attribute__((aligned(16))) char xall0[XBUF];
+  __shared__ __attribute__((aligned(16))) char xall1[XBUF];
+  __shared__ __attribute__((aligned(16))) char h1[HROWS * HP];
+  __shared__ __attribute__((aligned(16))) char ostage[8][TD_BN_STAGE_BYTES];
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cg = wave & 3, half = wave >> 2;
+  const int lane0 = t & 63;
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const uint32_t x_bytes = (uint32_t)((size_t)p.N * p.H * p.W * CIN * 2);  // (host: N*H*W*256 < 2^31)
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (uint32_t)((size_t)p.N * p.H * p.W * 512), 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_p;
+
+  // ---- resident for the whole launch: every weight fragment and bias of the block.  Everything else that depends on the lane is
+  // recomputed per tile behind an empty asm the optimiser cannot see through (a dozen VALU operations per phase): hoisted out of
+  // the tile loop it is spilled, and a spill reload is waited for with vmcnt(0) - which drains the next tile's DMA ----
+  const int lr = lane0 & 15, lg = lane0 >> 4;
+  uint4 w1r[NC][2], w2r[18], w3r[4][2];
+#pragma unroll
+  for (int kc = 0; kc < NC; ++kc)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) w1r[kc][ks] = *(const uint4*)(p.w1 + ((size_t)(16 * cg + lr) * CIN + kc * 64 + ks * 32 + lg * 8) * 2);
+#pragma unroll
+  for (int ks = 0; ks < 18; ++ks) w2r[ks] = *(const uint4*)(p.w2 + ((size_t)(16 * cg + lr) * 576 + ks * 32 + lg * 8) * 2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) w3r[i][ks] = *(const uint4*)(p.w3 + ((size_t)(64 * cg + 16 * i + lr) * 64 + ks * 32 + lg * 8) * 2);
+  float b1v[4], b2v[4], b3v[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    b1v[q] = p.b1[16 * cg + 4 * lg + q];
+    b2v[q] = p.b2[16 * cg + 4 * lg + q];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b3v[i][q] = p.b3[64 * cg + 16 * i + 4 * lg + q];
+  }
+  auto tile_px_of = [&](int tile, int& y0, int& x0) -> uint32_t {
+    const int img = tile / tiles_per_img;
+    const int trem = tile - img * tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    y0 = ty * TH;
+    x0 = tx * TW;
+    return (uint32_t)((img * p.H + y0) * p.W + x0);
+  };
+  // the 7 pieces of `tile` (tiles past the end: out-of-range offsets, zero fill) into buffer `buf`
+  auto issue_tile = [&](int tile, char* xbuf) {
+    int y0, x0;
+    const uint32_t px = tile_px_of(tile, y0, x0);
+    const bool exists = tile < p.n_tiles;
+    const bool interior = exists && y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;  // wave-uniform: the whole halo lies inside the image
+    char* dst = xbuf + cg * (HROWS * 128) + half * NP * 1024;
+    // DMA piece k of this wavefront: halo rows (half*7 + k)*8 .. +7 of channel chunk cg; the lane's source 16 bytes are chunk
+    // (lane & 7) ^ lrow of its row (the swizzle of the LDS image, applied on the source side: the DMA destination is lane-linear)
+    int ln = lane0;
+    asm volatile("" : "+v"(ln));
+    const int lrow = ln >> 3;
+    const uint32_t lane_part = (uint32_t)(cg * 128 + (((ln & 7) ^ lrow) << 4));
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int row = (half * NP + k) * 8 + lrow;
+      const int hy = (row * 205) >> 11, hx = row - hy * HW;  // row / 10 for row < 1029
+      // source relative to the tile's first centre pixel (modulo 2^32: the halo is "negative")
+      uint32_t off = (px + (uint32_t)((hy - 1) * p.W + (hx - 1))) * (CIN * 2) + lane_part;
+      bool ok = row < 100;  // rows 100 .. 111 are padding (compile-time true for all but the last two pieces of the second half)
+      if (!interior) ok = ok && exists && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+      off = ok ? off : TD_BN_OOB;
+#if TD_BN_ABL & 1
+      asm volatile("" ::"v"(off));
+#else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_p)(dst + k * 1024), 16, off, 0, 0, 0);
+#endif
+    }
+  };
+
+  // one tile, input in buffer B (compile-time: the two buffers are different LDS objects)
+  auto process = [&](int tile, auto B_) {
+    constexpr int B = decltype(B_)::value;
+    char* const xb_w = B ? xall1 : xall0;
+    char* const xo_w = B ? xall0 : xall1;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int lr = lane & 15, lg = lane >> 4;
+    const int cyl = lr >> 3, cxl = lr & 7;  // centre pixel of row block mb, lane lr: (2 * mb + cyl, cxl)
+    int y0, x0;
+    const uint32_t tile_px = tile_px_of(tile, y0, x0);
+    const bool interior = y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;
+    // the other buffer was last read in phase 3 of the previous tile, behind that tile's closing barrier
+    issue_tile(tile + gridDim.x, xo_w);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");  // this tile's pieces (issued a tile ago) have landed; the next tile's stay in flight
+    TD_BN_BARRIER();
+    const char* const xb = xb_w;
+    // ================= phase 1: conv1 on the halo tile: channels 16*cg .. +15, row blocks 4*half .. (4 / 3 of the 7) =================
+    {
+      const char* const xa0 = xb + lr * 128 + ((lg ^ (lr & 7)) << 4) + half * (4 * 2048);  // k-step parity 0
+      const char* const xa1 = xb + lr * 128 + (((4 + lg) ^ (lr & 7)) << 4) + half * (4 * 2048);
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = f32x4{b1v[0], b1v[1], b1v[2], b1v[3]};  // the bias seeds the accumulator
+      // 8 k-steps x 4 row blocks, fragment reads double-buffered one k-step (4 reads, 4 MFMAs) ahead: with two reads per group the
+      // ~100-cycle LDS latency of each group was exposed behind 32 cycles of MFMA issue
+      uint4 fr[2][4];
+      auto load_g = [&](int ks8, uint4 (&dst)[4]) {  // (the second half's 4th block is rows 112 .. 127 of the chunk = LDS bytes of the next chunk: read, never used)
+        const char* base = ((ks8 & 1) ? xa1 : xa0) + (ks8 >> 1) * (HROWS * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = *(const uint4*)(base + j * 2048);
+      };
+      load_g(0, fr[0]);
+#pragma unroll
+      for (int ks8 = 0; ks8 < 8; ++ks8) {
+        if (ks8 + 1 < 8) load_g(ks8 + 1, fr[(ks8 + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w1r[ks8 >> 1][ks8 & 1], *(const bf16x8*)&fr[ks8 & 1][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      char* const hw = h1 + (half * 64 + lr) * HP + (16 * cg + 4 * lg) * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint2 o;
+        o.x = bn_cvt_pk(fmaxf(acc[j][0], 0.f), fmaxf(acc[j][1], 0.f));
+        o.y = bn_cvt_pk(fmaxf(acc[j][2], 0.f), fmaxf(acc[j][3], 0.f));
+        if (!interior) {  // outside the image: conv2's zero padding (an interior tile has no such pixel; rows >= 100 are never read)
+          const int row = (half * 4 + j) * 16 + lr;
+          const int hy = (row * 205) >> 11, hx = row - hy * HW;
+          const bool inside = (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+          o.x = inside ? o.x : 0u;
+          o.y = inside ? o.y : 0u;
+        }
+        if (half * 4 + j < 7) bn_lds_store8(hw + j * 16 * HP, o);  // (wave-uniform; the 8th block does not exist)
+      }
+    }
+    TD_BN_BARRIER();  // h1 complete
+    // ================= phase 2: conv2 3x3: channels 16*cg .. +15, centre row blocks 2*half, 2*half + 1 =================
+    {
+      const char* const hr2 = h1 + ((4 * half + cyl) * HW + cxl) * HP + lg * 16;  // + ((2j + r) * HW + s) * HP + parity * 64
+      f32x4 acc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = f32x4{b2v[0], b2v[1], b2v[2], b2v[3]};
+      // 9 taps x (2 channel halves x 2 row blocks), fragment reads double-buffered one tap (4 reads, 4 MFMAs) ahead
+      uint4 fr[2][4];
+      auto load_t = [&](int tap, uint4 (&dst)[4]) {
+        const int r = tap / 3, s_ = tap - 3 * r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) dst[h * 2 + j] = *(const uint4*)(hr2 + ((2 * j + r) * HW + s_) * HP + h * 64);
+      };
+      load_t(0, fr[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) load_t(tap + 1, fr[(tap + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w2r[tap * 2 + h], *(const bf16x8*)&fr[tap & 1][h * 2 + j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      TD_BN_BARRIER();  // every wavefront has read its last h1 fragment: h2 overwrites it
+      char* const hw = h1 + (half * 32 + lr) * HP + (16 * cg + 4 * lg) * 2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        uint2 o;
+        o.x = bn_cvt_pk(fmaxf(acc[j][0], 0.f), fmaxf(acc[j][1], 0.f));
+        o.y = bn_cvt_pk(fmaxf(acc[j][2], 0.f), fmaxf(acc[j][3], 0.f));
+        bn_lds_store8(hw + j * 16 * HP, o);
+      }
+    }
+    TD_BN_BARRIER();  // h2 complete
+    // ================= phase 3: conv3 + identity + ReLU: channels 64*cg .. +63, centre row blocks 2*half, 2*half + 1 =================
+    {
+      // The identity goes through the matrix pipe: one more MFMA per N fragment with a 16 x 32 "weight" block that is the unit
+      // matrix in its first 16 columns - the activation operand is the pixel's 16 channels 64*cg + 16i .. of the input tile still
+      // in LDS (lane group lg < 2 reads channels 16i + 8lg .. + 7, groups 2, 3 read the same bytes against zero weights).
+      // bf16 x 1.0 accumulated in fp32 is exact, and it replaces an 8-byte LDS read + 10 VALU operations (unpack, add) per fragment.
+      uint4 eye = make_uint4(0u, 0u, 0u, 0u);  // row (channel) lr, columns 8*lg .. + 7: 1.0 (0x3F80) at column lr
+      if ((lr >> 3) == lg) {
+        const uint32_t one = 0x3F80u << (16 * (lr & 1));
+        const int d2 = (lr & 7) >> 1;
+        eye.x = d2 == 0 ? one : 0u; eye.y = d2 == 1 ? one : 0u; eye.z = d2 == 2 ? one : 0u; eye.w = d2 == 3 ? one : 0u;
+      }
+      const int hp0 = (4 * half + cyl + 1) * HW + cxl + 1;                       // halo row of the lane's centre pixel in its first row block (+ 20 for the second)
+      const char* const idb = xb + cg * (HROWS * 128) + hp0 * 128;
+      const uint32_t idk = (uint32_t)(((lg & 1) ^ (hp0 & 7)) << 4);              // 16-byte chunk (2i | lg & 1) ^ (row & 7) = 32i ^ idk ^ (second block: 64)
+      const char* const hr3 = h1 + (half * 32 + lr) * HP + lg * 16;              // + j * 16 * HP + ks * 64
+      char* const stw = ostage[wave] + lr * 128 + (lg & 1) * 8;
+      const uint32_t stk = (uint32_t)(((lg >> 1) ^ (lr & 7)) << 4);
+      const char* const strd = ostage[wave] + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + ps * 1024
+      const uint32_t st_lane = (uint32_t)((lane >> 3) * 512 + cg * 128 + (lane & 7) * 16);
+      const bool full = y0 + TH <= p.H && x0 + TW <= p.W;  // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int mb = 2 * half + j;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{b3v[i][0], b3v[i][1], b3v[i][2], b3v[i][3]};  // the bias seeds the accumulator
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const uint4 a = *(const uint4*)(hr3 + j * 16 * HP + ks * 64);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w3r[i][ks], *(const bf16x8*)&a, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint4 xi = *(const uint4*)(idb + j * (2 * HW * 128) + (idk ^ (uint32_t)(32 * i) ^ (uint32_t)(j * 64)));
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&eye, *(const bf16x8*)&xi, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint2 o;
+          o.x = bn_cvt_pk(fmaxf(acc[i][0], 0.f), fmaxf(acc[i][1], 0.f));
+          o.y = bn_cvt_pk(fmaxf(acc[i][2], 0.f), fmaxf(acc[i][3], 0.f));
+          bn_lds_store8(stw + (stk ^ (uint32_t)(32 * i)), o);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {  // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
+          const uint4 o16 = *(const uint4*)(strd + ps * 1024);
+          uint32_t off = (tile_px + (uint32_t)((2 * mb + ps) * p.W)) * 512u + st_lane;
+          if (!full) off = (y0 + 2 * mb + ps < p.H && x0 + (lane >> 3) < p.W) ? off : TD_BN_OOB;
+#if TD_BN_ABL & 2
+          asm volatile("" ::"v"(off), "v"(o16.x), "v"(o16.y), "v"(o16.z), "v"(o16.w));
+#else
+          bn_store16(rs_out, off, o16);
+#endif
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next row block overwrites the region
+      }
+    }
+    TD_BN_BARRIER();  // every wavefront is done with the tile: h1 and this input buffer may be overwritten
+  };
+  issue_tile(blockIdx.x, xall0);
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += 2 * gridDim.x) {
+    process(tile, std::integral_constant<int, 0>{});
+    if (tile + (int)gridDim.x >= p.n_tiles) break;
+    process(tile + gridDim.x, std::integral_constant<int, 1>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (out-of-range) pieces must not outlive the workgroup's LDS
+}
+
 }  // namespace td
 using namespace td;
 
@@ -557,7 +841,9 @@ extern "C" int td_bottleneck_fused(const void* x, void* out, const void* w1, con
   }
   static const int per_cu = [] { const char* e = getenv("TD_BNECK_WG_PER_CU"); return e ? std::max(1, atoi(e)) : 2; }();  // (A/B: persistent workgroups per CU)
   const int grid = (int)std::min<long long>(nt, (long long)per_cu * n_cu);
+  static const int v3 = [] { const char* e = getenv("TD_BNECK_V3"); return e ? atoi(e) : 1; }();  // (A/B: 0 = the register-staged form, two workgroups per CU)
   if (Cin == 64) bottleneck_fused_kernel<64, true><<<grid, 256, 0, st>>>(p);
+  else if (res256 && v3) bottleneck_resident3_kernel<<<(int)std::min<long long>(nt, (long long)n_cu), 512, 0, st>>>(p);
   else if (res256) bottleneck_resident_kernel<<<grid, 256, 0, st>>>(p);
   else bottleneck_fused_kernel<256, false><<<grid, 256, 0, st>>>(p);
   if (prof) prof_end(st);

@@ -34,8 +34,36 @@ def _all_reduce(t: torch.Tensor, op, group=None) -> None:
         dist.all_reduce(t, op=op, group=group)
 
 
+def _reduce_scatter_all_gather(buf: torch.Tensor, shard: torch.Tensor, op, group=None, async_op: bool = False):
+    """Average / sum the 1-D ``buf`` over the ranks as an explicit reduce-scatter + all-gather pair on the flat buffer (what a ring
+    all-reduce is made of, as two collectives the backend may schedule over all xGMI links independently; it is also where a
+    sharded optimizer step would go: between the two, each rank holds the reduced values of ITS slice).  The part of ``buf`` that
+    does not divide by the world size (< world elements) goes through a plain all-reduce.  ``shard``: scratch of at least
+    ceil(len / world) elements of buf's dtype.  Returns the work handles (async) or None."""
+    world = dist.get_world_size(group)
+    n = buf.numel()
+    m = n - n % world
+    works = []
+    host = buf.is_cuda and dist.get_backend(group) == "gloo"  # (CPU tests with a device buffer: staged through the host, synchronous)
+    if host:
+        hb = buf.cpu()
+        _reduce_scatter_all_gather(hb, torch.empty(max(1, m // world), dtype=hb.dtype), op, group)
+        buf.copy_(hb)
+        return None
+    if m:
+        sh = shard[: m // world]
+        w1 = dist.reduce_scatter_tensor(sh, buf[:m], op=op, group=group, async_op=async_op)
+        # (collectives of one group run in issue order on the backend's stream: the gather reads the scattered shard)
+        w2 = dist.all_gather_into_tensor(buf[:m], sh, group=group, async_op=async_op)
+        works += [w1, w2]
+    if n - m:
+        works.append(dist.all_reduce(buf[m:], op=op, group=group, async_op=async_op))
+    return works if async_op else None
+
+
 class FlatGradAllReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], wire_dtype: torch.dtype = torch.float32, group=None, late=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], wire_dtype: torch.dtype = torch.float32, group=None, late=None,
+                 collective: str = "all_reduce"):
         """``late``: optional set of parameters (or ids) whose gradient only becomes final in the LAST backward stage (the
         ResNet trunk when the step is split at the trunk boundary, harness.backward_in_stages): everything else is
         exchanged by ``launch(early=True)`` while that stage still runs - the overlap DDP's bucketed reducer gives the
@@ -63,6 +91,12 @@ class FlatGradAllReducer:
             else:
                 self.runs.append([off, off + p.numel(), lt])
             off += p.numel()
+        assert collective in ("all_reduce", "rs_ag")
+        self.collective = collective  # "rs_ag": reduce-scatter + all-gather on the flat buffer instead of one all-reduce (same result)
+        self._shard = None
+        if collective == "rs_ag":
+            longest = max((b - a for a, b, _ in self.runs), default=n) if late else n
+            self._shard = torch.zeros(max(1, -(-max(longest, 1) // max(self.world, 1))), dtype=self.wire.dtype, device=dev)
         self._pending: list = []
         self.always_communicate = False  # diagnostic: issue the collective even in a 1-rank group
         self._had_grad: Optional[List[bool]] = None     # which parameters had a local gradient at the last gather()
@@ -117,14 +151,22 @@ class FlatGradAllReducer:
             return
         avg = dist.is_initialized() and dist.get_backend(self.group) == "nccl"  # RCCL averages in the reduction itself
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        red = (lambda t_: _reduce_scatter_all_gather(t_, self._full_shard(), op, self.group)) if self.collective == "rs_ag" else \
+            (lambda t_: _all_reduce(t_, op, self.group))
         if self.wire is not self.flat:
             self.wire.copy_(self.flat)
-            _all_reduce(self.wire, op, self.group)
+            red(self.wire)
             self.flat.copy_(self.wire)
         else:
-            _all_reduce(self.flat, op, self.group)
+            red(self.flat)
         if not avg:
             self.flat.div_(self.world)
+
+    def _full_shard(self) -> torch.Tensor:
+        need = -(-self.numel // max(self.world, 1))
+        if self._shard is None or self._shard.numel() < need:
+            self._shard = torch.zeros(need, dtype=self.wire.dtype, device=self.flat.device)
+        return self._shard
 
     # ---- staged form: exchange what is final while the rest of backward still runs ----
     def gather_stage(self, early: bool) -> None:
@@ -154,6 +196,14 @@ class FlatGradAllReducer:
             if self.wire is not self.flat:
                 self.wire[a:b].copy_(buf)
                 buf = self.wire[a:b]
+            if self.collective == "rs_ag":
+                # (one scratch shard per run in flight: the runs of a stage are exchanged back to back on the backend's stream)
+                shard = torch.empty(max(1, -(-(b - a) // max(self.world, 1))), dtype=buf.dtype, device=buf.device) if self._pending else self._full_shard()
+                # (async only where collectives of a group are stream-ordered - RCCL; gloo runs async operations on independent threads:
+                #  the gather could read the shard before the scatter has written it)
+                works = _reduce_scatter_all_gather(buf, shard, op, self.group, async_op=dist.get_backend(self.group) == "nccl")
+                self._pending.append((works, a, b, avg))
+                continue
             if buf.is_cuda and dist.get_backend(self.group) == "gloo":  # host-staged (tests): synchronous
                 _all_reduce(buf, op, self.group)
                 work = None
@@ -172,8 +222,9 @@ class FlatGradAllReducer:
         (attach=True: ``.grad`` becomes the view of the flat buffer; False: copied back into the existing ``.grad``; None:
         nothing - the views were attached earlier, e.g. when the step replays from HIP graphs)."""
         for work, a, b, avg in self._pending:
-            if work is not None:
-                work.wait()
+            for w_ in (work if isinstance(work, (list, tuple)) else [work]):
+                if w_ is not None:
+                    w_.wait()
             if self.wire is not self.flat:
                 self.flat[a:b].copy_(self.wire[a:b])
             if not avg:
