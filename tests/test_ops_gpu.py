@@ -293,6 +293,28 @@ def test_frozen_bn_fold_and_mask_epilogues(dt):
     assert rel_err(dW, dW_ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("cfg", [(3, 128, 16, 12, 128), (2, 256, 8, 10, 256), (2, 64, 6, 6, 192), (1, 512, 4, 6, 512)])
+def test_stride2_3x3_dgrad_by_output_parity(cfg):
+    """Input gradient of a 3x3 / stride 2 / pad 1 convolution on an even-sized input (the second conv of layer2.0 / 3.0 / 4.0): bf16 runs
+    it as four parity-class forward-geometry launches over g (1x1 / 1x2 / 2x1 / 2x2 sub-filters taken as column blocks of w_dgrad,
+    output stride 2) - against torch's conv2d_input, with the residual + mask epilogue, incl. the last row / column whose second tap
+    falls outside g."""
+    from tubedetr_amd import ops
+
+    N, Co, Hg, Wg, Ci = cfg  # g [N, Co, Hg, Wg] -> dx [N, Ci, 2Hg, 2Wg]
+    dt = torch.bfloat16
+    H, W = 2 * Hg, 2 * Wg
+    g = torch.Generator().manual_seed(21 + Co)
+    w = rnd((Co, Ci, 3, 3), g, dt, 1.0 / math.sqrt(Ci * 9))
+    _, wd, _, _ = ops.weight_prep(w.to(dev()), dt)
+    gy, r, m = rnd((N, Co, Hg, Wg), g, dt), rnd((N, Ci, H, W), g, dt), rnd((N, Ci, H, W), g, dt)
+    ref = (torch.nn.grad.conv2d_input((N, Ci, H, W), w.to(dev()), gy.to(dev()), stride=2, padding=1) + r.to(dev())) * (m.to(dev()) > 0)
+    dx = ops.conv_dgrad(nhwc(gy, dt), wd, (H, W), 3, 3, 2, 1, residual=nhwc(r, dt), mask_src=nhwc(m, dt))
+    assert rel_err(from_nhwc(dx), ref) < TOL[dt]
+    dx2 = ops.conv_dgrad(nhwc(gy, dt), wd, (H, W), 3, 3, 2, 1)  # no epilogue operands
+    assert rel_err(from_nhwc(dx2), torch.nn.grad.conv2d_input((N, Ci, H, W), w.to(dev()), gy.to(dev()), stride=2, padding=1)) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_strided_1x1_dgrad_scatter(dt):
     from tubedetr_amd import ops

@@ -8,7 +8,7 @@ from tubedetr_amd import ops
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 125
 dev = torch.device("cuda:0")
 SHAPES = [  # (H=W, C, stride): layer3 / layer2 / layer4 conv2 and the strided first blocks
-    (22, 256, 1), (44, 128, 1), (11, 512, 1), (44, 256, 2), (88, 128, 2)]
+    (22, 256, 1), (44, 128, 1), (11, 512, 1), (44, 256, 2), (88, 128, 2), (22, 512, 2)]
 g = torch.Generator(device=dev).manual_seed(0)
 
 
@@ -34,6 +34,14 @@ for H, Cc, st in SHAPES:
     us = timeit(lambda: ops.conv_fwd(x, wf, bias, 3, 3, st, 1, relu=True, out=y))
     fl = 2.0 * frames * Ho * Ho * Cc * 9 * Cc
     print(f"fwd   N={frames} {H}x{H} C={Cc} s{st}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s")
+    if st == 2 and H % 2 == 0:  # input gradient of the stride-2 layer (TD_DGRAD_S2_PARITY: four parity-class launches vs one 9-tap gather)
+        nb = max(1, frames // 5)    # backward runs on the slow frames only
+        gy = torch.randn(nb, Ho, Ho, Cc, device=dev, generator=g).bfloat16()
+        wd = (torch.randn(Cc, 9 * Cc, device=dev, generator=g) * 0.02).bfloat16()
+        act = torch.randn(nb, H, H, Cc, device=dev, generator=g).relu().bfloat16()
+        dx = torch.empty(nb, H, H, Cc, device=dev, dtype=torch.bfloat16)
+        us = timeit(lambda: ops.conv_dgrad(gy, wd, (H, H), 3, 3, 2, 1, mask_src=act, out=dx))
+        print(f"dgrad N={nb} {H}x{H} C={Cc} s2: {us:8.1f} us  {2.0 * nb * Ho * Ho * Cc * 9 * Cc / us / 1e6:7.1f} TF/s (nominal 9-tap FLOPs)")
     if st == 1:
         gy = torch.randn(frames, Ho, Ho, Cc, device=dev, generator=g).bfloat16()
         wd = (torch.randn(Cc, 9 * Cc, device=dev, generator=g) * 0.02).bfloat16()

@@ -806,6 +806,226 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (out-of-range) pieces must not outlive the workgroup's LDS
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block 0 of layer1 (64 -> 64 -> 256 with the 1x1 downsample branch as its identity) in the form of bottleneck_resident3_kernel:
+// one workgroup of eight wavefronts per CU, 8 x 16 output tiles, the 10 x 18 halo tile of the 64-channel input (23 KiB) DMA'd into
+// one of two LDS buffers a tile ahead (3 pieces per wavefront), conv1 / conv2 results at a padded 144-byte pitch (fragment reads of
+// phase 2 are lane base + immediate), ALL weight fragments and biases resident in registers (8 + 72 + 32 + 32 + 24), biases seeding
+// the accumulators, wavefront w -> channel group w & 3 x row-block half w >> 2, no validity arithmetic for tiles whose halo lies
+// inside the image.  bottleneck_fused_kernel<64, true> above spends ~1 400 VALU instructions per wavefront and tile on element
+// index arithmetic, register staging, per-read swizzles and per-tile weight reloads: 2.09 ms per 1 000 frames.
+__global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p) {
+  constexpr int CIN = 64;
+  constexpr int TH = 8, TW = 16, HW = TW + 2;          // halo 10 x 18 = 180 pixels
+  constexpr int NHALO = (TH + 2) * HW, HROWS = 192;     // -> 12 blocks of 16 rows
+  constexpr int NP = 3;                                 // DMA pieces per wavefront and tile: row groups 3w .. 3w + 2 (8 rows x 128 B each)
+  constexpr int HP = 144;                               // row pitch of h1 / h2
+  constexpr int XBUF = HROWS * 128;
+  __shared__ __attribute__((aligned(16))) char x0buf[XBUF];  // (two LDS objects: see bottleneck_resident3_kernel)
+  __shared__ __attribute__((aligned(16))) char x1buf[XBUF];
+  __shared__ __attribute__((aligned(16))) char h1[HROWS * HP];
+  __shared__ __attribute__((aligned(16))) char ostage[8][TD_BN_STAGE_BYTES];
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cg = wave & 3, half = wave >> 2;
+  const int lane0 = t & 63;
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const uint32_t x_bytes = (uint32_t)((size_t)p.N * p.H * p.W * CIN * 2);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (uint32_t)((size_t)p.N * p.H * p.W * 512), 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_p;
+
+  // ---- resident for the whole launch: every weight fragment and bias (lane-derived addresses are recomputed per tile) ----
+  const int lr = lane0 & 15, lg = lane0 >> 4;
+  uint4 w1r[2], w2r[18], w3r[4][2], wdr[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) w1r[ks] = *(const uint4*)(p.w1 + ((size_t)(16 * cg + lr) * CIN + ks * 32 + lg * 8) * 2);
+#pragma unroll
+  for (int ks = 0; ks < 18; ++ks) w2r[ks] = *(const uint4*)(p.w2 + ((size_t)(16 * cg + lr) * 576 + ks * 32 + lg * 8) * 2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      w3r[i][ks] = *(const uint4*)(p.w3 + ((size_t)(64 * cg + 16 * i + lr) * 64 + ks * 32 + lg * 8) * 2);
+      wdr[i][ks] = *(const uint4*)(p.wd + ((size_t)(64 * cg + 16 * i + lr) * 64 + ks * 32 + lg * 8) * 2);
+    }
+  float b1v[4], b2v[4], b3v[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    b1v[q] = p.b1[16 * cg + 4 * lg + q];
+    b2v[q] = p.b2[16 * cg + 4 * lg + q];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = 64 * cg + 16 * i + 4 * lg + q;
+      b3v[i][q] = p.b3[n] + p.bd[n];
+    }
+  }
+
+  auto tile_px_of = [&](int tile, int& y0, int& x0) -> uint32_t {
+    const int img = tile / tiles_per_img;
+    const int trem = tile - img * tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    y0 = ty * TH;
+    x0 = tx * TW;
+    return (uint32_t)((img * p.H + y0) * p.W + x0);
+  };
+  auto issue_tile = [&](int tile, char* xbuf) {
+    int y0, x0;
+    const uint32_t px = tile_px_of(tile, y0, x0);
+    const bool exists = tile < p.n_tiles;
+    const bool interior = exists && y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;
+    int ln = lane0;
+    asm volatile("" : "+v"(ln));
+    const int lrow = ln >> 3;
+    const uint32_t lane_part = (uint32_t)(((ln & 7) ^ lrow) << 4);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int row = (wave * NP + k) * 8 + lrow;
+      const int hy = (row * 57) >> 10, hx = row - hy * HW;  // row / 18 for row < 1024
+      uint32_t off = (px + (uint32_t)((hy - 1) * p.W + (hx - 1))) * (CIN * 2) + lane_part;
+      bool ok = row < NHALO;
+      if (!interior) ok = ok && exists && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+      off = ok ? off : TD_BN_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_p)(xbuf + (wave * NP + k) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  auto process = [&](int tile, auto B_) {
+    constexpr int B = decltype(B_)::value;
+    char* const xb_w = B ? x1buf : x0buf;
+    char* const xo_w = B ? x0buf : x1buf;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int lr = lane & 15, lg = lane >> 4;
+    int y0, x0;
+    const uint32_t tile_px = tile_px_of(tile, y0, x0);
+    const bool interior = y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;
+    issue_tile(tile + gridDim.x, xo_w);  // (that buffer was last read in phase 3 of the previous tile, behind its closing barrier)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");  // this tile's pieces have landed; the next tile's stay in flight
+    TD_BN_BARRIER();
+    const char* const xb = xb_w;
+    // ================= phase 1: conv1 (64 -> 64) on the halo tile: channels 16*cg .. +15, row blocks 6*half .. + 5 =================
+    {
+      const char* const xa0 = xb + (half * 96 + lr) * 128 + ((lg ^ (lr & 7)) << 4);
+      const char* const xa1 = xb + (half * 96 + lr) * 128 + (((4 + lg) ^ (lr & 7)) << 4);
+      f32x4 acc[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[j] = f32x4{b1v[0], b1v[1], b1v[2], b1v[3]};
+      uint4 fr[2][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        fr[0][j] = *(const uint4*)(xa0 + j * 2048);
+        fr[1][j] = *(const uint4*)(xa1 + j * 2048);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w1r[ks], *(const bf16x8*)&fr[ks][j], acc[j], 0, 0, 0);
+      char* const hw = h1 + (half * 96 + lr) * HP + (16 * cg + 4 * lg) * 2;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        uint2 o;
+        o.x = bn_cvt_pk(fmaxf(acc[j][0], 0.f), fmaxf(acc[j][1], 0.f));
+        o.y = bn_cvt_pk(fmaxf(acc[j][2], 0.f), fmaxf(acc[j][3], 0.f));
+        if (!interior) {  // outside the image: conv2's zero padding (rows >= 180 are never read)
+          const int row = (half * 6 + j) * 16 + lr;
+          const int hy = (row * 57) >> 10, hx = row - hy * HW;
+          const bool inside = (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+          o.x = inside ? o.x : 0u;
+          o.y = inside ? o.y : 0u;
+        }
+        bn_lds_store8(hw + j * 16 * HP, o);
+      }
+    }
+    TD_BN_BARRIER();  // h1 complete
+    // ================= phase 2: conv2 3x3: channels 16*cg .. +15, tile rows 4*half .. + 3 (row block = one tile row of 16 pixels) =================
+    {
+      const char* const hr2 = h1 + ((4 * half) * HW + lr) * HP + lg * 16;  // centre (row j, column lr) -> halo pixel (j + r, lr + s): + ((j + r) * HW + s) * HP + parity * 64
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = f32x4{b2v[0], b2v[1], b2v[2], b2v[3]};
+      uint4 fr[2][4];
+      auto load_k = [&](int ks, uint4 (&dst)[4]) {
+        const int tap = ks >> 1, r = tap / 3, s_ = tap - 3 * r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = *(const uint4*)(hr2 + ((j + r) * HW + s_) * HP + (ks & 1) * 64);
+      };
+      load_k(0, fr[0]);
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) {
+        if (ks + 1 < 18) load_k(ks + 1, fr[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w2r[ks], *(const bf16x8*)&fr[ks & 1][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      TD_BN_BARRIER();  // every wavefront has read its last h1 fragment: h2 overwrites it
+      char* const hw = h1 + (half * 64 + lr) * HP + (16 * cg + 4 * lg) * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint2 o;
+        o.x = bn_cvt_pk(fmaxf(acc[j][0], 0.f), fmaxf(acc[j][1], 0.f));
+        o.y = bn_cvt_pk(fmaxf(acc[j][2], 0.f), fmaxf(acc[j][3], 0.f));
+        bn_lds_store8(hw + j * 16 * HP, o);
+      }
+    }
+    TD_BN_BARRIER();  // h2 complete
+    // ================= phase 3: conv3 + downsample(x) + ReLU: channels 64*cg .. +63, tile rows 4*half .. + 3 =================
+    {
+      const char* const hr3 = h1 + (half * 64 + lr) * HP + lg * 16;  // + j * 16 * HP + ks * 64
+      char* const stw = ostage[wave] + lr * 128 + (lg & 1) * 8;
+      const uint32_t stk = (uint32_t)(((lg >> 1) ^ (lr & 7)) << 4);
+      const char* const strd = ostage[wave] + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + ps * 1024
+      const uint32_t st_lane = (uint32_t)((lane >> 3) * 512 + cg * 128 + (lane & 7) * 16);
+      const bool full = y0 + TH <= p.H && x0 + TW <= p.W;  // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mb = 4 * half + j;  // tile row
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{b3v[i][0], b3v[i][1], b3v[i][2], b3v[i][3]};  // b3 + bd seed the accumulator
+        const int hp = (mb + 1) * HW + lr + 1;  // this pixel in the input halo tile (the downsample branch reads it)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const uint4 a = *(const uint4*)(hr3 + j * 16 * HP + ks * 64);
+          const uint4 xd = *(const uint4*)(xb + hp * 128 + (((ks * 4 + lg) ^ (hp & 7)) << 4));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w3r[i][ks], *(const bf16x8*)&a, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&wdr[i][ks], *(const bf16x8*)&xd, acc[i], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint2 o;
+          o.x = bn_cvt_pk(fmaxf(acc[i][0], 0.f), fmaxf(acc[i][1], 0.f));
+          o.y = bn_cvt_pk(fmaxf(acc[i][2], 0.f), fmaxf(acc[i][3], 0.f));
+          bn_lds_store8(stw + (stk ^ (uint32_t)(32 * i)), o);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {  // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
+          const uint4 o16 = *(const uint4*)(strd + ps * 1024);
+          uint32_t off = (tile_px + (uint32_t)(mb * p.W + ps * 8)) * 512u + st_lane;
+          if (!full) off = (y0 + mb < p.H && x0 + ps * 8 + (lane >> 3) < p.W) ? off : TD_BN_OOB;
+          bn_store16(rs_out, off, o16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next row overwrites the region
+      }
+    }
+    TD_BN_BARRIER();  // every wavefront is done with the tile: h1 and this input buffer may be overwritten
+  };
+  issue_tile(blockIdx.x, x0buf);
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += 2 * gridDim.x) {
+    process(tile, std::integral_constant<int, 0>{});
+    if (tile + (int)gridDim.x >= p.n_tiles) break;
+    process(tile + gridDim.x, std::integral_constant<int, 1>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (out-of-range) pieces must not outlive the workgroup's LDS
+}
+
 }  // namespace td
 using namespace td;
 
@@ -842,7 +1062,8 @@ extern "C" int td_bottleneck_fused(const void* x, void* out, const void* w1, con
   static const int per_cu = [] { const char* e = getenv("TD_BNECK_WG_PER_CU"); return e ? std::max(1, atoi(e)) : 2; }();  // (A/B: persistent workgroups per CU)
   const int grid = (int)std::min<long long>(nt, (long long)per_cu * n_cu);
   static const int v3 = [] { const char* e = getenv("TD_BNECK_V3"); return e ? atoi(e) : 1; }();  // (A/B: 0 = the register-staged form, two workgroups per CU)
-  if (Cin == 64) bottleneck_fused_kernel<64, true><<<grid, 256, 0, st>>>(p);
+  if (Cin == 64 && v3) bottleneck_first3_kernel<<<(int)std::min<long long>(nt, (long long)n_cu), 512, 0, st>>>(p);
+  else if (Cin == 64) bottleneck_fused_kernel<64, true><<<grid, 256, 0, st>>>(p);
   else if (res256 && v3) bottleneck_resident3_kernel<<<(int)std::min<long long>(nt, (long long)n_cu), 512, 0, st>>>(p);
   else if (res256) bottleneck_resident_kernel<<<grid, 256, 0, st>>>(p);
   else bottleneck_fused_kernel<256, false><<<grid, 256, 0, st>>>(p);

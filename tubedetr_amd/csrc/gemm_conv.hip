@@ -50,6 +50,9 @@ struct GemmParams {
   const int* out_map;
   const int* res_map;
   int tap_inner;  // 256-row tile kernel, spatial layers: walk the K axis channel-chunk-major (all taps of one 64-channel chunk, then the next chunk)
+  int w_ld;       // row stride of wmat in elements when it is not K (a launch that uses a subset of the columns of a larger matrix); 0 = K
+  int wtap[4];    // tap-uniform instances with use_wtap: tap t of this launch reads weight columns wtap[t] * C .. (the tap's block in the larger matrix)
+  int use_wtap;
 };
 
 template <typename T>
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     int n = n0 + (i * 4 + wave) * 8 + lrow;
-    b_off[i] = n < d.Nc ? (uint32_t)n * (uint32_t)((GX && p.w_shared) ? p.K1 : p.K) * ES : OOB;
+    b_off[i] = n < d.Nc ? (uint32_t)n * (uint32_t)(p.w_ld ? p.w_ld : ((GX && p.w_shared) ? p.K1 : p.K)) * ES : OOB;
   }
   // running decomposition of this lane's k index into (r, s, c)
   int kk = chunk * VEC;
@@ -339,7 +342,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stA + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
     }
-    const int kw = (GX && p.w_shared && k_tile0 >= p.K1) ? kk - p.K1 : kk;  // shared weight: the second source re-reads the same columns
+    int kw = (GX && p.w_shared && k_tile0 >= p.K1) ? kk - p.K1 : kk;  // shared weight: the second source re-reads the same columns
+    if constexpr (TU) {
+      if (p.use_wtap) kw = p.wtap[t_tap & 3] * d.C + t_kc + lane_c;  // the tap's column block in the larger matrix (wave-uniform choice)
+    }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       uint32_t off = (kvalid && b_off[i] != OOB) ? b_off[i] + (uint32_t)kw * ES : OOB;
@@ -2339,8 +2345,71 @@ static int persist_min_tiles() {
 }
 extern "C" int td_debug_set_stamp_buffer(unsigned long long* buf) { g_dbg = buf; return TD_OK; }
 
+// a launch that uses a subset of the column blocks (filter taps) of a larger weight matrix
+struct WeightSubset {
+  int w_ld;          // row stride of the matrix in elements
+  int ntap;          // taps of this launch, in its own (r', s') order
+  int wtap[4];       // their tap indices in the matrix
+  size_t w_bytes;    // addressable bytes from the pointer handed in
+};
+static int conv_gemm_launch(const void* src, const void* wmat, void* out, const td_conv_desc* d, const td_epilogue* e, int dtype,
+                            td_stream_t stream, const WeightSubset* sub);
+
+// Input gradient of a 3x3 / stride 2 / pad 1 convolution (the second conv of a stage's first block), by output parity.  dx pixel
+// (2a + ph, 2b + pw) only receives taps r with ph + 1 - r even: 1 tap per axis for an even coordinate, 2 for an odd one - 9 taps
+// over 4 pixels.  Walked as ONE gather over all 9 taps per output pixel (the generic input-gradient path) three quarters of the
+// MFMAs multiply zero rows: 4.0 ms per 16-clip step for the three such layers.  Here each parity class is a dense stride-1
+// FORWARD-geometry convolution over g with a 1x1 / 1x2 / 2x1 / 2x2 filter whose taps are column blocks of the same w_dgrad matrix
+// (no re-packed weights: the tap-uniform K walk takes a tap -> column-block map), written with output stride 2 at offset (ph, pw).
+static int conv_dgrad_s2_by_parity(const void* g, const void* w_dgrad, void* dx, const td_conv_desc* d, const td_epilogue* e, int dtype,
+                                   td_stream_t stream) {
+  const int Hg = d->Hs, Wg = d->Ws, Co = d->C, H = d->Ho, W = d->Wo;
+  const size_t es = 2, wbytes = (size_t)d->Nc * 9 * Co * es;
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      // axis taps in the sub-filter's own order r' = 0, 1 (source offset + r'): even coordinate: r = 1; odd: r' = 0 <-> r = 2, r' = 1 <-> r = 0
+      const int nr = ph ? 2 : 1, ns = pw ? 2 : 1;
+      const int rmap[2] = {ph ? 2 : 1, 0}, smap[2] = {pw ? 2 : 1, 0};
+      td_conv_desc c = {d->N, Hg, Wg, Co, Hg, Wg, nr, ns, 1, 0, 0, d->Nc, d->ldc, 2, H, W};
+      WeightSubset sub;
+      memset(&sub, 0, sizeof(sub));
+      sub.w_ld = 9 * Co;
+      sub.ntap = nr * ns;
+      for (int r = 0; r < nr; ++r)
+        for (int s_ = 0; s_ < ns; ++s_) sub.wtap[r * ns + s_] = rmap[r] * 3 + smap[s_];
+      const size_t ooff = ((size_t)ph * W + pw) * d->ldc * es;
+      td_epilogue ec;
+      memset(&ec, 0, sizeof(ec));
+      if (e) ec = *e;
+      if (ec.residual) ec.residual = (const char*)ec.residual + ooff;
+      if (ec.mask_src) ec.mask_src = (const char*)ec.mask_src + ooff;
+      const char* wp = (const char*)w_dgrad;
+      if (sub.ntap == 1) {  // one tap: its column block by pointer offset (a 1x1 launch has no tap walk)
+        wp += (size_t)sub.wtap[0] * Co * es;
+        sub.wtap[0] = 0;
+      }
+      sub.w_bytes = wbytes - (size_t)(wp - (const char*)w_dgrad);
+      const int rc = conv_gemm_launch(g, wp, (char*)dx + ooff, &c, &ec, dtype, stream, &sub);
+      if (rc) return rc;
+    }
+  return TD_OK;
+}
+
 extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const td_conv_desc* d, const td_epilogue* e,
                             int dtype, td_stream_t stream) {
+  TD_REQUIRE(src && wmat && out && d, "td_conv_gemm: null pointer");
+  static const int parity = [] { const char* e_ = getenv("TD_DGRAD_S2_PARITY"); return e_ ? atoi(e_) : 1; }();  // (A/B: 0 = one gather over all 9 taps)
+  if (parity && dtype == TD_BF16 && d->mode == 1 && d->stride == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && !d->aniso && d->out_sp <= 1 &&
+      d->Ho == 2 * d->Hs && d->Wo == 2 * d->Ws && d->C % 64 == 0 && d->ldc >= d->Nc && !(e && (e->dropout_p > 0.f || e->sigmoid))) {
+    int rc = validate(d, dtype, "td_conv_gemm");
+    if (rc) return rc;
+    return conv_dgrad_s2_by_parity(src, wmat, out, d, e, dtype, stream);
+  }
+  return conv_gemm_launch(src, wmat, out, d, e, dtype, stream, nullptr);
+}
+
+static int conv_gemm_launch(const void* src, const void* wmat, void* out, const td_conv_desc* d, const td_epilogue* e, int dtype,
+                            td_stream_t stream, const WeightSubset* sub) {
   TD_REQUIRE(src && wmat && out && d, "td_conv_gemm: null pointer");
   int rc = validate(d, dtype, "td_conv_gemm");
   if (rc) return rc;
@@ -2359,6 +2428,12 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
     TD_REQUIRE(sb < 4294967000.0 && wb < 4294967000.0, "td_conv_gemm: operand exceeds the 4 GiB buffer-descriptor range");
     p.src_bytes = (uint32_t)sb;
     p.w_bytes = (uint32_t)wb;
+  }
+  if (sub) {
+    p.w_ld = sub->w_ld;
+    p.w_bytes = (uint32_t)sub->w_bytes;
+    p.use_wtap = sub->ntap > 1;
+    for (int i = 0; i < 4; ++i) p.wtap[i] = sub->wtap[i];
   }
   p.alpha = 1.f;
   p.dbg = g_dbg;
@@ -2394,7 +2469,7 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
                      ((d->stride == 1 && d->Hs == d->Ho && d->Ws == d->Wo) ||
                       (d->stride > 1 && d->mode == 0 && (d->Ho - 1) * d->stride < d->Hs && (d->Wo - 1) * d->stride < d->Ws));
     const int NTp = d->Nc / 128, Pp = 2 * n_cu / 8;
-    const bool shape_ok = pw0 && dtype == TD_BF16 && p.K % 64 == 0 && p.K <= 256 && d->Nc % 128 == 0 &&
+    const bool shape_ok = pw0 && !p.w_ld && dtype == TD_BF16 && p.K % 64 == 0 && p.K <= 256 && d->Nc % 128 == 0 &&
                           (NTp == 1 || NTp == 2 || NTp == 4 || NTp == 8 || NTp == 16) && Pp >= NTp && d->ldc % 8 == 0 && !p.sigmoid &&
                           p.alpha == 1.f && n_cu % 8 == 0 && (!p.drop_thresh || persist_dropout);
     const int MTp = cdiv(p.M, 64);
@@ -2449,15 +2524,15 @@ extern "C" int td_conv_gemm(const void* src, const void* wmat, void* out, const 
   static const int tu_on = [] { const char* e_ = getenv("TD_CONV_TAP_UNIFORM"); return e_ ? atoi(e_) : 1; }();
   const int bk = dtype == TD_BF16 ? 64 : 32;
   // (a strided 1x1 - the downsample branch of a stage's first block - is the one-tap case of the same addressing)
-  const bool tu = tu_on && !pw && !d->aniso && (d->R * d->S > 1 || (d->stride > 1 && d->mode == 0)) && d->R * d->S <= 32 && d->C % bk == 0 && p.d.out_sp == 1 &&
-                  (d->mode == 0 || d->stride == 1);
+  const bool tu = tu_on && !pw && !d->aniso && (d->R * d->S > 1 || (d->stride > 1 && d->mode == 0)) && d->R * d->S <= 32 && d->C % bk == 0 &&
+                  (p.d.out_sp == 1 || d->mode == 0) && (d->mode == 0 || d->stride == 1);
   {
     // 256-row tiles (conv_gemm_big_kernel): MFMA-bound bf16 layers with enough workgroups to matter
     static const int big_on = [] { const char* e_ = getenv("TD_CONV_BIG"); return e_ ? atoi(e_) : 1; }();
     static const int big_min = [] { const char* e_ = getenv("TD_CONV_BIG_MIN_WG"); return e_ ? atoi(e_) : 160; }();
     const int bnb = d->Nc % 256 == 0 ? 256 : 128;
     const int wgs = cdiv(p.M, 256) * (d->Nc / bnb);
-    if (big_on && dtype == TD_BF16 && (pw || tu) && d->Nc % 128 == 0 && p.K % 64 == 0 && p.K >= 512 && d->ldc % 8 == 0 && !p.sigmoid &&
+    if (big_on && dtype == TD_BF16 && (pw || tu) && p.d.out_sp == 1 && !p.use_wtap && !p.w_ld && d->Nc % 128 == 0 && p.K % 64 == 0 && p.K >= 512 && d->ldc % 8 == 0 && !p.sigmoid &&
         !p.drop_thresh && wgs >= big_min && (double)p.M * d->ldc < 2147483647.0) {
       if (prof) {
         prof_begin(tu ? TD_PROF_GEMM_256 : TD_PROF_GEMM_256_PW, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);

@@ -127,7 +127,9 @@ def prepared(W: Tensor, dtype: torch.dtype, *, bn=None, need_dgrad: bool = True,
             Co, Ci, R, S_ = W.shape
             RS = R * S_
         assert W.dtype == torch.float32 and W.is_contiguous()
-        e.base_ref, e.offset, e.shape, e.bn, e.dtype = weakref.ref(base), W.storage_offset(), tuple(W.shape), bn, dtype
+        # element offset of W inside `base` (NOT inside the storage: once FusedAdamWEMA has moved the parameters into its flat
+        # buffer, base.data_ptr() itself sits at a storage offset - counting that twice read far outside the weight)
+        e.base_ref, e.offset, e.shape, e.bn, e.dtype = weakref.ref(base), W.storage_offset() - base.storage_offset(), tuple(W.shape), bn, dtype
         e.need_dgrad, e.dims = need_dgrad, (Co, Ci, RS)
         e.cpad = cpad if cpad is not None else ops.pad_to(Ci, ops.vec_of(dtype))
         e.co_alloc = max(Co, pad_out)
