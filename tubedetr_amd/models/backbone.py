@@ -239,7 +239,7 @@ class ResNetTrunkFn(Function):
         n_chunks = 1 if save else -(-N // n_max)
         if n_chunks > 1:
             step_n = -(-N // n_chunks)
-            feats, hw = [], (C.c_int * 3)()
+            full, hw = None, (C.c_int * 3)()
             assert n_grad == N or not save
             for a in range(0, N, step_n):
                 b = min(N, a + step_n)
@@ -251,8 +251,9 @@ class ResNetTrunkFn(Function):
                                            0, ws.data_ptr(), nbytes, C.byref(feat_p), hw, int(pairs), first_stage, code, _hip.stream_ptr()), "td_resnet_fwd")
                 off = feat_p.value - ws.data_ptr()
                 n_el = (b - a) * hw[0] * hw[1] * hw[2]
-                feats.append(ws[off : off + n_el * dt.itemsize].view(dt).view(b - a, hw[0], hw[1], hw[2]).clone())
-            full = torch.cat(feats)
+                if full is None:  # the chunks' features go straight into their rows of ONE result tensor (no clone + torch.cat: 1.6 GB less copied at 16 clips)
+                    full = torch.empty((N, hw[0], hw[1], hw[2]), dtype=dt, device=x.device)
+                full[a:b].copy_(ws[off : off + n_el * dt.itemsize].view(dt).view(b - a, hw[0], hw[1], hw[2]))
             return full[:n_grad], full[n_grad:]
         srcs, n_srcs = sources(0, N)
         nbytes = L.td_resnet_fwd_ws_bytes(N, H, W, nb, code, save)
