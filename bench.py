@@ -66,8 +66,8 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 # algorithmic TFLOP per clip fwd+bwd
 ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
 DEFAULT_CLIPS_PER_GPU = 16
-PMC_TRAFFIC = "r03_pmc_traffic.json"
-PMC_MFMA = "r03_pmc_mfma.json"
+PMC_TRAFFIC = "r04_pmc_traffic.json"
+PMC_MFMA = "r04_pmc_mfma.json"
 
 
 def make_batch(T, res, k, L, seed, device, clips=1, frames="u8"):

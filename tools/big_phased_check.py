@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CASES = [  # (kind, frames, H, C, Nout)
     ("fwd3x3", 125, 22, 256, 256), ("fwd3x3", 1000, 22, 256, 256), ("dgrad3x3", 200, 22, 256, 256), ("fwd3x3", 500, 11, 512, 512),
     ("pw", 125, 22, 1024, 256), ("pw", 500, 11, 2048, 512), ("pw_res", 301, 22, 512, 256), ("fwd3x3", 37, 22, 256, 256),
+    # 128 output channels: the three-stage phased instance (layer2's 3x3 forward / input gradient, its conv1, an odd K-tile count)
+    ("fwd3x3", 200, 44, 128, 128), ("dgrad3x3", 100, 44, 128, 128), ("pw", 200, 44, 512, 128), ("pw_res", 150, 44, 832, 128), ("fwd3x3", 23, 44, 128, 128),
     # persistent pointwise instance (K <= 256): conv3 + residual of layer3 / layer1 / layer2, a conv1 input gradient (residual + mask), no operands, dropout
     ("pw_res", 800, 22, 256, 1024), ("pw_res", 100, 88, 64, 256), ("pw_res", 77, 44, 128, 512), ("pw_res_mask", 200, 22, 256, 1024),
     ("pw_res_mask", 50, 44, 128, 512), ("pw", 333, 22, 192, 256), ("pw_mask", 200, 22, 256, 1024), ("pw_drop", 100, 22, 256, 2048)]

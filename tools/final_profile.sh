@@ -1,16 +1,41 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/final_profile.sh <tag>
-# The round's committed measurements: rocprofv3 kernel stats of the default workload + the three PMC passes
-# (FETCH_SIZE | WRITE_SIZE | MFMA-busy; never combined with each other or with other trace domains), aggregated per kernel.
+# usage (on the GPU box, from the repo root): tools/final_profile.sh <tag>      e.g. r04
+# The round's committed measurements, all from ONE call on ONE box:
+#   1. rocprofv3 kernel stats of the default workload (eager launches, 6 steps)
+#   2. the three PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA-busy; never combined with each other or with other trace domains),
+#      aggregated per kernel, then profiles/<tag>_pmc_traffic.json / _pmc_mfma.json (what bench.py reads for roofline.traffic / mfma_util)
+#   3. the default bench line (with its roofline and CPU legs) and one-flag variants of it
 tag=$1
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out
+O=$R/gpurun_out
+export TD_ALLOW_RANDOM_TEXT_ENCODER=1
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -- python $R/bench.py --no-graph --steps 3 --warmup 2 --cpu-frames 0 --roofline-steps 1 > $R/gpurun_out/${tag}_stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_stats -- python $R/bench.py --no-graph --steps 3 --warmup 2 --cpu-frames 0 --roofline-steps 1 > $O/${tag}_bench_cfg3x16_under_rocprof.json 2> $O/${tag}_stats.err
+find /tmp/${tag}_stats -name "*kernel_stats.csv" -exec cp {} $O/${tag}_bench_cfg3x16_kernel_stats.csv \;
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1); [ "$name" = "SQ_VALU_MFMA_BUSY_CYCLES" ] && name=MFMA
-  timeout 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/${tag}_pmc_$name -- python $R/bench.py --no-graph --steps 1 --warmup 1 --cpu-frames 0 --roofline-steps 0 > $R/gpurun_out/${tag}_pmc_$name.log 2>&1
-  python $R/tools/pmc_collect.py agg /tmp/${tag}_pmc_$name $R/gpurun_out/${tag}_pmc_${name}_per_kernel.csv >> $R/gpurun_out/${tag}_pmc_$name.log 2>&1
+  timeout 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/${tag}_pmc_$name -- python $R/bench.py --no-graph --steps 1 --warmup 1 --cpu-frames 0 --roofline-steps 0 > $O/${tag}_pmc_$name.log 2>&1
+  python $R/tools/pmc_collect.py agg /tmp/${tag}_pmc_$name $O/${tag}_pmc_${name}_per_kernel.csv >> $O/${tag}_pmc_$name.log 2>&1
 done
-find $R/gpurun_out/${tag}_stats -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${tag}_kernel_stats.csv \;
+cd $R
+python tools/pmc_traffic.py $O/${tag}_pmc_FETCH_SIZE_per_kernel.csv $O/${tag}_pmc_WRITE_SIZE_per_kernel.csv $O/${tag}_pmc_traffic.json > $O/${tag}_pmc_traffic.log 2>&1
+python tools/pmc_collect.py mfma $O/${tag}_pmc_MFMA_per_kernel.csv $O/${tag}_pmc_mfma.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --no-graph --steps 1 --warmup 1 --cpu-frames 0 --roofline-steps 0" > $O/${tag}_pmc_mfma.log 2>&1
+cp $O/${tag}_pmc_traffic.json $O/${tag}_pmc_mfma.json profiles/   # the bench line below reads them (this box's copy of the repo)
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/${tag}_bench_cfg3x16.json 2> $O/${tag}_bench_cfg3x16.err
+V="--steps 10 --warmup 3 --cpu-frames 0 --roofline-steps 0"
+timeout 600 python bench.py $V > $O/${tag}_bench_variant_default.json 2>/dev/null
+TD_CONV_BIG_PHASED=0 TD_PW_PERSIST_V2=0 TD_BNECK_V3=0 TD_DGRAD_S2_PARITY=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_round3_kernels.json 2>/dev/null
+TD_CONV_BIG_PHASED=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_lockstep.json 2>/dev/null
+TD_PW_PERSIST_V2=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_pw1.json 2>/dev/null
+TD_BNECK_V3=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_layer1_r3.json 2>/dev/null
+TD_DGRAD_S2_PARITY=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_dgrad9tap.json 2>/dev/null
+timeout 600 python bench.py $V --clips-per-gpu 1 > $O/${tag}_bench_variant_b1.json 2>/dev/null
+timeout 600 python bench.py $V --clips-per-gpu 8 > $O/${tag}_bench_variant_b8.json 2>/dev/null
+timeout 600 python bench.py $V --clips-per-gpu 8 --dedupe > $O/${tag}_bench_variant_b8_dedupe.json 2>/dev/null
+timeout 600 python bench.py $V --no-graph > $O/${tag}_bench_variant_eager.json 2>/dev/null
+timeout 600 python bench.py $V --force-ddp > $O/${tag}_bench_variant_ddp1.json 2>/dev/null
+timeout 600 python bench.py $V --force-ddp --grad-collective rs_ag > $O/${tag}_bench_variant_ddp1_rs_ag.json 2>/dev/null
+timeout 600 python bench.py $V > $O/${tag}_bench_variant_default_again.json 2>/dev/null
+for f in $O/${tag}_bench_*.json; do echo "$(basename $f): $(grep -o '"value": [0-9.]*' $f | head -1) $(grep -o '"ms_per_step": [0-9.]*' $f | head -1)"; done
 echo done

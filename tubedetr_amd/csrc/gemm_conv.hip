@@ -1184,6 +1184,276 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The phased main loop for 128 output channels (layer2's 3x3 layers and its conv1): 256 x 128 tiles, THREE 48-KiB stages.
+// Same two wavefront groups one barrier apart, same counted waits and table walk as conv_gemm_big8_kernel; what differs:
+//   * wavefront tile 64 x 64 (4 M x 2 N wavefronts), so a K tile is TWO phases of 16 MFMAs (M fragments 2p, 2p + 1);
+//   * with three stages tile kt + 2 goes into the stage tile kt - 1 has left: all of its six pieces per wavefront (2 weight,
+//     2 + 2 activation) are issued during tile kt - four in phase 0, two in phase 1 - into regions whose last read lies at least
+//     three barrier intervals back; every piece has four phases of lead;
+//   * waits: before phase 0 of a tile vmcnt(8), before phase 1 vmcnt(10) (the pieces issued since the needed one);
+//   * the loop is unrolled over three tiles (stage = compile-time constant); the table entry that drives the pieces of tile
+//     T + 2 is read in phase 1 of tile T - 1 and returns with that phase's fragments.
+template <bool TU>
+__global__ __launch_bounds__(512, 1) void conv_gemm_big8n_kernel(GemmParams p) {
+  using T = u16;
+  constexpr int ES = 2, BM = 256, BN = 128, BK = 64, NW = 8, VEC = 8;
+  constexpr int WM = 64, WN = 64, TM = 4, TN = 4;
+  constexpr int WREG = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  constexpr int MAXT = 160;
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+  __shared__ __attribute__((aligned(16))) uint4 ktab[MAXT];
+
+  const td_conv_desc& d = p.d;
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int NT = d.Nc / BN;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mt = (seq / NT) * 8 + xcd, nt = seq - (seq / NT) * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (m0 >= p.M) return;
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;
+  const int lane_c = chunk * VEC;
+  const int HoWo = d.Ho * d.Wo;
+  const int RS = d.R * d.S;
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const int wy = wave >> 1, wx = wave & 1;
+  const int grp = wave >> 2;  // the wavefront's group (one wavefront of each group per SIMD)
+
+  // activation piece (h, k): half h (the rows phase h consumes: M fragments 2h, 2h + 1 of every row group), this wavefront's
+  // rows (wave >> 1) * 64 + h * 32 + ((wave & 1) * 2 + k) * 8 .. + 8
+  uint32_t a_off[4], a_mask[4];
+  const float rcp_howo = 1.f / (float)HoWo, rcp_wo = 1.f / (float)d.Wo;
+  auto divmod = [](int a, int dv, float rcp, int& q, int& r) {
+    q = (int)((float)a * rcp);
+    r = a - q * dv;
+    const int up = r >= dv, dn = r < 0;
+    q += up - dn;
+    r += (dn - up) * dv;
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + (wave >> 1) * WM + (q >> 1) * 32 + ((wave & 1) * 2 + (q & 1)) * 8 + lrow;
+    const bool ok = m < p.M;
+    if constexpr (!TU) {
+      a_off[q] = ((uint32_t)m * (uint32_t)p.K + (uint32_t)lane_c) * ES;
+      a_mask[q] = ok ? 1u : 0u;
+    } else {
+      const int mm = ok ? m : 0;
+      int n, rem, ho, wo;
+      divmod(mm, HoWo, rcp_howo, n, rem);
+      divmod(rem, d.Wo, rcp_wo, ho, wo);
+      const int hb = d.mode == 0 ? ho * d.stride - d.pad : ho + d.pad;
+      const int wb = d.mode == 0 ? wo * d.stride - d.pad : wo + d.pad;
+      a_off[q] = ((uint32_t)(n * d.Hs * d.Ws + hb * d.Ws + wb) * (uint32_t)d.C + (uint32_t)lane_c) * ES;
+      uint32_t cols = 0, msk = 0;
+      for (int sx = 0; sx < d.S; ++sx) cols |= ((unsigned)(d.mode == 0 ? wb + sx : wb - sx) < (unsigned)d.Ws ? 1u : 0u) << sx;
+      for (int r = 0; r < d.R; ++r) msk |= ((unsigned)(d.mode == 0 ? hb + r : hb - r) < (unsigned)d.Hs ? cols : 0u) << (r * d.S);
+      a_mask[q] = ok ? msk : 0u;
+    }
+  }
+  uint32_t b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) b_off[i] = ((uint32_t)(n0 + (i * NW + wave) * 8 + lrow) * (uint32_t)p.K + (uint32_t)lane_c) * ES;
+  const int nk = p.K / BK;
+  const bool tap_inner = TU && p.tap_inner;
+  if (t < nk + 6) {  // (the loop runs a multiple of three tiles and looks two ahead)
+    uint32_t xo, tap = 0, wo;
+    if constexpr (TU) {
+      const int cpt = d.C / BK;
+      const int chunkc = tap_inner ? t / RS : t % cpt;
+      tap = tap_inner ? t - chunkc * RS : t / cpt;
+      const int r = (int)tap / d.S, sx = (int)tap - r * d.S;
+      const int pix = d.mode == 0 ? r * d.Ws + sx : -(r * d.Ws + sx);
+      xo = (uint32_t)(pix * d.C + chunkc * BK) * ES;
+      wo = (uint32_t)((int)tap * d.C + chunkc * BK) * ES;
+    } else {
+      xo = wo = (uint32_t)t * BK * ES;
+    }
+    ktab[t] = make_uint4(xo, t < nk ? tap : 0u, wo, t < nk ? 0xFFFFFFFFu : 0u);
+  }
+  auto issue_x = [&](char* stage, int q, const u32x4_t& e) {
+    const uint32_t ok = (0u - ((a_mask[q] >> (e.y & 31)) & 1u)) & e.w;
+    uint32_t off = a_off[q] + e.x;
+    off = (off & ok) | (OOB & ~ok);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stage + ((wave >> 1) * WM + (q >> 1) * 32 + ((wave & 1) * 2 + (q & 1)) * 8) * 128), 16, off, 0, 0, 0);
+  };
+  auto issue_w = [&](char* stage, int i, const u32x4_t& e) {
+    const uint32_t off = ((b_off[i] + e.z) & e.w) | (OOB & ~e.w);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(stage + WREG + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
+  };
+
+  const int lr = lane & 15, lg = lane >> 4;
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+  const uint32_t xa0 = lds0 + (uint32_t)((wy * WM + lr) * 128 + ((lg ^ (lr & 7)) << 4));
+  const uint32_t wa0 = lds0 + (uint32_t)(WREG + (wx * WN + lr) * 128 + ((lg ^ (lr & 7)) << 4));
+  uint32_t xa[3][2], wa[3][2];  // [stage][k-step]
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) {
+    xa[s_][0] = xa0 + s_ * STAGE; xa[s_][1] = (xa0 ^ 64u) + s_ * STAGE;
+    wa[s_][0] = wa0 + s_ * STAGE; wa[s_][1] = (wa0 ^ 64u) + s_ * STAGE;
+  }
+  u32x4_t wreg[2][TN], xreg[2][2];
+  const uint32_t tab0 = (uint32_t)(uintptr_t)(lds_ptr_t)ktab;
+  uint32_t taddr = tab0 + 3 * 16;
+  u32x4_t e[3];
+  // one phase of tile T in stage S: pieces of tile T + 2 (table entry e[(S + 2) % 3]) into stage (S + 2) % 3
+  auto phase = [&](auto S_, auto P_) {
+    constexpr int S = decltype(S_)::value, P = decltype(P_)::value, S2 = (S + 2) % 3;
+    char* const nxt = smem + S2 * STAGE;
+    if constexpr (P == 0) {
+      wreg[0][0] = lds_read16<0 * 2048>(wa[S][0]); wreg[0][1] = lds_read16<1 * 2048>(wa[S][0]);
+      wreg[0][2] = lds_read16<2 * 2048>(wa[S][0]); wreg[0][3] = lds_read16<3 * 2048>(wa[S][0]);
+    }
+    xreg[0][0] = lds_read16<(2 * P + 0) * 2048>(xa[S][0]);
+    xreg[1][0] = lds_read16<(2 * P + 1) * 2048>(xa[S][0]);
+    if constexpr (P == 0) {
+      wreg[1][0] = lds_read16<0 * 2048>(wa[S][1]); wreg[1][1] = lds_read16<1 * 2048>(wa[S][1]);
+      wreg[1][2] = lds_read16<2 * 2048>(wa[S][1]); wreg[1][3] = lds_read16<3 * 2048>(wa[S][1]);
+    }
+    xreg[0][1] = lds_read16<(2 * P + 0) * 2048>(xa[S][1]);
+    xreg[1][1] = lds_read16<(2 * P + 1) * 2048>(xa[S][1]);
+    if constexpr (P == 0) {
+      issue_w(nxt, 0, e[S2]); issue_w(nxt, 1, e[S2]); issue_x(nxt, 0, e[S2]); issue_x(nxt, 1, e[S2]);
+      wait_vmcnt<10>();  // activation half 1 of THIS tile has landed (issued since: 4 + 2 pieces of tile T + 1, 4 of tile T + 2)
+    } else {
+      e[S] = lds_read16<0>(taddr);  // entry T + 3: drives the pieces tile T + 1 issues
+      taddr += 16;
+      issue_x(nxt, 2, e[S2]); issue_x(nxt, 3, e[S2]);
+      wait_vmcnt<8>();   // weights and activation half 0 of tile T + 1 have landed (issued since: its half 1, 6 pieces of tile T + 2)
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][2 * P + j]) : "v"(wreg[ks][i]), "v"(xreg[j][ks]));
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- epilogue bookkeeping ----
+  constexpr int CR = 16, NCH = WM / CR, EPL = 8, LPR = WN / EPL, RPI = 64 / LPR, NIT = CR / RPI, CPRW = WN / 4;
+  const int cc = lane % LPR, rsub = lane / LPR;
+  const int n = n0 + wx * WN + cc * EPL;
+  uint32_t offs[2][NIT];
+  bool live[2][NIT];
+  uint4 res[2][NIT], msk[2][NIT];
+  auto fetch_chunk = [&](int c, int b) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wy * WM + c * CR + it * RPI + rsub;
+      live[b][it] = m < p.M;
+      offs[b][it] = (uint32_t)min(m, p.M - 1) * (uint32_t)d.ldc + (uint32_t)n;
+      if (p.residual) res[b][it] = ld16(p.residual + offs[b][it] * ES);
+      if (p.mask_src) msk[b][it] = ld16(p.mask_src + offs[b][it] * ES);
+    }
+  };
+
+#define TD_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+  TD_STAMP(0);
+  __syncthreads();  // the K table is complete
+  {
+    const u32x4_t e0 = lds_read16<0>(tab0);
+    const u32x4_t e1 = lds_read16<16>(tab0);
+    e[2] = lds_read16<32>(tab0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the issue order of the steady state: per tile 2 weight pieces, activation half 0, activation half 1
+    issue_w(smem, 0, e0); issue_w(smem, 1, e0); issue_x(smem, 0, e0); issue_x(smem, 1, e0); issue_x(smem, 2, e0); issue_x(smem, 3, e0);
+    issue_w(smem + STAGE, 0, e1); issue_w(smem + STAGE, 1, e1); issue_x(smem + STAGE, 0, e1); issue_x(smem + STAGE, 1, e1);
+    issue_x(smem + STAGE, 2, e1); issue_x(smem + STAGE, 3, e1);
+  }
+  wait_vmcnt<8>();  // weights and activation half 0 of tile 0 have landed
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind the first from here on
+  TD_STAMP(1);
+  const int ntri = (nk + 2) / 3;  // ONE loop over tile triples and nothing else (extra tiles: zero fill without traffic)
+#pragma unroll 1
+  for (int it = 0; it < ntri; ++it) {
+    phase(ic<0>{}, ic<0>{}); phase(ic<0>{}, ic<1>{});
+    phase(ic<1>{}, ic<0>{}); phase(ic<1>{}, ic<1>{});
+    phase(ic<2>{}, ic<0>{}); phase(ic<2>{}, ic<1>{});
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with the second group's last barrier
+  TD_STAMP(2);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // trailing zero-fill DMAs must not land in the staging regions below
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the asm MFMAs' results are read below
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(acc[i][j]));
+  fetch_chunk(0, 0);
+  __builtin_amdgcn_s_barrier();  // every wavefront is done with the stage buffers: they become the staging regions
+  TD_STAMP(3);
+  float* stg = (float*)(smem + wave * (CR * WN * 4));
+  const float alpha = p.alpha;
+  float bias[EPL];
+#pragma unroll
+  for (int r = 0; r < EPL; ++r) bias[r] = p.bias ? p.bias[n + r] : 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int b = c & 1;
+    {
+      const int row = lr;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int cx = (i * 4 + lg) ^ (row & (CPRW - 1));
+        const f32x4 a = acc[i][c];
+        *(float4*)(stg + row * WN + cx * 4) = make_float4(a[0] * alpha, a[1] * alpha, a[2] * alpha, a[3] * alpha);
+      }
+    }
+    if (c + 1 < NCH) fetch_chunk(c + 1, b ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + rsub;
+      const int sw = row & (CPRW - 1);
+      float v[EPL];
+#pragma unroll
+      for (int q = 0; q < EPL / 4; ++q) {
+        const float4 f = *(const float4*)(stg + row * WN + (((cc * (EPL / 4) + q) ^ sw) * 4));
+        v[4 * q + 0] = f.x + bias[4 * q + 0]; v[4 * q + 1] = f.y + bias[4 * q + 1];
+        v[4 * q + 2] = f.z + bias[4 * q + 2]; v[4 * q + 3] = f.w + bias[4 * q + 3];
+      }
+      if (p.residual) {
+        float r8[EPL];
+        unpack16<T>(res[b][it], r8);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] += r8[r];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.mask_src) {
+        float m8[EPL];
+        unpack16<T>(msk[b][it], m8);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
+      }
+      if (live[b][it]) st16(p.out + offs[b][it] * ES, pack16<T>(v));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next chunk overwrites the region
+  }
+  TD_STAMP(5);
+#undef TD_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent, weight-stationary instance for the HBM-bound pointwise layers with K <= 256 (bottleneck conv3 forward,
 // conv1 dgrad: [M][K] x [Nc][K]^T with M in the 10^4..10^6 range).  In the tiled kernel above two thirds of such a
 // workgroup's HBM->LDS traffic is the weight tile it re-reads for every 64 rows, and with one K tile in flight per
@@ -2551,6 +2821,9 @@ static int conv_gemm_launch(const void* src, const void* wmat, void* out, const 
       } else if (bnb == 256) {
         if (tu) conv_gemm_big_kernel<256, true><<<gb, 512, 0, st>>>(p);
         else conv_gemm_big_kernel<256, false><<<gb, 512, 0, st>>>(p);
+      } else if (phased && p.K <= 64 * 154 && p.M < (1 << 24)) {
+        if (tu) conv_gemm_big8n_kernel<true><<<gb, 512, 0, st>>>(p);
+        else conv_gemm_big8n_kernel<false><<<gb, 512, 0, st>>>(p);
       } else {
         if (tu) conv_gemm_big_kernel<128, true><<<gb, 512, 0, st>>>(p);
         else conv_gemm_big_kernel<128, false><<<gb, 512, 0, st>>>(p);
