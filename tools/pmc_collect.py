@@ -27,7 +27,7 @@ def family(name):
         return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, *, *>"
     if "td::pw_resident_kernel" in name or "td::pw_resident2_kernel" in name:
         return "td::pw_resident_kernel<*>"
-    m = re.search(r"td::conv_gemm_big8?_kernel<(?:\d+, )?(true|false)>", name)  # lock-step (BN = 128) and phased (256 x 256) instances: one family
+    m = re.search(r"td::conv_gemm_big(?:8n?)?_kernel<(?:\d+, )?(true|false)>", name)  # lock-step and phased (256 x 256, 256 x 128) instances: one family
     if m:  # the 256-row tile kernel on spatial (3x3, MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers
         return f"td::conv_gemm_big_kernel<*, {m.group(1)}>"
     if "td::stem_pool_kernel" in name or re.search(r"td::bottleneck_(fused|resident|resident3|first3)_kernel", name):
