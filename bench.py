@@ -14,8 +14,9 @@ reference's --batch_size, main.py:63; default 16: 288 GB of HBM hold the 111 GB 
 launch of the step - the 100-row-per-clip decoder, RoBERTa on 30 tokens per clip, the 12 100-row trunk backward - then does B
 times the work; measured in round 3: 88.9 / 95.1 clips/s at B = 8 / 16 on one box, profiles/README.md): `value` counts
 clips, not steps.  Up to B = 8 the slow and the fast frames of a step share ONE trunk pass (1 000 frames); beyond that a pass
-would exceed the kernels' 32-bit tensor addressing (1 083 bf16 frames of res 352) and the slow frames (kept for backward) and
-the no-grad fast frames (two chunks of 800) run as separate passes.  Inputs are generated on the device before the timed region.
+that keeps activations for backward would exceed the kernels' 32-bit tensor addressing (1 083 bf16 frames of res 352): the slow
+frames (kept for backward) and the no-grad fast frames (1 600, ONE td_resnet_fwd call whose layer1 launches go out in two frame
+groups) run as two passes.  Inputs are generated on the device before the timed region.
 
 Execution: the step is captured once in HIP graph(s) and replayed (`--no-graph`: eager launches; GPU-bound too from B = 4 on).
   N = 1 : one graph, RoBERTa on a forked branch (its 120-row GEMMs overlap the trunk; `--no-text-stream`: linear graph).
@@ -308,8 +309,6 @@ def main():
     args = tubedetr_amd.default_args(stride=k, fast=not a.no_fast, no_tsa=a.no_tsa, compute_dtype=cdt, video_max_len_train=max(200, T))
     model, criterion, weight_dict = build_model(args)
     model.to(dev)
-    if a.dedupe and B * (T + (T + k - 1) // k) > 1083 * (352 * 352) // (res * res):
-        raise SystemExit("bench: --dedupe is implemented for steps whose slow + fast frames share one trunk pass (<= 8 clips of cfg3 per step)")
     model.slow_frames_are_strided_fast = bool(a.dedupe)  # legal because the synthetic clip has slow = video[::k]
     model.train(not a.eval_dropout_off)
     tok = BatchTokenizer()

@@ -177,9 +177,10 @@ def test_model_bf16_close_to_fp32_and_trains():
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
-def test_dedupe_slow_frames_is_exact():
-    """slow_frames_are_strided_fast=True (one trunk pass, slow frames not recomputed) gives the same outputs and
-    gradients as the two-set pass when the slow frames really are fast[::k]."""
+def test_dedupe_slow_frames_is_exact(monkeypatch):
+    """slow_frames_are_strided_fast=True (slow frames not recomputed: one trunk pass, or - beyond the frames one saved pass can
+    address, forced here with TD_TRUNK_MAX_FRAMES - the slow pass plus a no-grad pass over the OTHER fast frames) gives the same
+    outputs and gradients as the two-set pass when the slow frames really are fast[::k]."""
     from oracle.tubedetr_oracle import OracleConfig
     from oracle.weights import fill_state, state_spec, synthetic_batch
     from tubedetr_amd.harness import FixedTokenizer, batch_to, forward_step
@@ -189,18 +190,22 @@ def test_dedupe_slow_frames_is_exact():
     sd = fill_state(state_spec(cfg), 13)
     dev = torch.device("cuda:0")
     res = {}
-    for flag in (False, True):
+    for flag in (False, True, "split"):
+        monkeypatch.delenv("TD_TRUNK_MAX_FRAMES", raising=False)
+        if flag == "split":
+            monkeypatch.setenv("TD_TRUNK_MAX_FRAMES", "6")  # 14 fast frames, 4 of them slow: no single pass
         model, criterion, weight_dict = _build(cfg)
         model.load_state_dict(sd, strict=True)
         model.to(dev).eval()
-        model.slow_frames_are_strided_fast = flag
+        model.slow_frames_are_strided_fast = bool(flag)
         model.transformer.tokenizer = FixedTokenizer(batch["input_ids"], batch["attention_mask"])
         loss, _, out, _ = forward_step(model, criterion, weight_dict, batch_to(batch, dev))
         loss.backward()
         res[flag] = (out["pred_boxes"].detach().clone(), out["pred_sted"].detach().clone(),
                      model.backbone[0].body.layer3[5].conv2.weight.grad.clone(), model.input_proj.weight.grad.clone())
-    for a, b in zip(res[False], res[True]):
-        assert (a - b).abs().max() <= 1e-5 * max(1.0, b.abs().max().item())
+    for other in (True, "split"):
+        for a, b in zip(res[False], res[other]):
+            assert (a - b).abs().max() <= 1e-5 * max(1.0, b.abs().max().item()), other
 
 
 @pytest.mark.parametrize("text_stream", ["0", "1"])

@@ -33,6 +33,7 @@ TD_DGRAD_S2_PARITY=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_dg
 timeout 600 python bench.py $V --clips-per-gpu 1 > $O/${tag}_bench_variant_b1.json 2>/dev/null
 timeout 600 python bench.py $V --clips-per-gpu 8 > $O/${tag}_bench_variant_b8.json 2>/dev/null
 timeout 600 python bench.py $V --clips-per-gpu 8 --dedupe > $O/${tag}_bench_variant_b8_dedupe.json 2>/dev/null
+timeout 600 python bench.py $V --dedupe > $O/${tag}_bench_variant_b16_dedupe.json 2>/dev/null
 timeout 600 python bench.py $V --no-graph > $O/${tag}_bench_variant_eager.json 2>/dev/null
 timeout 600 python bench.py $V --force-ddp > $O/${tag}_bench_variant_ddp1.json 2>/dev/null
 timeout 600 python bench.py $V --force-ddp --grad-collective rs_ag > $O/${tag}_bench_variant_ddp1_rs_ag.json 2>/dev/null

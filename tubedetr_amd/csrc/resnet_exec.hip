@@ -111,15 +111,44 @@ static Plan make_plan(int N, int H, int W, const int* nb, int dtype, int save) {
   return P;
 }
 
+// Frames one launch may cover: every operand is addressed through a 32-bit buffer descriptor (< 2^31 elements and < 4 GiB per
+// tensor).  A launch whose largest operand would leave that range over N frames is issued over equal frame groups instead -
+// frames are the leading dimension of every activation, so a group is the same launch on rebased pointers.  (Only the no-grad
+// pass uses this: at res 352 its layer1 tensors pass 4 GiB beyond 1 083 bf16 frames.)  TD_TRUNK_MAX_FRAMES=n (tests): pretend
+// the range ends at n frames of the largest activation (16 * H * W elements per frame).
+struct FrameGroups {
+  double lim_elems;
+  int N;
+  FrameGroups(int N_, int H, int W, int es) : N(N_) {
+    lim_elems = std::min(2147483647.0, 4294963200.0 / es);
+    if (const char* e = getenv("TD_TRUNK_MAX_FRAMES")) lim_elems = std::min(lim_elems, atof(e) * 16.0 * H * W);
+  }
+  // frames per group for a launch whose largest operand has `per_frame` elements per frame
+  int step(size_t per_frame) const {
+    const long long nmax = std::max(1LL, (long long)(lim_elems / (double)per_frame));
+    if (N <= nmax) return N;
+    const long long groups = (N + nmax - 1) / nmax;
+    return (int)((N + groups - 1) / groups);
+  }
+};
+static inline size_t frame_elems(const Tens& t) { return (size_t)t.H * t.W * t.C; }
+
 static int run_conv(const char* ws, const Tens& in, const Tens& out, int N, const ConvSpec& c, const void* w, const float* bias,
-                    const void* residual, int relu, int dtype, td_stream_t st) {
-  td_conv_desc d = {N, in.H, in.W, in.C, out.H, out.W, c.k, c.k, c.stride, c.pad, 0, c.cout, c.cout, 1, 0, 0};
-  td_epilogue e;
-  memset(&e, 0, sizeof(e));
-  e.bias = bias;
-  e.residual = residual;
-  e.relu = relu;
-  return td_conv_gemm(ws + in.off, w, (void*)(ws + out.off), &d, &e, dtype, st);
+                    const char* residual, int relu, int dtype, td_stream_t st, const FrameGroups* fg = nullptr) {
+  const int es = dtype == TD_BF16 ? 2 : 4;
+  const int step = fg ? fg->step(std::max(frame_elems(in), frame_elems(out))) : N;
+  for (int f0 = 0; f0 < N; f0 += step) {
+    const int n = std::min(step, N - f0);
+    td_conv_desc d = {n, in.H, in.W, in.C, out.H, out.W, c.k, c.k, c.stride, c.pad, 0, c.cout, c.cout, 1, 0, 0};
+    td_epilogue e;
+    memset(&e, 0, sizeof(e));
+    e.bias = bias;
+    e.residual = residual ? residual + (size_t)f0 * frame_elems(out) * es : nullptr;  // (a residual has the output's shape)
+    e.relu = relu;
+    int rc = td_conv_gemm(ws + in.off + (size_t)f0 * frame_elems(in) * es, w, (void*)(ws + out.off + (size_t)f0 * frame_elems(out) * es), &d, &e, dtype, st);
+    if (rc) return rc;
+  }
+  return TD_OK;
 }
 
 }  // namespace td
@@ -149,6 +178,10 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   TD_REQUIRE(ws_bytes >= P.total, "td_resnet_fwd: workspace too small (%zu < %zu)", ws_bytes, P.total);
   char* base = (char*)ws;
   int rc;
+  // a pass that keeps its activations for backward is walked by td_resnet_bwd as ONE workspace of whole tensors: it must fit the
+  // 32-bit range as it is (td_conv_gemm reports it if not); the no-grad pass splits oversized launches into frame groups
+  const FrameGroups groups(N, H, W, P.es);
+  const FrameGroups* fg = save ? nullptr : &groups;
   bool stem_done = false;  // the fused stem wrote the pooled tensor already
   if (stem_pairs) {
     // pixel-pair stem (see tubedetr_hip.h): 4-channel pixels in the first half of x's region = [H][W/2] elements of 8 channels
@@ -162,22 +195,28 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
       rc = td_stem_pool(base + P.x.off, w_fwd[0], bias[0], base + P.pool.off, N, H, W, dtype, stream);
       stem_done = true;
     } else {
-      td_conv_desc d = {N, H, W / 2, 8, P.stem.H, P.stem.W, 7, 4, 2, 3, 0, 64, 64, 1, 0, 0, 1, 1, 2};
-      td_epilogue e;
-      memset(&e, 0, sizeof(e));
-      e.bias = bias[0];
-      e.relu = 1;
-      rc = td_conv_gemm(base + P.x.off, w_fwd[0], base + P.stem.off, &d, &e, dtype, stream);
+      const int step = fg ? fg->step(frame_elems(P.stem)) : N;
+      for (int f0 = 0; f0 < N && !rc; f0 += step) {
+        td_conv_desc d = {std::min(step, N - f0), H, W / 2, 8, P.stem.H, P.stem.W, 7, 4, 2, 3, 0, 64, 64, 1, 0, 0, 1, 1, 2};
+        td_epilogue e;
+        memset(&e, 0, sizeof(e));
+        e.bias = bias[0];
+        e.relu = 1;
+        rc = td_conv_gemm(base + P.x.off + (size_t)f0 * H * W * 4 * P.es, w_fwd[0], base + P.stem.off + (size_t)f0 * frame_elems(P.stem) * P.es, &d, &e, dtype, stream);
+      }
     }
   } else {
     rc = td_frames_to_nhwc(srcs, n_srcs, 3, H, W, P.x.C, mean, inv_std, base + P.x.off, dtype, stream);
     if (rc) return rc;
-    rc = run_conv(base, P.x, P.stem, N, P.convs[0], w_fwd[0], bias[0], nullptr, 1, dtype, stream);
+    rc = run_conv(base, P.x, P.stem, N, P.convs[0], w_fwd[0], bias[0], nullptr, 1, dtype, stream, fg);
   }
   if (rc) return rc;
   if (!stem_done) {
-    rc = td_maxpool3x3s2(base + P.stem.off, base + P.pool.off, N, P.stem.H, P.stem.W, 64, dtype, stream);
-    if (rc) return rc;
+    const int step = fg ? fg->step(frame_elems(P.stem)) : N;
+    for (int f0 = 0; f0 < N; f0 += step)
+      if ((rc = td_maxpool3x3s2(base + P.stem.off + (size_t)f0 * frame_elems(P.stem) * P.es, base + P.pool.off + (size_t)f0 * frame_elems(P.pool) * P.es,
+                                std::min(step, N - f0), P.stem.H, P.stem.W, 64, dtype, stream)))
+        return rc;
   }
   // conv3 of a layer1 block + conv1 of the block behind it as ONE launch (td_pw_chain): 64 -> 256 -> 64 (| 128 into layer2)
   static const int chain_on = [] { const char* e = getenv("TD_PW_CHAIN"); return e ? atoi(e) : 3; }();  // bit 0: inside layer1, bit 1: into layer2
@@ -194,18 +233,21 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
     const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
     if (l1_fused && (l1_fused >= 2 || cd >= 0) && dtype == TD_BF16 && !conv1_done && (!save || b.stage < first_train_stage) && b.stride == 1 && P.convs[c1].cout == 64 &&
         P.convs[c3].cout == 256 && ((P.convs[c1].cin == 64 && cd >= 0) || (P.convs[c1].cin == 256 && cd < 0)) &&
-        (double)N * b.out.H * b.out.W * 256 < 2147483647.0) {
-      if ((rc = td_bottleneck_fused(base + b.in.off, base + b.out.off, w_fwd[c1], bias[c1], w_fwd[c2], bias[c2], w_fwd[c3], bias[c3],
-                                    cd >= 0 ? w_fwd[cd] : nullptr, cd >= 0 ? bias[cd] : nullptr, N, b.in.H, b.in.W, P.convs[c1].cin, dtype, stream)))
-        return rc;
+        (fg || (double)N * b.out.H * b.out.W * 256 < 2147483647.0)) {
+      const int step = fg ? fg->step(frame_elems(b.out)) : N;
+      for (int f0 = 0; f0 < N; f0 += step)
+        if ((rc = td_bottleneck_fused(base + b.in.off + (size_t)f0 * frame_elems(b.in) * P.es, base + b.out.off + (size_t)f0 * frame_elems(b.out) * P.es, w_fwd[c1],
+                                      bias[c1], w_fwd[c2], bias[c2], w_fwd[c3], bias[c3], cd >= 0 ? w_fwd[cd] : nullptr, cd >= 0 ? bias[cd] : nullptr,
+                                      std::min(step, N - f0), b.in.H, b.in.W, P.convs[c1].cin, dtype, stream)))
+          return rc;
       continue;
     }
-    if (!conv1_done && (rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream))) return rc;
+    if (!conv1_done && (rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream, fg))) return rc;
     conv1_done = false;
-    if ((rc = run_conv(base, b.h1, b.h2, N, P.convs[c2], w_fwd[c2], bias[c2], nullptr, 1, dtype, stream))) return rc;
-    const void* idt = base + b.in.off;
+    if ((rc = run_conv(base, b.h1, b.h2, N, P.convs[c2], w_fwd[c2], bias[c2], nullptr, 1, dtype, stream, fg))) return rc;
+    const char* idt = base + b.in.off;
     if (cd >= 0) {
-      if ((rc = run_conv(base, b.in, b.idt, N, P.convs[cd], w_fwd[cd], bias[cd], nullptr, 0, dtype, stream))) return rc;
+      if ((rc = run_conv(base, b.in, b.idt, N, P.convs[cd], w_fwd[cd], bias[cd], nullptr, 0, dtype, stream, fg))) return rc;
       idt = base + b.idt.off;
     }
     if (chain_on && dtype == TD_BF16 && bi + 1 < P.blocks.size()) {
@@ -213,7 +255,7 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
       const ConvSpec &s3 = P.convs[c3], &s1 = P.convs[nb.conv[0]];
       const long long rows = (long long)N * b.out.H * b.out.W;
       const bool fits = s3.cin == 64 && s3.cout == 256 && s1.cin == 256 && s1.k == 1 && s1.stride == 1 && (s1.cout == 64 || (s1.cout == 128 && (chain_on & 2))) &&
-                        rows * 256 < 2147483647LL && nb.h1.off != b.h2.off && nb.h1.off != b.out.off && nb.h1.off != b.in.off && (cd < 0 || nb.h1.off != b.idt.off);
+                        (double)rows * 256 < groups.lim_elems && nb.h1.off != b.h2.off && nb.h1.off != b.out.off && nb.h1.off != b.in.off && (cd < 0 || nb.h1.off != b.idt.off);
       if (fits) {
         if ((rc = td_pw_chain(base + b.h2.off, w_fwd[c3], bias[c3], idt, base + b.out.off, w_fwd[nb.conv[0]], bias[nb.conv[0]], base + nb.h1.off, (int)rows,
                               64, 256, s1.cout, dtype, stream)))
@@ -222,7 +264,7 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
         continue;
       }
     }
-    if ((rc = run_conv(base, b.h2, b.out, N, P.convs[c3], w_fwd[c3], bias[c3], idt, 1, dtype, stream))) return rc;
+    if ((rc = run_conv(base, b.h2, b.out, N, P.convs[c3], w_fwd[c3], bias[c3], idt, 1, dtype, stream, fg))) return rc;
   }
   const Tens& last = P.blocks.empty() ? P.pool : P.blocks.back().out;
   *feat = base + last.off;

@@ -233,9 +233,11 @@ class ResNetTrunkFn(Function):
 
         # every activation of a pass is addressed through a 32-bit buffer descriptor: < 2^31 elements and < 4 GiB per tensor.
         # The largest one has 16 * H * W elements per frame (stem output / layer1 output).  A no-grad pass over more frames than
-        # that (eval / the fast frames of a large fp32 batch) is cut into equal chunks; a pass that keeps its activations
-        # for backward is not (its backward walks ONE workspace): the C library reports the limit.
-        n_max = ResNetBody.max_frames(H, W, dt)
+        # that (eval / the fast frames of a large batch) is still ONE td_resnet_fwd call: the executor issues the launches whose
+        # operands would leave the range over equal frame groups (resnet_exec.hip: FrameGroups).  Only beyond FOUR times that
+        # many frames - where the 4-channel input tensor itself leaves the range - is the pass cut into chunks here.  A pass
+        # that keeps its activations for backward is not split (its backward walks ONE workspace): the C library reports the limit.
+        n_max = 4 * ResNetBody.max_frames(H, W, dt)
         n_chunks = 1 if save else -(-N // n_max)
         if n_chunks > 1:
             step_n = -(-N // n_chunks)

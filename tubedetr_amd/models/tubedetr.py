@@ -172,13 +172,15 @@ class TubeDETR(nn.Module):
         # sine encoding: the transformer forms the positional operand from the (original) pad mask itself, see Joiner.forward
         want_pos = not self._sine_pos
         merged = self._joiner and self.fast and samples_fast is not None and torch.is_grad_enabled() and samples_fast.tensors.shape[1:] == samples.tensors.shape[1:]
+        dedupe = merged and self.slow_frames_are_strided_fast and sum(durations) == samples_fast.tensors.shape[0]
         if merged:
-            # one pass holds at most ResNetBody.max_frames frames (32-bit tensor addressing: 1 083 bf16 frames at res 352); a larger
-            # batch runs the slow frames (kept for backward) and the no-grad fast frames (cut into equal chunks) as separate passes
+            # a pass that keeps activations for backward holds at most ResNetBody.max_frames frames (32-bit tensor addressing: 1 083
+            # bf16 frames at res 352); a larger batch runs the slow frames (kept for backward) and the no-grad fast frames as two
+            # passes (the no-grad one is one td_resnet_fwd call at any size: its oversized launches go out in frame groups)
             body = self.backbone[0].body
             limit = body.max_frames(samples.tensors.shape[-2], samples.tensors.shape[-1], self.compute_dtype)
-            merged = samples.tensors.shape[0] + samples_fast.tensors.shape[0] <= limit
-        if merged and self.slow_frames_are_strided_fast and sum(durations) == samples_fast.tensors.shape[0]:
+            merged = (samples_fast.tensors.shape[0] if dedupe else samples.tensors.shape[0] + samples_fast.tensors.shape[0]) <= limit
+        if merged and dedupe:
             # one trunk pass over the fast frames, permuted so that the slow (= every k-th) frames come first
             n_slow = samples.tensors.shape[0]
             perm, inv = self._dedupe_index(durations, samples_fast.tensors.device)
@@ -205,7 +207,18 @@ class TubeDETR(nn.Module):
         identity = dest.numel() == b * t
         fast_src = None
         if self.fast:
-            if not merged:
+            if not merged and dedupe:
+                # the slow frames ARE fast frames (video[::k]): only the other fast frames go through the no-grad pass, the slow
+                # frames' features are taken (detached) from the pass above
+                n_slow = src.shape[0]
+                perm, inv = self._dedupe_index(durations, samples_fast.tensors.device)
+                assert n_slow == sum(math.ceil(d / k) for d in durations)
+                rest = NestedTensor(FrameSources([(_one_tensor(samples_fast.tensors), perm[n_slow:])], _valid(samples_fast.tensors)), samples_fast.mask[perm[n_slow:]])
+                with torch.no_grad():
+                    features_rest, _ = self.backbone(rest, want_pos=False)
+                src_rest, mask_rest = features_rest[-1].decompose()
+                src_fast_feat, mask_fast = torch.cat([src.detach(), src_rest])[inv], torch.cat([mask, mask_rest])[inv]
+            elif not merged:
                 with torch.no_grad():  # the fast branch does not back-propagate into the backbone (tubedetr.py:128-129)
                     features_fast, _ = self.backbone(samples_fast, want_pos=False) if self._joiner else self.backbone(samples_fast)  # its encoding is never used
                 src_fast_feat, mask_fast = features_fast[-1].decompose()
