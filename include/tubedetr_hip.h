@@ -362,6 +362,18 @@ int td_cross_q1_fwd(const void* u, const void* mem, const void* pos, const uint8
 int td_cross_q1_bwd(const void* u, const void* mem, const void* pos, const float* probs, const void* d_zext, const float* dwavg,
                     void* d_u, float* d_mem, int accumulate, int F, int S, int H, int E, int ldz, float dropout_p, uint32_t dropout_seed,
                     const uint32_t* dropout_counter, int dtype, td_stream_t stream);
+/* bf16 mode: the memory gradient of ALL layers in one pass instead of an fp32 read-modify-write of [F*S][E] per layer.
+ * td_cross_q1_bwd_coef = td_cross_q1_bwd without d_mem: row f*S + s of `coef` (bf16, row stride coef_ld, a multiple of 32)
+ * receives this layer's sixteen coefficients [ds[0..H) | pd[0..H)] at column coef_col (a multiple of 16; one block per layer).
+ * td_cross_q1_dmem then forms  d_mem[f*S + s] = sum over layers l, heads h of  ds_l[h][s] u_l[f][h] + pd_l[h][s] d_z_l[f][h]
+ * as one [S][coef_ld] x [coef_ld][E] product per frame on the matrix pipe and writes it in T (bf16): u[l] / d_zext[l] are the
+ * tensors layer l handed to td_cross_q1_bwd_coef with coef_col = 16 l (a layer that did not run: both NULL, its columns of a
+ * zero-filled `coef` are never written).  models/transformer.py:725-745 (backward of the six layers' shared memory). */
+int td_cross_q1_bwd_coef(const void* u, const void* mem, const void* pos, const float* probs, const void* d_zext, const float* dwavg,
+                         void* d_u, void* coef, int coef_ld, int coef_col, int F, int S, int H, int E, int ldz, float dropout_p,
+                         uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream);
+int td_cross_q1_dmem(const void* coef, int coef_ld, const void* const* u, const void* const* d_zext, int n_layers, void* d_mem, int F, int S,
+                     int H, int E, int ldz, int dtype, td_stream_t stream);
 /* Block-structured forms of one [E][E] slice of nn.MultiheadAttention.in_proj_weight (fp32, [out][in]; out channel j belongs to
  * head j / (E/H)) for those GEMMs: w_n [E][H*E + nb] holds W[j][:] * alpha in column block head(j) of row j (zeros elsewhere)
  * and, if bias != NULL (nb = H, else 0), bias[j] in column H*E + head(j); w_t [H*E + nb][E] is its transpose.  Both in `dtype`.

@@ -983,6 +983,45 @@ def test_cross_attention_query_side_with_a_memory_that_needs_no_gradient():
     assert peak1 - peak0 >= F_ * S * E * 4  # the fp32 d(memory) buffer exists only when the memory wants it
 
 
+@pytest.mark.parametrize("F_,S,nl", [(24, 151, 6), (5, 37, 3), (3, 16, 1)])
+def test_cross_attention_deferred_memory_gradient(F_, S, nl):
+    """bf16 mode: td_cross_q1_bwd_coef + ONE td_cross_q1_dmem (coefficients per memory row, then a [S][16 nl] x [16 nl][E] MFMA product
+    per frame) against td_cross_q1_bwd's fp32 accumulation over the layers (the VALU kernel: an fp32 d(memory) keeps it off the matrix
+    pipe) - d_u and the memory gradient within bf16 rounding of the probabilities / coefficients and of the stored result; dropout and key
+    padding on; a layer that never ran contributes nothing."""
+    from tubedetr_amd import ops
+
+    E, H = 256, 8
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(100 + S)
+    r = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).to(dt).to(dev())
+    mem, pos = r(F_ * S, E), r(F_ * S, E)
+    key_pad = (torch.rand(F_, S, generator=g) < 0.2).to(dev())
+    key_pad[:, 0] = False
+    ran = [l for l in range(nl) if not (nl == 6 and l == 4)]  # (layer 4 of the six never runs its backward)
+    KP = (16 * nl + 31) // 32 * 32
+    coef = torch.zeros((F_ * S, KP), dtype=dt, device=dev())
+    dmem_ref, layers, first = torch.empty((F_ * S, E), dtype=torch.float32, device=dev()), [None] * nl, True
+    for l in ran:
+        u = r(F_, H * E, s=0.2)
+        seed = 1234 + l
+        probs, _wavg, _zext = ops.cross_q1_fwd(u, mem, pos, key_pad, F_, S, H, need_wavg=True, dropout_p=0.1, seed=seed)
+        d_zext = r(F_, H * E + H, s=0.5)
+        dwa = (torch.randn(F_, S, generator=g) * 0.3).to(dev())
+        du_ref = ops.cross_q1_bwd(u, mem, pos, probs, d_zext, dwa, dmem_ref, not first, F_, S, H, dropout_p=0.1, seed=seed)
+        du_new = ops.cross_q1_bwd_coef(u, mem, pos, probs, d_zext, dwa, coef, 16 * l, F_, S, H, dropout_p=0.1, seed=seed)
+        assert rel_err(du_new, du_ref) < 1e-2
+        layers[l] = (u, d_zext)
+        first = False
+    dmem = ops.cross_q1_dmem(coef, layers, F_, S, H, E)
+    assert dmem.dtype == dt and dmem.shape == (F_ * S, E) and torch.isfinite(dmem.float()).all()
+    assert rel_err(dmem, dmem_ref) < 1e-2
+    # per-row check too (a wrong row / channel mapping hides behind a max-norm over the tensor when one row dominates)
+    num = (dmem.float() - dmem_ref).norm(dim=1)
+    den = dmem_ref.norm(dim=1).clamp_min(1e-3 * dmem_ref.norm(dim=1).max())
+    assert (num / den).max().item() < 2e-2
+
+
 def test_cross_attention_query_side_draws_the_same_dropout_mask_as_the_projected_path():
     """Same (seed, element index) dropout keys as td_mha_fwd with Lq = 1: with dropout on, the query-side formulation and the
     projected-memory path (functional.MHAFn) agree on outputs, returned weights and gradients."""

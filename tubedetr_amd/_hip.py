@@ -11,7 +11,7 @@ import os
 import torch
 
 TD_F32, TD_BF16 = 0, 1
-EXPECTED_ABI = 6  # td_abi_version() of the library these signatures were written against
+EXPECTED_ABI = 7  # td_abi_version() of the library these signatures were written against
 _LIB_PATH = os.environ.get("TD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtubedetr_hip.so")  # (TD_HIP_LIB: an A/B build of the same ABI, tools/build_variant.sh)
 _lib = None
 
@@ -112,6 +112,8 @@ _SIGS = {
     "td_mha_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],
     "td_cross_q1_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U32, _P, _I, _P],
     "td_cross_q1_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _U32, _P, _I, _P],
+    "td_cross_q1_bwd_coef": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U32, _P, _I, _P],
+    "td_cross_q1_dmem": [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "td_head_blocks_expand": [_P, _P, _F, _P, _P, _I, _I, _I, _P],
     "td_head_blocks_extract": [_P, _F, _P, _P, _I, _I, _P],
     "td_mha_lean_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _U32, _P, _I, _P],

@@ -38,6 +38,8 @@ struct CrossQ1Params {
   const float* dwavg;
   void *zext, *du;
   float* dmem;
+  u16* coef;  // deferred d(memory) (bf16 mode): row f*S + s receives [ds[0..8) | pd[0..8)] as bf16 at column coef_col (row stride coef_ld)
+  int coef_ld, coef_col;
   int F, S, ldz, accumulate;
   uint32_t drop_thresh;
   float drop_scale;
@@ -225,6 +227,151 @@ __global__ __launch_bounds__(256) void cross_q1_fwd_kernel(CrossQ1Params p) {
   if (t < QH) Elem<T>::store(p.zext, (size_t)f * p.ldz + QH * QE + t, sSp[t]);
 }
 
+// The frame core on the matrix pipe (bf16 mode, S <= SMAX): both products of a frame are tiles of v_mfma_f32_16x16x32_bf16.
+//   scores  D[head][row]   = U [16 x 256] . X^T   (A = u, heads 8..15 zero; B = 16 memory rows, 16 contiguous bytes of a row per lane:
+//           the natural operand, straight from HBM; the positional rows are a second product into the same accumulator - never added)
+//   sums    D[head][chan]  = P [16 x S] . X       (A = the probabilities after dropout in bf16; B = the SAME rows, now needed with the
+//           row index along the lane's eight values: the wavefront that fetched a row tile also left it in an LDS image, read back
+//           with the transposing ds_read_b64_tr_b16 - the memory rows come from HBM once, the VALU kernel's second pass re-read them)
+// Wavefront w fetches row tiles w, w + 4, ... (16 rows x 512 bytes of memory + as much of pos in flight per tile) and owns channels
+// 64 w .. 64 w + 63 of the sums.  Softmax, dropout mask, probs / wavg outputs: exactly the VALU kernel's code on fp32 scores.
+typedef __bf16 cq_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cq_bf4 __attribute__((ext_vector_type(4)));
+typedef float cq_f4 __attribute__((ext_vector_type(4)));
+
+template <int SMAX>
+__global__ __launch_bounds__(256) void cross_q1_fwd_mfma_kernel(CrossQ1Params p) {
+  constexpr int HALF = SMAX * 256;  // one 128-channel half of the row image: SMAX rows of 256 bytes
+  __shared__ __attribute__((aligned(16))) char sX[2 * HALF];
+  __shared__ __attribute__((aligned(16))) float sS[QH * SMAX];   // scores, then exp(score - max)
+  __shared__ __attribute__((aligned(16))) float sP[SMAX * QH];   // probabilities after dropout, [s][h] (wavg)
+  __shared__ __attribute__((aligned(16))) u16 sPb[QH * SMAX];    // the same in bf16, [h][s]: A operand of the sums
+  __shared__ float sSp[QH];
+  const int S = p.S, SP32 = (S + 31) & ~31;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int lr = lane & 15, lg = lane >> 4, jrow = lr >> 2, q = lr & 3;
+  const int f = blockIdx.x;
+  const size_t row0 = (size_t)f * S;
+  const u16* mem = (const u16*)p.mem;
+  const u16* pos = (const u16*)p.pos;
+  uint4 ua[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    ua[ks] = make_uint4(0u, 0u, 0u, 0u);
+    if (lr < QH) ua[ks] = *(const uint4*)((const u16*)p.u + ((size_t)f * QH + lr) * QE + ks * 32 + lg * 8);
+  }
+  for (int m0 = wave * 16; m0 < SP32; m0 += 64) {
+    const int row = m0 + lr;
+    const bool valid = row < S;
+    uint4 xm[8], xp[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      xm[ks] = make_uint4(0u, 0u, 0u, 0u);
+      if (valid) xm[ks] = *(const uint4*)(mem + (row0 + row) * QE + ks * 32 + lg * 8);
+    }
+    if (pos) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        xp[ks] = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) xp[ks] = *(const uint4*)(pos + (row0 + row) * QE + ks * 32 + lg * 8);
+      }
+    }
+    cq_f4 acc = cq_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const cq_bf8*)&ua[ks], *(const cq_bf8*)&xm[ks], acc, 0, 0, 0);
+    if (pos) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const cq_bf8*)&ua[ks], *(const cq_bf8*)&xp[ks], acc, 0, 0, 0);
+    }
+    // D[i = head][j = row]: lane holds heads 4 lg + rr of row m0 + lr
+    if (lg < 2 && valid) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) sS[(4 * lg + rr) * SMAX + row] = acc[rr];
+    }
+    // the rows themselves into the image (rows >= S: zeros): chunk c = 4 ks + lg of half c >> 4 at slot (((c16 >> 1) ^ swz(row)) << 1) | (c16 & 1)
+    const int swz = (row & 3) | (((row >> 3) & 1) << 2);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int c = 4 * ks + lg, hf = c >> 4, c16 = c & 15;
+      const int slot = (((c16 >> 1) ^ swz) << 1) | (c16 & 1);
+      *(uint4*)(sX + hf * HALF + row * 256 + slot * 16) = xm[ks];
+    }
+  }
+  __syncthreads();
+  const uint32_t seed = effective_seed(p.seed, p.seed_dev);
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = wave + 4 * hh;
+    float* row = sS + h * SMAX;
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += 64) {
+      float v = row[s];
+      if (p.kpm && p.kpm[row0 + s]) v = -INFINITY;
+      row[s] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      const float e = __expf(row[s] - mx);
+      row[s] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    float spd = 0.f;
+    const size_t prow = ((size_t)f * QH + h) * S;
+    for (int s = lane; s < SP32; s += 64) {
+      float pr = 0.f;
+      if (s < S) {
+        pr = row[s] * inv;
+        p.probs[prow + s] = pr;
+        if (p.drop_thresh) pr = dropout_keep(seed, (uint32_t)(prow + s), p.drop_thresh) ? pr * p.drop_scale : 0.f;
+        sP[s * QH + h] = pr;
+        spd += pr;
+      }
+      sPb[h * SMAX + s] = f32_to_bf16(pr);
+    }
+    spd = wave_sum(spd);
+    if (lane == 0) sSp[h] = spd;
+  }
+  __syncthreads();
+  if (p.wavg)
+    for (int s = t; s < S; s += 256) {
+      const float4 a = *(const float4*)(sP + s * QH), b = *(const float4*)(sP + s * QH + 4);
+      p.wavg[row0 + s] = (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * (1.f / QH);
+    }
+  // sums: this wavefront's 64 channels = four 16-column blocks of half wave >> 1
+  cq_f4 z[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) z[n] = cq_f4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = jrow | ((lg & 1) << 2);
+  const char* half = sX + (wave >> 1) * HALF;
+  for (int ks = 0; ks < SP32 / 32; ++ks) {
+    uint4 pa = make_uint4(0u, 0u, 0u, 0u);
+    if (lr < QH) pa = *(const uint4*)(sPb + lr * SMAX + ks * 32 + lg * 8);
+    const int r0 = ks * 32 + 8 * lg + jrow;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int blk16 = (wave & 1) * 4 + n;
+      const int cb = ((blk16 ^ fsw) << 5) + q * 8;
+      const cq_bf4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) cq_bf4*)(half + r0 * 256 + cb));
+      const cq_bf4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) cq_bf4*)(half + (r0 + 4) * 256 + cb));
+      const cq_bf8 b = cq_bf8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      z[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const cq_bf8*)&pa, b, z[n], 0, 0, 0);
+    }
+  }
+  // D[i = head][j = channel]: lane holds heads 4 lg + rr, channel 64 wave + 16 n + lr
+  if (lg < 2) {
+    u16* zrow = (u16*)p.zext + (size_t)f * p.ldz;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) zrow[(4 * lg + rr) * QE + wave * 64 + 16 * n + lr] = f32_to_bf16(z[n][rr]);
+  }
+  if (t < QH) ((u16*)p.zext)[(size_t)f * p.ldz + QH * QE + t] = f32_to_bf16(sSp[t]);
+}
+
 // Backward of the frame core.  Inputs: d(zext) (d_z [h][c] and d(sum_s pd) [h]), the gradient of the head-averaged weights;
 // outputs: d_u [h][c] = sum_s ds[h][s] (x_s + pos_s) and, accumulated over the layers in fp32,
 // d(memory row s) = sum_h ds[h][s] u[h] + pd[h][s] d_z[h].
@@ -285,6 +432,27 @@ __global__ __launch_bounds__(256) void cross_q1_bwd_kernel(CrossQ1Params p) {
     for (int s = lane; s < S; s += 64) sDS[s * QH + h] = p.probs[prow + s] * (row[s] - delta);
   }
   __syncthreads();
+  if (p.coef) {
+    // deferred d(memory): d(mem row s) = sum over the layers and heads of ds[h][s] u[h] + pd[h][s] d_z[h] is ONE product
+    // [S x 16 nl] . [16 nl x E] per frame (cross_q1_dmem_kernel, on the matrix pipe) once every layer has left its 16
+    // coefficients per row here - instead of an fp32 read-modify-write of the whole [F*S][E] gradient per layer
+    for (int s = t; s < S; s += 256) {
+      const float4 a = *(const float4*)(sDS + s * QH), b = *(const float4*)(sDS + s * QH + 4);
+      const float4 c = *(const float4*)(sPD + s * QH), d = *(const float4*)(sPD + s * QH + 4);
+      uint4 lo, hi;
+      lo.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+      lo.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+      lo.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+      lo.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+      hi.x = (uint32_t)f32_to_bf16(c.x) | ((uint32_t)f32_to_bf16(c.y) << 16);
+      hi.y = (uint32_t)f32_to_bf16(c.z) | ((uint32_t)f32_to_bf16(c.w) << 16);
+      hi.z = (uint32_t)f32_to_bf16(d.x) | ((uint32_t)f32_to_bf16(d.y) << 16);
+      hi.w = (uint32_t)f32_to_bf16(d.z) | ((uint32_t)f32_to_bf16(d.w) << 16);
+      uint4* dst = (uint4*)(p.coef + (row0 + s) * (size_t)p.coef_ld + p.coef_col);
+      dst[0] = lo;
+      dst[1] = hi;
+    }
+  }
   float du[QH][4];
 #pragma unroll
   for (int h = 0; h < QH; ++h) du[h][0] = du[h][1] = du[h][2] = du[h][3] = 0.f;
@@ -331,6 +499,285 @@ __global__ __launch_bounds__(256) void cross_q1_bwd_kernel(CrossQ1Params p) {
   for (int h = 0; h < QH; ++h) *(float4*)(sU + wave * QH * QE + h * QE + 4 * lane) = make_float4(du[h][0], du[h][1], du[h][2], du[h][3]);
   __syncthreads();
   reduce_store_rows<T>(sU, p.du, (size_t)f * QH * QE, t);
+}
+
+// Backward of the frame core on the matrix pipe (bf16 mode, S <= SMAX, the memory gradient deferred or not wanted): the same two
+// products as cross_q1_fwd_mfma_kernel with d_z in the place of u (no positional rows: d_z . x_s) and ds in the place of the
+// probabilities (d_u = sum_s ds[h][s] (x_s + pos_s): the image holds the SUM of the memory and positional rows, added in fp32 and
+// rounded once to bf16 - the rows are fetched from HBM once).  The softmax backward in between is the VALU kernel's.
+template <int SMAX>
+__global__ __launch_bounds__(256) void cross_q1_bwd_mfma_kernel(CrossQ1Params p) {
+  constexpr int HALF = SMAX * 256;
+  __shared__ __attribute__((aligned(16))) char sX[2 * HALF];
+  __shared__ __attribute__((aligned(16))) float sS[QH * SMAX];    // d_z . x_s, then dP
+  __shared__ __attribute__((aligned(16))) float sDS[SMAX * QH];   // [s][h]
+  __shared__ __attribute__((aligned(16))) float sPD[SMAX * QH];   // [s][h]
+  __shared__ __attribute__((aligned(16))) u16 sDSb[QH * SMAX];    // ds in bf16, [h][s]: A operand of d_u
+  const int S = p.S, SP32 = (S + 31) & ~31;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int lr = lane & 15, lg = lane >> 4, jrow = lr >> 2, q = lr & 3;
+  const int f = blockIdx.x;
+  const size_t row0 = (size_t)f * S;
+  const u16* mem = (const u16*)p.mem;
+  const u16* pos = (const u16*)p.pos;
+  uint4 da[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    da[ks] = make_uint4(0u, 0u, 0u, 0u);
+    if (lr < QH) da[ks] = *(const uint4*)((const u16*)p.dz + (size_t)f * p.ldz + lr * QE + ks * 32 + lg * 8);
+  }
+  for (int m0 = wave * 16; m0 < SP32; m0 += 64) {
+    const int row = m0 + lr;
+    const bool valid = row < S;
+    uint4 xm[8], xp[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      xm[ks] = make_uint4(0u, 0u, 0u, 0u);
+      if (valid) xm[ks] = *(const uint4*)(mem + (row0 + row) * QE + ks * 32 + lg * 8);
+    }
+    if (pos) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        xp[ks] = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) xp[ks] = *(const uint4*)(pos + (row0 + row) * QE + ks * 32 + lg * 8);
+      }
+    }
+    cq_f4 acc = cq_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const cq_bf8*)&da[ks], *(const cq_bf8*)&xm[ks], acc, 0, 0, 0);
+    if (lg < 2 && valid) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) sS[(4 * lg + rr) * SMAX + row] = acc[rr];
+    }
+    const int swz = (row & 3) | (((row >> 3) & 1) << 2);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      uint4 v = xm[ks];
+      if (pos) {
+        const uint32_t a_[4] = {xm[ks].x, xm[ks].y, xm[ks].z, xm[ks].w}, b_[4] = {xp[ks].x, xp[ks].y, xp[ks].z, xp[ks].w};
+        uint32_t o_[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(a_[e] << 16) + __uint_as_float(b_[e] << 16);
+          const float hi = __uint_as_float(a_[e] & 0xFFFF0000u) + __uint_as_float(b_[e] & 0xFFFF0000u);
+          o_[e] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+        }
+        v = make_uint4(o_[0], o_[1], o_[2], o_[3]);
+      }
+      const int c = 4 * ks + lg, hf = c >> 4, c16 = c & 15;
+      const int slot = (((c16 >> 1) ^ swz) << 1) | (c16 & 1);
+      *(uint4*)(sX + hf * HALF + row * 256 + slot * 16) = v;
+    }
+  }
+  __syncthreads();
+  const uint32_t seed = effective_seed(p.seed, p.seed_dev);
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = wave + 4 * hh;
+    float* row = sS + h * SMAX;
+    const float dsp = Elem<u16>::load(p.dz, (size_t)f * p.ldz + QH * QE + h);
+    const size_t prow = ((size_t)f * QH + h) * S;
+    float delta = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      const float pr = p.probs[prow + s];
+      const bool keep = !p.drop_thresh || dropout_keep(seed, (uint32_t)(prow + s), p.drop_thresh);
+      float g = row[s] + dsp;
+      if (p.dwavg) g += p.dwavg[row0 + s] * (1.f / QH);
+      const float dp = keep ? g * p.drop_scale : 0.f;
+      row[s] = dp;
+      delta += pr * dp;
+      sPD[s * QH + h] = keep ? pr * p.drop_scale : 0.f;
+    }
+    delta = wave_sum(delta);
+    for (int s = lane; s < SP32; s += 64) {
+      float ds = 0.f;
+      if (s < S) {
+        ds = p.probs[prow + s] * (row[s] - delta);
+        sDS[s * QH + h] = ds;
+      }
+      sDSb[h * SMAX + s] = f32_to_bf16(ds);
+    }
+  }
+  __syncthreads();
+  if (p.coef) {
+    for (int s = t; s < S; s += 256) {
+      const float4 a = *(const float4*)(sDS + s * QH), b = *(const float4*)(sDS + s * QH + 4);
+      const float4 c = *(const float4*)(sPD + s * QH), d = *(const float4*)(sPD + s * QH + 4);
+      uint4 lo, hi;
+      lo.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+      lo.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+      lo.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+      lo.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+      hi.x = (uint32_t)f32_to_bf16(c.x) | ((uint32_t)f32_to_bf16(c.y) << 16);
+      hi.y = (uint32_t)f32_to_bf16(c.z) | ((uint32_t)f32_to_bf16(c.w) << 16);
+      hi.z = (uint32_t)f32_to_bf16(d.x) | ((uint32_t)f32_to_bf16(d.y) << 16);
+      hi.w = (uint32_t)f32_to_bf16(d.z) | ((uint32_t)f32_to_bf16(d.w) << 16);
+      uint4* dst = (uint4*)(p.coef + (row0 + s) * (size_t)p.coef_ld + p.coef_col);
+      dst[0] = lo;
+      dst[1] = hi;
+    }
+  }
+  cq_f4 z[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) z[n] = cq_f4{0.f, 0.f, 0.f, 0.f};
+  const int fsw = jrow | ((lg & 1) << 2);
+  const char* half = sX + (wave >> 1) * HALF;
+  for (int ks = 0; ks < SP32 / 32; ++ks) {
+    uint4 pa = make_uint4(0u, 0u, 0u, 0u);
+    if (lr < QH) pa = *(const uint4*)(sDSb + lr * SMAX + ks * 32 + lg * 8);
+    const int r0 = ks * 32 + 8 * lg + jrow;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int blk16 = (wave & 1) * 4 + n;
+      const int cb = ((blk16 ^ fsw) << 5) + q * 8;
+      const cq_bf4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) cq_bf4*)(half + r0 * 256 + cb));
+      const cq_bf4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) cq_bf4*)(half + (r0 + 4) * 256 + cb));
+      const cq_bf8 b = cq_bf8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      z[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const cq_bf8*)&pa, b, z[n], 0, 0, 0);
+    }
+  }
+  if (lg < 2) {
+    u16* drow = (u16*)p.du + (size_t)f * QH * QE;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) drow[(4 * lg + rr) * QE + wave * 64 + 16 * n + lr] = f32_to_bf16(z[n][rr]);
+  }
+}
+
+// d(memory) of all the layers at once (bf16 mode): per frame  D [S][E] = C [S][KP] . B [KP][E]  with C the coefficient rows the
+// layers' backward kernels left (k = 16 * layer + {ds[h], 8 + pd[h]}) and B row k = u_layer[h] or d_z_layer[h] - 10 x 16 output
+// tiles of v_mfma_f32_16x16x32_bf16 over KP / 32 k-steps.  C fragments are 16 contiguous bytes of a row (k along the lane's eight
+// values: the natural A operand); B is staged in LDS k-major as it lies in HBM and read with the transposing ds_read_b64_tr_b16
+// (the image and its 32-byte-block swizzle are the weight-gradient kernels': gemm_conv.hip wgrad_wide_body).  Wavefront w owns
+// channels 64 w .. 64 w + 63: its twelve B fragments live in registers across the row tiles; results go through a per-wavefront
+// LDS transposition so that every row is stored as 128 contiguous bytes.  One fp32-free pass writes the gradient in bf16.
+constexpr int DM_MAXL = 8;
+struct CrossDmemParams {
+  const u16* coef;
+  const u16* u[DM_MAXL];
+  const u16* dz[DM_MAXL];
+  u16* dmem;
+  int F, S, NL, ldz, coef_ld;
+};
+typedef __bf16 dm_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dm_bf4 __attribute__((ext_vector_type(4)));
+typedef float dm_f4 __attribute__((ext_vector_type(4)));
+
+template <int KT>  // k-steps of 32 (KP = 32 KT)
+__global__ __launch_bounds__(256) void cross_q1_dmem_kernel(CrossDmemParams p) {
+  constexpr int KP = 32 * KT, HALF = KP * 256;   // one 128-channel half of the B image: KP rows of 256 bytes
+  __shared__ __attribute__((aligned(16))) char sB[2 * HALF];
+  __shared__ __attribute__((aligned(16))) float sT[4][16 * 64];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int f = blockIdx.x, S = p.S;
+  const int lr = lane & 15, lg = lane >> 4, jrow = lr >> 2, q = lr & 3;
+  const size_t row0 = (size_t)f * S;
+  // the coefficient fragments of the first PF row tiles (S <= 160: all of them) are requested before anything else: a tile's
+  // load -> MFMA -> store chain would otherwise pay the memory latency once per tile (measured: 128 us per launch, latency-bound)
+  constexpr int PF = 10;
+  auto load_a = [&](int m0, int ks) {
+    const int ra = m0 + lr;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (ra < S) v = *(const uint4*)(p.coef + (row0 + ra) * (size_t)p.coef_ld + ks * 32 + lg * 8);
+    return v;
+  };
+  uint4 apf[PF][KT];
+#pragma unroll
+  for (int mt = 0; mt < PF; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) apf[mt][ks] = load_a(mt * 16, ks);
+  // B image: row k, 32 chunks of 8 channels; chunk c of half hf sits at 16-byte slot (((c >> 1) ^ swz(k)) << 1) | (c & 1)
+  {
+    constexpr int NCH = KP * 32 / 256;  // chunks per thread
+    uint4 v[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = t + i * 256, k = idx >> 5, ch = idx & 31;
+      const int l = k >> 4, kind = (k >> 3) & 1, h = k & 7;
+      v[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (l < p.NL && p.u[l]) {
+        const u16* src = kind ? p.dz[l] + (size_t)f * p.ldz + h * QE : p.u[l] + ((size_t)f * QH + h) * QE;
+        v[i] = *(const uint4*)(src + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = t + i * 256, k = idx >> 5, ch = idx & 31;
+      const int hf = ch >> 4, c16 = ch & 15;
+      const int swz = (k & 3) | (((k >> 3) & 1) << 2);
+      const int slot = (((c16 >> 1) ^ swz) << 1) | (c16 & 1);
+      *(uint4*)(sB + hf * HALF + k * 256 + slot * 16) = v[i];
+    }
+  }
+  __syncthreads();
+  const int fsw = jrow | ((lg & 1) << 2);  // the swizzle of rows 8 lg + jrow (+ 4) of any k-step
+  dm_bf8 bf[4][KT];
+  {
+    const char* half = sB + (wave >> 1) * HALF;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int blk16 = (wave & 1) * 4 + n;
+#pragma unroll
+      for (int ks = 0; ks < KT; ++ks) {
+        const int r0 = ks * 32 + 8 * lg + jrow;
+        const int cb = ((blk16 ^ fsw) << 5) + q * 8;
+        const dm_bf4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) dm_bf4*)(half + r0 * 256 + cb));
+        const dm_bf4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) dm_bf4*)(half + (r0 + 4) * 256 + cb));
+        bf[n][ks] = dm_bf8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+  }
+  float* st = sT[wave];
+  auto tile = [&](int m0, const uint4 (&a4)[KT]) {
+    dm_bf8 af[KT];
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) af[ks] = *(const dm_bf8*)&a4[ks];
+    dm_f4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      acc[n] = dm_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KT; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf[n][ks], acc[n], 0, 0, 0);
+    }
+    // D[i][j]: lane holds rows i = 4 lg + rr, column j = lr of tile n  ->  st[row][16 n + lr] (row pitch 64 floats, rows
+    // rotated by 16 floats per row group of four so that the four lane groups hit different banks)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) st[(4 * lg + rr) * 64 + ((16 * n + lr + 16 * lg) & 63)] = acc[n][rr];
+    // (same wavefront reads what it wrote: LDS operations of a wavefront complete in order)
+    const int row = lane >> 2, c0 = (lane & 3) * 16;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+      const float4 x = *(const float4*)(st + row * 64 + ((c0 + e + 16 * (row >> 2)) & 63));
+      v[e] = x.x; v[e + 1] = x.y; v[e + 2] = x.z; v[e + 3] = x.w;
+    }
+    if (m0 + row < S) {
+      uint4 o0, o1;
+      o0.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      o0.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      o0.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+      o0.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+      o1.x = (uint32_t)f32_to_bf16(v[8]) | ((uint32_t)f32_to_bf16(v[9]) << 16);
+      o1.y = (uint32_t)f32_to_bf16(v[10]) | ((uint32_t)f32_to_bf16(v[11]) << 16);
+      o1.z = (uint32_t)f32_to_bf16(v[12]) | ((uint32_t)f32_to_bf16(v[13]) << 16);
+      o1.w = (uint32_t)f32_to_bf16(v[14]) | ((uint32_t)f32_to_bf16(v[15]) << 16);
+      uint4* dst = (uint4*)(p.dmem + (row0 + m0 + row) * QE + wave * 64 + c0);
+      dst[0] = o0;
+      dst[1] = o1;
+    }
+  };
+#pragma unroll
+  for (int mt = 0; mt < PF; ++mt)
+    if (mt * 16 < S) tile(mt * 16, apf[mt]);
+  for (int m0 = PF * 16; m0 < S; m0 += 16) {
+    uint4 a4[KT];
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) a4[ks] = load_a(m0, ks);
+    tile(m0, a4);
+  }
 }
 
 // Block-structured forms of a per-head projection W [E][E] (row j = output channel j of head j / hd): column block h of
@@ -409,40 +856,103 @@ extern "C" int td_cross_q1_fwd(const void* u, const void* mem, const void* pos, 
     const double es = dtype == TD_BF16 ? 2.0 : 4.0;
     prof_set_bytes((double)F * S * QE * es * (pos ? 2.0 : 1.0) + (double)F * QH * S * 4.0 + (double)F * (QH * QE + ldz) * es);
   }
-  if (dtype == TD_BF16) cross_q1_fwd_kernel<u16><<<F, 256, lds, st>>>(p);
+  // TD_CROSS_Q1_MFMA=0: the VALU kernel in bf16 too (A/B; the fp32 mode always runs it: exact-fp32 parity)
+  static const int mfma_on = [] { const char* e_ = getenv("TD_CROSS_Q1_MFMA"); return e_ ? atoi(e_) : 1; }();
+  if (dtype == TD_BF16 && mfma_on && S <= 128) cross_q1_fwd_mfma_kernel<128><<<F, 256, 0, st>>>(p);
+  else if (dtype == TD_BF16 && mfma_on && S <= 160) cross_q1_fwd_mfma_kernel<160><<<F, 256, 0, st>>>(p);
+  else if (dtype == TD_BF16 && mfma_on && S <= 256) cross_q1_fwd_mfma_kernel<256><<<F, 256, 0, st>>>(p);
+  else if (dtype == TD_BF16) cross_q1_fwd_kernel<u16><<<F, 256, lds, st>>>(p);
   else cross_q1_fwd_kernel<float><<<F, 256, lds, st>>>(p);
   if (prof) prof_end(st);
   return check_launch("td_cross_q1_fwd");
 }
 
-extern "C" int td_cross_q1_bwd(const void* u, const void* mem, const void* pos, const float* probs, const void* d_zext, const float* dwavg,
-                               void* d_u, float* d_mem, int accumulate, int F, int S, int H, int E, int ldz, float dropout_p,
-                               uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream) {
-  TD_REQUIRE(u && mem && probs && d_zext && d_u, "td_cross_q1_bwd: null pointer");
-  TD_REQUIRE(d_mem || !accumulate, "td_cross_q1_bwd: accumulate without d_mem");
-  TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "td_cross_q1_bwd: bad dtype %d", dtype);
-  TD_REQUIRE(al16(u) && al16(mem) && al16(pos) && al16(d_zext) && al16(d_u) && al16(d_mem), "td_cross_q1_bwd: rows must be 16-byte aligned");
+static int cross_q1_bwd_launch(const void* u, const void* mem, const void* pos, const float* probs, const void* d_zext, const float* dwavg, void* d_u,
+                               float* d_mem, int accumulate, void* coef, int coef_ld, int coef_col, int F, int S, int H, int E, int ldz, float dropout_p,
+                               uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream, const char* who) {
+  TD_REQUIRE(u && mem && probs && d_zext && d_u, "%s: null pointer", who);
+  TD_REQUIRE(d_mem || !accumulate, "%s: accumulate without d_mem", who);
+  TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "%s: bad dtype %d", who, dtype);
+  TD_REQUIRE(al16(u) && al16(mem) && al16(pos) && al16(d_zext) && al16(d_u) && al16(d_mem) && al16(coef), "%s: rows must be 16-byte aligned", who);
   CrossQ1Params p;
   memset(&p, 0, sizeof(p));
-  int rc = fill_q1(p, F, S, H, E, ldz, dropout_p, dropout_seed, dropout_counter, "td_cross_q1_bwd");
+  int rc = fill_q1(p, F, S, H, E, ldz, dropout_p, dropout_seed, dropout_counter, who);
   if (rc) return rc;
   p.u = u; p.mem = mem; p.pos = pos; p.probs = (float*)probs; p.dz = d_zext; p.dwavg = dwavg; p.du = d_u; p.dmem = d_mem;
   p.accumulate = (accumulate && d_mem) ? 1 : 0;
+  p.coef = (u16*)coef; p.coef_ld = coef_ld; p.coef_col = coef_col;
   const int SP = (S + 3) & ~3;
   const size_t lds = (size_t)(3 * QH * SP + 4 * QH * QE) * sizeof(float);
-  TD_REQUIRE(lds <= 64 * 1024, "td_cross_q1_bwd: S=%d too large for LDS", S);
+  TD_REQUIRE(lds <= 64 * 1024, "%s: S=%d too large for LDS", who, S);
   hipStream_t st = (hipStream_t)stream;
   const bool prof = prof_on();
   if (prof) {
     prof_begin(TD_PROF_CROSS_Q1, dtype, 8.0 * F * S * QH * QE, st, F, S, QE, 0, 0, 1);
     const double es = dtype == TD_BF16 ? 2.0 : 4.0;
     prof_set_bytes((double)F * S * QE * es * (pos ? 2.0 : 1.0) + (d_mem ? (double)F * S * QE * 4.0 * (accumulate ? 2.0 : 1.0) : 0.0) + (double)F * QH * S * 4.0 +
-                   (double)F * (2 * QH * QE + ldz) * es);
+                   (double)F * (2 * QH * QE + ldz) * es + (coef ? (double)F * S * 32.0 : 0.0));
   }
-  if (dtype == TD_BF16) cross_q1_bwd_kernel<u16><<<F, 256, lds, st>>>(p);
+  // the matrix-pipe kernel can serve the bf16 launches that do not touch an fp32 d(memory) (deferred, or not wanted).  Measured at
+  // 1 600 frames x 151 rows: 142 us against 131 us for the VALU kernel in the same mode (one workgroup per CU: every wavefront pays
+  // three dependent memory round trips) - off by default, TD_CROSS_Q1_BWD_MFMA=1 selects it
+  static const int mfma_on = [] { const char* e_ = getenv("TD_CROSS_Q1_BWD_MFMA"); return e_ ? atoi(e_) : 0; }();
+  if (dtype == TD_BF16 && mfma_on && !d_mem && S <= 128) cross_q1_bwd_mfma_kernel<128><<<F, 256, 0, st>>>(p);
+  else if (dtype == TD_BF16 && mfma_on && !d_mem && S <= 160) cross_q1_bwd_mfma_kernel<160><<<F, 256, 0, st>>>(p);
+  else if (dtype == TD_BF16 && mfma_on && !d_mem && S <= 256) cross_q1_bwd_mfma_kernel<256><<<F, 256, 0, st>>>(p);
+  else if (dtype == TD_BF16) cross_q1_bwd_kernel<u16><<<F, 256, lds, st>>>(p);
   else cross_q1_bwd_kernel<float><<<F, 256, lds, st>>>(p);
   if (prof) prof_end(st);
-  return check_launch("td_cross_q1_bwd");
+  return check_launch(who);
+}
+
+extern "C" int td_cross_q1_bwd(const void* u, const void* mem, const void* pos, const float* probs, const void* d_zext, const float* dwavg,
+                               void* d_u, float* d_mem, int accumulate, int F, int S, int H, int E, int ldz, float dropout_p,
+                               uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream) {
+  return cross_q1_bwd_launch(u, mem, pos, probs, d_zext, dwavg, d_u, d_mem, accumulate, nullptr, 0, 0, F, S, H, E, ldz, dropout_p, dropout_seed, dropout_counter,
+                             dtype, stream, "td_cross_q1_bwd");
+}
+
+extern "C" int td_cross_q1_bwd_coef(const void* u, const void* mem, const void* pos, const float* probs, const void* d_zext, const float* dwavg,
+                                    void* d_u, void* coef, int coef_ld, int coef_col, int F, int S, int H, int E, int ldz, float dropout_p,
+                                    uint32_t dropout_seed, const uint32_t* dropout_counter, int dtype, td_stream_t stream) {
+  TD_REQUIRE(coef && dtype == TD_BF16, "td_cross_q1_bwd_coef: the deferred d(memory) is a bf16-mode path (fp32 accumulates in td_cross_q1_bwd)");
+  TD_REQUIRE(coef_ld % 32 == 0 && coef_col % 16 == 0 && coef_col >= 0 && coef_col + 16 <= coef_ld, "td_cross_q1_bwd_coef: coef_ld=%d must be a multiple of 32, coef_col=%d a multiple of 16 inside it", coef_ld, coef_col);
+  return cross_q1_bwd_launch(u, mem, pos, probs, d_zext, dwavg, d_u, nullptr, 0, coef, coef_ld, coef_col, F, S, H, E, ldz, dropout_p, dropout_seed,
+                             dropout_counter, dtype, stream, "td_cross_q1_bwd_coef");
+}
+
+extern "C" int td_cross_q1_dmem(const void* coef, int coef_ld, const void* const* u, const void* const* d_zext, int n_layers, void* d_mem, int F, int S,
+                                int H, int E, int ldz, int dtype, td_stream_t stream) {
+  TD_REQUIRE(coef && u && d_zext && d_mem, "td_cross_q1_dmem: null pointer");
+  TD_REQUIRE(dtype == TD_BF16, "td_cross_q1_dmem: bf16 only");
+  TD_REQUIRE(E == QE && H == QH, "td_cross_q1_dmem: built for %d channels in %d heads (got E=%d H=%d)", QE, QH, E, H);
+  TD_REQUIRE(F >= 1 && S >= 1 && n_layers >= 1 && n_layers <= DM_MAXL, "td_cross_q1_dmem: bad sizes F=%d S=%d layers=%d (at most %d)", F, S, n_layers, DM_MAXL);
+  TD_REQUIRE(coef_ld % 32 == 0 && coef_ld >= 16 * n_layers && coef_ld <= 32 * 4, "td_cross_q1_dmem: coef_ld=%d must be a multiple of 32 holding 16 columns per layer", coef_ld);
+  TD_REQUIRE(ldz >= QH * QE + QH && ldz % 8 == 0, "td_cross_q1_dmem: ldz=%d", ldz);
+  CrossDmemParams p;
+  memset(&p, 0, sizeof(p));
+  p.coef = (const u16*)coef; p.dmem = (u16*)d_mem; p.F = F; p.S = S; p.NL = n_layers; p.ldz = ldz; p.coef_ld = coef_ld;
+  for (int l = 0; l < n_layers; ++l) {
+    TD_REQUIRE((u[l] == nullptr) == (d_zext[l] == nullptr), "td_cross_q1_dmem: layer %d: u and d_zext must both be given or both be NULL", l);
+    TD_REQUIRE(al16(u[l]) && al16(d_zext[l]), "td_cross_q1_dmem: rows must be 16-byte aligned");
+    p.u[l] = (const u16*)u[l];
+    p.dz[l] = (const u16*)d_zext[l];
+  }
+  TD_REQUIRE(al16(coef) && al16(d_mem), "td_cross_q1_dmem: rows must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const bool prof = prof_on();
+  if (prof) {
+    prof_begin(TD_PROF_CROSS_Q1, dtype, 2.0 * F * S * coef_ld * QE, st, F, S, QE, 0, 0, 2);
+    prof_set_bytes((double)F * S * (coef_ld + QE) * 2.0 + (double)F * n_layers * (QH * QE + ldz) * 2.0);
+  }
+  switch (coef_ld / 32) {
+    case 1: cross_q1_dmem_kernel<1><<<F, 256, 0, st>>>(p); break;
+    case 2: cross_q1_dmem_kernel<2><<<F, 256, 0, st>>>(p); break;
+    case 3: cross_q1_dmem_kernel<3><<<F, 256, 0, st>>>(p); break;
+    default: cross_q1_dmem_kernel<4><<<F, 256, 0, st>>>(p); break;
+  }
+  if (prof) prof_end(st);
+  return check_launch("td_cross_q1_dmem");
 }
 
 extern "C" int td_head_blocks_expand(const float* W, const float* bias, float alpha, void* w_n, void* w_t, int E, int H, int dtype,

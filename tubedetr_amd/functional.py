@@ -646,6 +646,11 @@ class _CrossQ1Shared:
         self.mem, self.pos = mem, pos
         self.dmem = None
         self.want_dmem = want_dmem  # False: the memory needs no gradient (nothing will collect the buffer)
+        # bf16 mode (TD_CROSS_DMEM_DEFER=0: off): no fp32 [F*S, E] buffer and no read-modify-write per layer - every layer's backward
+        # leaves sixteen coefficients per memory row in `coef`, CrossMemFn.backward forms the gradient of all layers in one pass
+        self.n_layers = 0   # layer nodes that took this memory in the forward pass (their index = their coefficient block)
+        self.coef = None    # [F*S, pad32(16 * n_layers)] bf16, zero-filled
+        self.deferred = {}  # layer index -> (u, d_zext) of a layer whose backward has run
 
 
 class CrossMemFn(Function):
@@ -662,6 +667,13 @@ class CrossMemFn(Function):
     def backward(ctx, g):
         sh = ctx.shared
         assert g is None, "the consumers of CrossMemFn hand their gradient over through the shared buffer"
+        if sh.coef is not None:
+            assert sh.dmem is None
+            E = sh.mem.shape[1]
+            F_, H = next(iter(sh.deferred.values()))[0].shape[0], next(iter(sh.deferred.values()))[0].shape[1] // E
+            d = ops.cross_q1_dmem(sh.coef, [sh.deferred.get(l) for l in range(sh.n_layers)], F_, sh.mem.shape[0] // F_, H, E)
+            sh.coef, sh.deferred = None, {}
+            return d, None
         if sh.dmem is None:
             return None, None
         d = sh.dmem if sh.mem.dtype == torch.float32 else ops.cast(sh.dmem, sh.mem.dtype)
@@ -705,6 +717,8 @@ class CrossQ1Fn(Function):
         ctx.cfg = (F, S, H, E, scale, p_attn, seed_attn, p_out, seed_out)
         ctx.params = (W_in, b_in, W_out, b_out)
         ctx.shared = shared
+        ctx.layer = shared.n_layers
+        shared.n_layers += 1
         return out, (wavg if need_w else None)
 
     @staticmethod
@@ -723,15 +737,21 @@ class CrossQ1Fn(Function):
         d_zext = ops.linear_fwd(dctx, wv_t)
         Gv = ops.linear_wgrad(dctx, zext)  # dense [E, H*E + H]; (not through the batched launch: its job-table ring is sized for a few calls per step)
         ops.head_blocks_extract(Gv, 1.0, dW_in[2 * E :], db_in[2 * E :], H)
-        first = sh.dmem is None
-        if not sh.want_dmem:
-            dmem = None  # the memory needs no gradient: the kernel neither forms nor stores it
-        elif first:
-            dmem = sh.dmem = torch.empty((F * S, E), dtype=torch.float32, device=dev)
-        else:
-            dmem = sh.dmem
         dwa = dwavg.contiguous().float() if dwavg is not None else None
-        d_u = ops.cross_q1_bwd(u, sh.mem, sh.pos, probs, d_zext, dwa, dmem, sh.want_dmem and not first, F, S, H, dropout_p=p_attn, seed=seed_attn)
+        if sh.want_dmem and dt == torch.bfloat16 and _CROSS_DMEM_DEFER and sh.n_layers <= 8 and sh.dmem is None:
+            if sh.coef is None:
+                sh.coef = torch.zeros((F * S, (16 * sh.n_layers + 31) // 32 * 32), dtype=dt, device=dev)
+            d_u = ops.cross_q1_bwd_coef(u, sh.mem, sh.pos, probs, d_zext, dwa, sh.coef, 16 * ctx.layer, F, S, H, dropout_p=p_attn, seed=seed_attn)
+            sh.deferred[ctx.layer] = (u, d_zext)
+        else:
+            first = sh.dmem is None
+            if not sh.want_dmem:
+                dmem = None  # the memory needs no gradient: the kernel neither forms nor stores it
+            elif first:
+                dmem = sh.dmem = torch.empty((F * S, E), dtype=torch.float32, device=dev)
+            else:
+                dmem = sh.dmem
+            d_u = ops.cross_q1_bwd(u, sh.mem, sh.pos, probs, d_zext, dwa, dmem, sh.want_dmem and not first, F, S, H, dropout_p=p_attn, seed=seed_attn)
         dq = ops.linear_fwd(d_u, wk_n)
         Gk = ops.linear_wgrad(q, d_u)
         ops.head_blocks_extract(Gk, scale, dW_in[E : 2 * E], None, H)
@@ -745,6 +765,9 @@ class CrossQ1Fn(Function):
         need_pos = q_pos is not None and ctx.needs_input_grad[1]
         d_q_in = ops.linear_fwd(dq, wq_d) if (ctx.needs_input_grad[0] or need_pos) else None
         return (d_q_in if ctx.needs_input_grad[0] else None, d_q_in if need_pos else None, None, dW_in, db_in, dW_out, db_out) + (None,) * 10
+
+
+_CROSS_DMEM_DEFER = _os.environ.get("TD_CROSS_DMEM_DEFER", "1") != "0"
 
 
 def cross_q1_memory(mem, pos):

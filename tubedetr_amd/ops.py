@@ -586,6 +586,38 @@ def cross_q1_bwd(u: Tensor, mem: Tensor, pos: Optional[Tensor], probs: Tensor, d
     return d_u
 
 
+def cross_q1_bwd_coef(u: Tensor, mem: Tensor, pos: Optional[Tensor], probs: Tensor, d_zext: Tensor, dwavg: Optional[Tensor], coef: Tensor, coef_col: int,
+                      F: int, S: int, H: int, *, dropout_p: float = 0.0, seed: int = 0) -> Tensor:
+    """cross_q1_bwd for the deferred d(memory) of the bf16 mode: -> d_u [F, H*E]; instead of touching a [F*S, E] gradient the layer leaves
+    its sixteen coefficients per memory row in columns coef_col .. coef_col + 15 of ``coef`` [F*S, KP] bf16 (cross_q1_dmem forms the
+    gradient of all layers from them in one pass)."""
+    E = mem.shape[1]
+    assert u.dtype == torch.bfloat16 and d_zext.shape == (F, H * E + H) and d_zext.is_contiguous() and d_zext.dtype == u.dtype and probs.is_contiguous()
+    assert coef.dtype == torch.bfloat16 and coef.is_contiguous() and coef.shape[0] == F * S and coef.shape[1] % 32 == 0 and coef_col % 16 == 0 and coef_col + 16 <= coef.shape[1]
+    assert dwavg is None or (dwavg.dtype == torch.float32 and dwavg.is_contiguous() and dwavg.numel() == F * S)
+    d_u = torch.empty((F, H * E), dtype=u.dtype, device=u.device)
+    check(_hip.lib().td_cross_q1_bwd_coef(ptr(u), ptr(mem), ptr(pos), ptr(probs), ptr(d_zext), ptr(dwavg), ptr(d_u), ptr(coef), coef.shape[1], coef_col, F, S, H, E,
+                                          H * E + H, dropout_p, seed & 0xFFFFFFFF, _ctr() if dropout_p > 0 else None, dtype_code(u.dtype), stream_ptr()),
+          "td_cross_q1_bwd_coef")
+    return d_u
+
+
+def cross_q1_dmem(coef: Tensor, layers, F: int, S: int, H: int, E: int) -> Tensor:
+    """d(memory) [F*S, E] bf16 of all the time-aligned cross-attention layers from their coefficient rows (cross_q1_bwd_coef) and
+    ``layers`` = [(u_l, d_zext_l) | None per layer]: one MFMA product per frame (csrc/cross_attn.hip cross_q1_dmem_kernel)."""
+    import ctypes as C
+
+    n = len(layers)
+    assert coef.dtype == torch.bfloat16 and coef.is_contiguous() and coef.shape == (F * S, coef.shape[1]) and coef.shape[1] >= 16 * n
+    us = (C.c_void_p * n)(*[(ptr(l[0]) if l is not None else None) for l in layers])
+    dzs = (C.c_void_p * n)(*[(ptr(l[1]) if l is not None else None) for l in layers])
+    for l in layers:
+        assert l is None or (l[0].dtype == torch.bfloat16 and l[0].shape == (F, H * E) and l[0].is_contiguous() and l[1].shape == (F, H * E + H) and l[1].is_contiguous())
+    d_mem = torch.empty((F * S, E), dtype=torch.bfloat16, device=coef.device)
+    check(_hip.lib().td_cross_q1_dmem(ptr(coef), coef.shape[1], us, dzs, n, ptr(d_mem), F, S, H, E, H * E + H, dtype_code(coef.dtype), stream_ptr()), "td_cross_q1_dmem")
+    return d_mem
+
+
 def mha_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, probs: Tensor, dwavg: Optional[Tensor], H: int, scale: float,
             dq: Tensor, dk: Tensor, dv: Tensor, *, dropout_p: float = 0.0, seed: int = 0):
     """dq/dk/dv must be allocated by the caller with exactly the strides of q/k/v (e.g. views of a packed buffer)."""
