@@ -157,8 +157,9 @@ def mfma(src, dst, command=""):
         is_q1 = lambda r: "td::cross_q1_" in r["kernel"]
         res["decoder_attention_group_precise"] = {
             "definition": "decoder temporal self-attention kernels (mha_*_mfma_kernel, probabilities-based instances) + the time-aligned cross-attention: "
-                          "its frame core td::cross_q1_*_kernel (key / value projections moved to the query side: the memory rows are not projected, "
-                          "the core is fp32 VALU arithmetic bound by the HBM read of the memory rows), or - TD_CROSS_Q1=0 - the hoisted key / value "
+                          "its frame core td::cross_q1_*_kernel (key / value projections moved to the query side: the memory rows are not projected; in bf16 "
+                          "the score and weighted-sum products and the deferred d(memory) pass are v_mfma_f32_16x16x32_bf16 tiles, HBM-bound by the memory "
+                          "rows: a few MFMAs per kilobyte), or - TD_CROSS_Q1=0 - the hoisted key / value "
                           "projection GEMMs (launches of td::conv_gemm_kernel with grid " + (kv_grid or "<TD_KV_GRID unset>") + ")",
             "target": 0.40, "attention_kernels": util_rows(is_att), "cross_q1_frame_core": util_rows(is_q1), "kv_projections": util_rows(is_kv),
             "group": util_rows(lambda r: is_att(r) or is_kv(r) or is_q1(r))}

@@ -233,14 +233,14 @@ __global__ __launch_bounds__(256) void cross_q1_fwd_kernel(CrossQ1Params p) {
 //   sums    D[head][chan]  = P [16 x S] . X       (A = the probabilities after dropout in bf16; B = the SAME rows, now needed with the
 //           row index along the lane's eight values: the wavefront that fetched a row tile also left it in an LDS image, read back
 //           with the transposing ds_read_b64_tr_b16 - the memory rows come from HBM once, the VALU kernel's second pass re-read them)
-// Wavefront w fetches row tiles w, w + 4, ... (16 rows x 512 bytes of memory + as much of pos in flight per tile) and owns channels
-// 64 w .. 64 w + 63 of the sums.  Softmax, dropout mask, probs / wavg outputs: exactly the VALU kernel's code on fp32 scores.
+// Eight wavefronts per frame: wavefront w fetches row tiles w, w + 8 (16 rows x 512 bytes of memory + as much of pos in flight per
+// tile), normalises head w and owns channels 32 w .. 32 w + 31 of the sums.  Softmax, dropout mask, probs / wavg outputs: exactly the VALU kernel's code on fp32 scores.
 typedef __bf16 cq_bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cq_bf4 __attribute__((ext_vector_type(4)));
 typedef float cq_f4 __attribute__((ext_vector_type(4)));
 
 template <int SMAX>
-__global__ __launch_bounds__(256) void cross_q1_fwd_mfma_kernel(CrossQ1Params p) {
+__global__ __launch_bounds__(512) void cross_q1_fwd_mfma_kernel(CrossQ1Params p) {
   constexpr int HALF = SMAX * 256;  // one 128-channel half of the row image: SMAX rows of 256 bytes
   __shared__ __attribute__((aligned(16))) char sX[2 * HALF];
   __shared__ __attribute__((aligned(16))) float sS[QH * SMAX];   // scores, then exp(score - max)
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void cross_q1_fwd_mfma_kernel(CrossQ1Params p)
     ua[ks] = make_uint4(0u, 0u, 0u, 0u);
     if (lr < QH) ua[ks] = *(const uint4*)((const u16*)p.u + ((size_t)f * QH + lr) * QE + ks * 32 + lg * 8);
   }
-  for (int m0 = wave * 16; m0 < SP32; m0 += 64) {
+  for (int m0 = wave * 16; m0 < SP32; m0 += 128) {
     const int row = m0 + lr;
     const bool valid = row < S;
     uint4 xm[8], xp[8];
@@ -299,9 +299,8 @@ __global__ __launch_bounds__(256) void cross_q1_fwd_mfma_kernel(CrossQ1Params p)
   }
   __syncthreads();
   const uint32_t seed = effective_seed(p.seed, p.seed_dev);
-#pragma unroll 1
-  for (int hh = 0; hh < 2; ++hh) {
-    const int h = wave + 4 * hh;
+  {
+    const int h = wave;  // one head per wavefront
     float* row = sS + h * SMAX;
     float mx = -INFINITY;
     for (int s = lane; s < S; s += 64) {
@@ -337,23 +336,23 @@ __global__ __launch_bounds__(256) void cross_q1_fwd_mfma_kernel(CrossQ1Params p)
   }
   __syncthreads();
   if (p.wavg)
-    for (int s = t; s < S; s += 256) {
+    for (int s = t; s < S; s += 512) {
       const float4 a = *(const float4*)(sP + s * QH), b = *(const float4*)(sP + s * QH + 4);
       p.wavg[row0 + s] = (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * (1.f / QH);
     }
   // sums: this wavefront's 64 channels = four 16-column blocks of half wave >> 1
-  cq_f4 z[4];
+  cq_f4 z[2];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) z[n] = cq_f4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < 2; ++n) z[n] = cq_f4{0.f, 0.f, 0.f, 0.f};
   const int fsw = jrow | ((lg & 1) << 2);
-  const char* half = sX + (wave >> 1) * HALF;
+  const char* half = sX + (wave >> 2) * HALF;
   for (int ks = 0; ks < SP32 / 32; ++ks) {
     uint4 pa = make_uint4(0u, 0u, 0u, 0u);
     if (lr < QH) pa = *(const uint4*)(sPb + lr * SMAX + ks * 32 + lg * 8);
     const int r0 = ks * 32 + 8 * lg + jrow;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int blk16 = (wave & 1) * 4 + n;
+    for (int n = 0; n < 2; ++n) {
+      const int blk16 = (wave & 3) * 2 + n;
       const int cb = ((blk16 ^ fsw) << 5) + q * 8;
       const cq_bf4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) cq_bf4*)(half + r0 * 256 + cb));
       const cq_bf4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) cq_bf4*)(half + (r0 + 4) * 256 + cb));
@@ -365,9 +364,9 @@ __global__ __launch_bounds__(256) void cross_q1_fwd_mfma_kernel(CrossQ1Params p)
   if (lg < 2) {
     u16* zrow = (u16*)p.zext + (size_t)f * p.ldz;
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) zrow[(4 * lg + rr) * QE + wave * 64 + 16 * n + lr] = f32_to_bf16(z[n][rr]);
+      for (int rr = 0; rr < 4; ++rr) zrow[(4 * lg + rr) * QE + wave * 32 + 16 * n + lr] = f32_to_bf16(z[n][rr]);
   }
   if (t < QH) ((u16*)p.zext)[(size_t)f * p.ldz + QH * QE + t] = f32_to_bf16(sSp[t]);
 }
@@ -506,7 +505,7 @@ __global__ __launch_bounds__(256) void cross_q1_bwd_kernel(CrossQ1Params p) {
 // probabilities (d_u = sum_s ds[h][s] (x_s + pos_s): the image holds the SUM of the memory and positional rows, added in fp32 and
 // rounded once to bf16 - the rows are fetched from HBM once).  The softmax backward in between is the VALU kernel's.
 template <int SMAX>
-__global__ __launch_bounds__(256) void cross_q1_bwd_mfma_kernel(CrossQ1Params p) {
+__global__ __launch_bounds__(512) void cross_q1_bwd_mfma_kernel(CrossQ1Params p) {
   constexpr int HALF = SMAX * 256;
   __shared__ __attribute__((aligned(16))) char sX[2 * HALF];
   __shared__ __attribute__((aligned(16))) float sS[QH * SMAX];    // d_z . x_s, then dP
@@ -526,7 +525,7 @@ __global__ __launch_bounds__(256) void cross_q1_bwd_mfma_kernel(CrossQ1Params p)
     da[ks] = make_uint4(0u, 0u, 0u, 0u);
     if (lr < QH) da[ks] = *(const uint4*)((const u16*)p.dz + (size_t)f * p.ldz + lr * QE + ks * 32 + lg * 8);
   }
-  for (int m0 = wave * 16; m0 < SP32; m0 += 64) {
+  for (int m0 = wave * 16; m0 < SP32; m0 += 128) {
     const int row = m0 + lr;
     const bool valid = row < S;
     uint4 xm[8], xp[8];
@@ -571,9 +570,8 @@ __global__ __launch_bounds__(256) void cross_q1_bwd_mfma_kernel(CrossQ1Params p)
   }
   __syncthreads();
   const uint32_t seed = effective_seed(p.seed, p.seed_dev);
-#pragma unroll 1
-  for (int hh = 0; hh < 2; ++hh) {
-    const int h = wave + 4 * hh;
+  {
+    const int h = wave;  // one head per wavefront
     float* row = sS + h * SMAX;
     const float dsp = Elem<u16>::load(p.dz, (size_t)f * p.ldz + QH * QE + h);
     const size_t prow = ((size_t)f * QH + h) * S;
@@ -600,7 +598,7 @@ __global__ __launch_bounds__(256) void cross_q1_bwd_mfma_kernel(CrossQ1Params p)
   }
   __syncthreads();
   if (p.coef) {
-    for (int s = t; s < S; s += 256) {
+    for (int s = t; s < S; s += 512) {
       const float4 a = *(const float4*)(sDS + s * QH), b = *(const float4*)(sDS + s * QH + 4);
       const float4 c = *(const float4*)(sPD + s * QH), d = *(const float4*)(sPD + s * QH + 4);
       uint4 lo, hi;
@@ -617,18 +615,18 @@ __global__ __launch_bounds__(256) void cross_q1_bwd_mfma_kernel(CrossQ1Params p)
       dst[1] = hi;
     }
   }
-  cq_f4 z[4];
+  cq_f4 z[2];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) z[n] = cq_f4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < 2; ++n) z[n] = cq_f4{0.f, 0.f, 0.f, 0.f};
   const int fsw = jrow | ((lg & 1) << 2);
-  const char* half = sX + (wave >> 1) * HALF;
+  const char* half = sX + (wave >> 2) * HALF;
   for (int ks = 0; ks < SP32 / 32; ++ks) {
     uint4 pa = make_uint4(0u, 0u, 0u, 0u);
     if (lr < QH) pa = *(const uint4*)(sDSb + lr * SMAX + ks * 32 + lg * 8);
     const int r0 = ks * 32 + 8 * lg + jrow;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int blk16 = (wave & 1) * 4 + n;
+    for (int n = 0; n < 2; ++n) {
+      const int blk16 = (wave & 3) * 2 + n;
       const int cb = ((blk16 ^ fsw) << 5) + q * 8;
       const cq_bf4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) cq_bf4*)(half + r0 * 256 + cb));
       const cq_bf4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) cq_bf4*)(half + (r0 + 4) * 256 + cb));
@@ -639,9 +637,9 @@ __global__ __launch_bounds__(256) void cross_q1_bwd_mfma_kernel(CrossQ1Params p)
   if (lg < 2) {
     u16* drow = (u16*)p.du + (size_t)f * QH * QE;
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) drow[(4 * lg + rr) * QE + wave * 64 + 16 * n + lr] = f32_to_bf16(z[n][rr]);
+      for (int rr = 0; rr < 4; ++rr) drow[(4 * lg + rr) * QE + wave * 32 + 16 * n + lr] = f32_to_bf16(z[n][rr]);
   }
 }
 
@@ -664,29 +662,32 @@ typedef __bf16 dm_bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 dm_bf4 __attribute__((ext_vector_type(4)));
 typedef float dm_f4 __attribute__((ext_vector_type(4)));
 
+#ifndef TD_DM_ABL
+#define TD_DM_ABL 0  // timing ablations (tools/build_variant.sh; results WRONG): 1 no stores, 2 no coefficient loads, 4 no u / d_z loads
+#endif
 template <int KT>  // k-steps of 32 (KP = 32 KT)
 __global__ __launch_bounds__(256) void cross_q1_dmem_kernel(CrossDmemParams p) {
   constexpr int KP = 32 * KT, HALF = KP * 256;   // one 128-channel half of the B image: KP rows of 256 bytes
   __shared__ __attribute__((aligned(16))) char sB[2 * HALF];
-  __shared__ __attribute__((aligned(16))) float sT[4][16 * 64];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int f = blockIdx.x, S = p.S;
   const int lr = lane & 15, lg = lane >> 4, jrow = lr >> 2, q = lr & 3;
   const size_t row0 = (size_t)f * S;
-  // the coefficient fragments of the first PF row tiles (S <= 160: all of them) are requested before anything else: a tile's
-  // load -> MFMA -> store chain would otherwise pay the memory latency once per tile (measured: 128 us per launch, latency-bound)
-  constexpr int PF = 10;
   auto load_a = [&](int m0, int ks) {
     const int ra = m0 + lr;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
+#if !(TD_DM_ABL & 2)
     if (ra < S) v = *(const uint4*)(p.coef + (row0 + ra) * (size_t)p.coef_ld + ks * 32 + lg * 8);
+#endif
     return v;
   };
-  uint4 apf[PF][KT];
+  // coefficient fragments two row tiles ahead (requested before the image is built: they fly during the fill)
+  uint4 a0[KT], a1[KT];
 #pragma unroll
-  for (int mt = 0; mt < PF; ++mt)
-#pragma unroll
-    for (int ks = 0; ks < KT; ++ks) apf[mt][ks] = load_a(mt * 16, ks);
+  for (int ks = 0; ks < KT; ++ks) {
+    a0[ks] = load_a(0, ks);
+    a1[ks] = load_a(16, ks);
+  }
   // B image: row k, 32 chunks of 8 channels; chunk c of half hf sits at 16-byte slot (((c >> 1) ^ swz(k)) << 1) | (c & 1)
   {
     constexpr int NCH = KP * 32 / 256;  // chunks per thread
@@ -696,10 +697,12 @@ __global__ __launch_bounds__(256) void cross_q1_dmem_kernel(CrossDmemParams p) {
       const int idx = t + i * 256, k = idx >> 5, ch = idx & 31;
       const int l = k >> 4, kind = (k >> 3) & 1, h = k & 7;
       v[i] = make_uint4(0u, 0u, 0u, 0u);
+#if !(TD_DM_ABL & 4)
       if (l < p.NL && p.u[l]) {
         const u16* src = kind ? p.dz[l] + (size_t)f * p.ldz + h * QE : p.u[l] + ((size_t)f * QH + h) * QE;
         v[i] = *(const uint4*)(src + ch * 8);
       }
+#endif
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -728,7 +731,8 @@ __global__ __launch_bounds__(256) void cross_q1_dmem_kernel(CrossDmemParams p) {
       }
     }
   }
-  float* st = sT[wave];
+  __syncthreads();  // every wavefront holds its fragments: the image is dead, its first 16 KiB become the four transposition buffers
+  float* st = (float*)sB + wave * (16 * 64);
   auto tile = [&](int m0, const uint4 (&a4)[KT]) {
     dm_bf8 af[KT];
 #pragma unroll
@@ -747,36 +751,37 @@ __global__ __launch_bounds__(256) void cross_q1_dmem_kernel(CrossDmemParams p) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) st[(4 * lg + rr) * 64 + ((16 * n + lr + 16 * lg) & 63)] = acc[n][rr];
     // (same wavefront reads what it wrote: LDS operations of a wavefront complete in order)
-    const int row = lane >> 2, c0 = (lane & 3) * 16;
-    float v[16];
-#pragma unroll
-    for (int e = 0; e < 16; e += 4) {
-      const float4 x = *(const float4*)(st + row * 64 + ((c0 + e + 16 * (row >> 2)) & 63));
-      v[e] = x.x; v[e + 1] = x.y; v[e + 2] = x.z; v[e + 3] = x.w;
-    }
+    // lane -> row lane / 4, channels 8 (lane % 4) .. + 8 of the first and of the second 32: an instruction stores 64 contiguous bytes per row
+    const int row = lane >> 2, c0 = (lane & 3) * 8, rot = 16 * (row >> 2);
+    const float4 x0 = *(const float4*)(st + row * 64 + ((c0 + rot) & 63)), x1 = *(const float4*)(st + row * 64 + ((c0 + 4 + rot) & 63));
+    const float4 y0 = *(const float4*)(st + row * 64 + ((c0 + 32 + rot) & 63)), y1 = *(const float4*)(st + row * 64 + ((c0 + 36 + rot) & 63));
+#if TD_DM_ABL & 1
+    if (m0 + row < S && x0.x == 123.456f) {
+#else
     if (m0 + row < S) {
+#endif
       uint4 o0, o1;
-      o0.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      o0.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-      o0.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-      o0.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
-      o1.x = (uint32_t)f32_to_bf16(v[8]) | ((uint32_t)f32_to_bf16(v[9]) << 16);
-      o1.y = (uint32_t)f32_to_bf16(v[10]) | ((uint32_t)f32_to_bf16(v[11]) << 16);
-      o1.z = (uint32_t)f32_to_bf16(v[12]) | ((uint32_t)f32_to_bf16(v[13]) << 16);
-      o1.w = (uint32_t)f32_to_bf16(v[14]) | ((uint32_t)f32_to_bf16(v[15]) << 16);
-      uint4* dst = (uint4*)(p.dmem + (row0 + m0 + row) * QE + wave * 64 + c0);
-      dst[0] = o0;
-      dst[1] = o1;
+      o0.x = (uint32_t)f32_to_bf16(x0.x) | ((uint32_t)f32_to_bf16(x0.y) << 16);
+      o0.y = (uint32_t)f32_to_bf16(x0.z) | ((uint32_t)f32_to_bf16(x0.w) << 16);
+      o0.z = (uint32_t)f32_to_bf16(x1.x) | ((uint32_t)f32_to_bf16(x1.y) << 16);
+      o0.w = (uint32_t)f32_to_bf16(x1.z) | ((uint32_t)f32_to_bf16(x1.w) << 16);
+      o1.x = (uint32_t)f32_to_bf16(y0.x) | ((uint32_t)f32_to_bf16(y0.y) << 16);
+      o1.y = (uint32_t)f32_to_bf16(y0.z) | ((uint32_t)f32_to_bf16(y0.w) << 16);
+      o1.z = (uint32_t)f32_to_bf16(y1.x) | ((uint32_t)f32_to_bf16(y1.y) << 16);
+      o1.w = (uint32_t)f32_to_bf16(y1.z) | ((uint32_t)f32_to_bf16(y1.w) << 16);
+      u16* dst = p.dmem + (row0 + m0 + row) * QE + wave * 64 + c0;
+      *(uint4*)dst = o0;
+      *(uint4*)(dst + 32) = o1;
     }
   };
+  // ONE loop over row-tile pairs (the two prefetch sets alternate); tiles past S are skipped by the wave-uniform tests
+  for (int m0 = 0; m0 < S; m0 += 32) {
+    tile(m0, a0);
 #pragma unroll
-  for (int mt = 0; mt < PF; ++mt)
-    if (mt * 16 < S) tile(mt * 16, apf[mt]);
-  for (int m0 = PF * 16; m0 < S; m0 += 16) {
-    uint4 a4[KT];
+    for (int ks = 0; ks < KT; ++ks) a0[ks] = load_a(m0 + 32, ks);
+    if (m0 + 16 < S) tile(m0 + 16, a1);
 #pragma unroll
-    for (int ks = 0; ks < KT; ++ks) a4[ks] = load_a(m0, ks);
-    tile(m0, a4);
+    for (int ks = 0; ks < KT; ++ks) a1[ks] = load_a(m0 + 48, ks);
   }
 }
 
@@ -858,9 +863,9 @@ extern "C" int td_cross_q1_fwd(const void* u, const void* mem, const void* pos, 
   }
   // TD_CROSS_Q1_MFMA=0: the VALU kernel in bf16 too (A/B; the fp32 mode always runs it: exact-fp32 parity)
   static const int mfma_on = [] { const char* e_ = getenv("TD_CROSS_Q1_MFMA"); return e_ ? atoi(e_) : 1; }();
-  if (dtype == TD_BF16 && mfma_on && S <= 128) cross_q1_fwd_mfma_kernel<128><<<F, 256, 0, st>>>(p);
-  else if (dtype == TD_BF16 && mfma_on && S <= 160) cross_q1_fwd_mfma_kernel<160><<<F, 256, 0, st>>>(p);
-  else if (dtype == TD_BF16 && mfma_on && S <= 256) cross_q1_fwd_mfma_kernel<256><<<F, 256, 0, st>>>(p);
+  if (dtype == TD_BF16 && mfma_on && S <= 128) cross_q1_fwd_mfma_kernel<128><<<F, 512, 0, st>>>(p);
+  else if (dtype == TD_BF16 && mfma_on && S <= 160) cross_q1_fwd_mfma_kernel<160><<<F, 512, 0, st>>>(p);
+  else if (dtype == TD_BF16 && mfma_on && S <= 256) cross_q1_fwd_mfma_kernel<256><<<F, 512, 0, st>>>(p);
   else if (dtype == TD_BF16) cross_q1_fwd_kernel<u16><<<F, 256, lds, st>>>(p);
   else cross_q1_fwd_kernel<float><<<F, 256, lds, st>>>(p);
   if (prof) prof_end(st);
@@ -892,13 +897,12 @@ static int cross_q1_bwd_launch(const void* u, const void* mem, const void* pos, 
     prof_set_bytes((double)F * S * QE * es * (pos ? 2.0 : 1.0) + (d_mem ? (double)F * S * QE * 4.0 * (accumulate ? 2.0 : 1.0) : 0.0) + (double)F * QH * S * 4.0 +
                    (double)F * (2 * QH * QE + ldz) * es + (coef ? (double)F * S * 32.0 : 0.0));
   }
-  // the matrix-pipe kernel can serve the bf16 launches that do not touch an fp32 d(memory) (deferred, or not wanted).  Measured at
-  // 1 600 frames x 151 rows: 142 us against 131 us for the VALU kernel in the same mode (one workgroup per CU: every wavefront pays
-  // three dependent memory round trips) - off by default, TD_CROSS_Q1_BWD_MFMA=1 selects it
-  static const int mfma_on = [] { const char* e_ = getenv("TD_CROSS_Q1_BWD_MFMA"); return e_ ? atoi(e_) : 0; }();
-  if (dtype == TD_BF16 && mfma_on && !d_mem && S <= 128) cross_q1_bwd_mfma_kernel<128><<<F, 256, 0, st>>>(p);
-  else if (dtype == TD_BF16 && mfma_on && !d_mem && S <= 160) cross_q1_bwd_mfma_kernel<160><<<F, 256, 0, st>>>(p);
-  else if (dtype == TD_BF16 && mfma_on && !d_mem && S <= 256) cross_q1_bwd_mfma_kernel<256><<<F, 256, 0, st>>>(p);
+  // the matrix-pipe kernel serves the bf16 launches that do not touch an fp32 d(memory) (deferred, or not wanted): 92 us against 129 us
+  // for the VALU kernel in the same mode at 1 600 frames x 151 rows (212 us with the fp32 read-modify-write).  TD_CROSS_Q1_MFMA=0: off
+  static const int mfma_on = [] { const char* e_ = getenv("TD_CROSS_Q1_MFMA"); return e_ ? atoi(e_) : 1; }();
+  if (dtype == TD_BF16 && mfma_on && !d_mem && S <= 128) cross_q1_bwd_mfma_kernel<128><<<F, 512, 0, st>>>(p);
+  else if (dtype == TD_BF16 && mfma_on && !d_mem && S <= 160) cross_q1_bwd_mfma_kernel<160><<<F, 512, 0, st>>>(p);
+  else if (dtype == TD_BF16 && mfma_on && !d_mem && S <= 256) cross_q1_bwd_mfma_kernel<256><<<F, 512, 0, st>>>(p);
   else if (dtype == TD_BF16) cross_q1_bwd_kernel<u16><<<F, 256, lds, st>>>(p);
   else cross_q1_bwd_kernel<float><<<F, 256, lds, st>>>(p);
   if (prof) prof_end(st);
