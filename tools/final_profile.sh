@@ -25,11 +25,13 @@ cp $O/${tag}_pmc_traffic.json $O/${tag}_pmc_mfma.json profiles/   # the bench li
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/${tag}_bench_cfg3x16.json 2> $O/${tag}_bench_cfg3x16.err
 V="--steps 10 --warmup 3 --cpu-frames 0 --roofline-steps 0"
 timeout 600 python bench.py $V > $O/${tag}_bench_variant_default.json 2>/dev/null
-TD_CONV_BIG_PHASED=0 TD_PW_PERSIST_V2=0 TD_BNECK_V3=0 TD_DGRAD_S2_PARITY=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_round3_kernels.json 2>/dev/null
+TD_CONV_BIG_PHASED=0 TD_PW_PERSIST_V2=0 TD_BNECK_V3=0 TD_DGRAD_S2_PARITY=0 TD_CROSS_Q1_MFMA=0 TD_CROSS_DMEM_DEFER=0 TD_MHA_XCD_MAP=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_round3_kernels.json 2>/dev/null
 TD_CONV_BIG_PHASED=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_lockstep.json 2>/dev/null
 TD_PW_PERSIST_V2=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_pw1.json 2>/dev/null
 TD_BNECK_V3=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_layer1_r3.json 2>/dev/null
 TD_DGRAD_S2_PARITY=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_dgrad9tap.json 2>/dev/null
+TD_CROSS_Q1_MFMA=0 TD_CROSS_DMEM_DEFER=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_cross_valu.json 2>/dev/null
+TD_MHA_XCD_MAP=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_mha_plain_order.json 2>/dev/null
 timeout 600 python bench.py $V --clips-per-gpu 1 > $O/${tag}_bench_variant_b1.json 2>/dev/null
 timeout 600 python bench.py $V --clips-per-gpu 8 > $O/${tag}_bench_variant_b8.json 2>/dev/null
 timeout 600 python bench.py $V --clips-per-gpu 8 --dedupe > $O/${tag}_bench_variant_b8_dedupe.json 2>/dev/null

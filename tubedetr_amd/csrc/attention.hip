@@ -10,6 +10,19 @@
 
 namespace td {
 
+// Workgroup -> (batch element, head).  Consecutive workgroup ids go round the eight XCDs, and each XCD has its own L2: with
+// heads as the fast index the eight heads of a batch element - eight 64-byte column blocks of the SAME 512-byte rows - land on eight
+// different L2s, every one of which fetches whole 128-byte lines for its half.  Here the ids an XCD sees (id % 8 fixed) walk the
+// heads of ONE element before moving on: a row's lines are fetched into one L2 and hit there by the other heads.  Needs the batch
+// to be a multiple of eight (else the plain order); TD_MHA_XCD_MAP=0: the plain order (A/B).
+__device__ __forceinline__ int xcd_bh(int id, int BH, int H, int on) {
+  const int B = BH / H;
+  if (!on || (B & 7)) return id;
+  const int x = id & 7, j = id >> 3;
+  return ((j / H) * 8 + x) * H + (j % H);
+}
+
+
 constexpr int HD = 32;
 constexpr int KJ = 8;    // keys per lane: Lk <= 64*KJ
 constexpr int QT = 32;   // queries per forward workgroup
@@ -23,6 +36,7 @@ struct MhaParams {
   float* ds_ws;
   float* stats;  // lean path: [B*H][Lq][4] = (row max of the scaled masked scores, 1 / sum exp, delta = dO . O, unused)
   int B, H, Lq, Lk, ldq, ldk, ldv, ldo;
+  int xcd_map;  // workgroup ids walk the heads of one batch element per XCD (xcd_bh)
   float scale;
   uint32_t drop_thresh;
   float drop_scale;
@@ -41,7 +55,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaParams p) {
   float* sV = sK + Lk * LS;
   float* sP = sV + Lk * LS;  // [4][Lk]
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = xcd_bh(blockIdx.x, gridDim.x, p.H, p.xcd_map), b = bh / p.H, h = bh - b * p.H;
   for (int idx = t; idx < Lk * HDV; idx += 256) {
     int kk = idx / HDV, d = idx - kk * HDV;
     sK[kk * LS + d] = Elem<T>::load(p.k, (size_t)(b * Lk + kk) * p.ldk + h * HDV + d);
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaParams p) {
   float* sV = sK + Lk * LS;
   float* sP = sV + Lk * LS;  // [4][Lk]
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = xcd_bh(blockIdx.x, gridDim.x, p.H, p.xcd_map), b = bh / p.H, h = bh - b * p.H;
   for (int idx = t; idx < Lk * HDV; idx += 256) {
     int kk = idx / HDV, d = idx - kk * HDV;
     sK[kk * LS + d] = Elem<T>::load(p.k, (size_t)(b * Lk + kk) * p.ldk + h * HDV + d);
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaParams p) {
   float* sQ = sm;              // [Lq][HDV]
   float* sO = sm + Lq * HDV;   // [Lq][HDV]
   const int t = threadIdx.x;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = xcd_bh(blockIdx.x, gridDim.x, p.H, p.xcd_map), b = bh / p.H, h = bh - b * p.H;
   for (int idx = t; idx < Lq * HDV; idx += 256) {
     int qq = idx / HDV, d = idx - qq * HDV;
     sQ[idx] = Elem<T>::load(p.q, (size_t)(b * Lq + qq) * p.ldq + h * HDV + d);
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(MhaParams p) {
   __shared__ __attribute__((aligned(16))) float sBias[KP];
   const int Lk = p.Lk, Lq = p.Lq, nthr = blockDim.x, nw = nthr >> 6;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = xcd_bh(blockIdx.x, gridDim.x, p.H, p.xcd_map), b = bh / p.H, h = bh - b * p.H;
   const u16* Q = (const u16*)p.q;
   const u16* K = (const u16*)p.k;
   const u16* V = (const u16*)p.v;
@@ -360,7 +374,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(MhaParams p) {
   __shared__ __attribute__((aligned(16))) u16 sKt[32 * VS];
   const int Lk = p.Lk, Lq = p.Lq, nthr = blockDim.x, nw = nthr >> 6;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = xcd_bh(blockIdx.x, gridDim.x, p.H, p.xcd_map), b = bh / p.H, h = bh - b * p.H;
   const u16* K = (const u16*)p.k;
   const u16* V = (const u16*)p.v;
   const u16* DO = (const u16*)p.dout;
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(MhaParams p) {
   u16* sQt = (u16*)sm;
   u16* sOt = sQt + 32 * QS;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = xcd_bh(blockIdx.x, gridDim.x, p.H, p.xcd_map), b = bh / p.H, h = bh - b * p.H;
   stage_transposed(sQt, QS, (const u16*)p.q + (size_t)b * Lq * p.ldq + h * HD, p.ldq, Lq, QP, t, nthr);
   stage_transposed(sOt, QS, (const u16*)p.dout + (size_t)b * Lq * p.ldo + h * HD, p.ldo, Lq, QP, t, nthr);
   __syncthreads();
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_lean_kernel(MhaParams p) {
   __shared__ __attribute__((aligned(16))) float sBias[KP];
   const int Lk = p.Lk, Lq = p.Lq, nthr = blockDim.x, nw = nthr >> 6;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = xcd_bh(blockIdx.x, gridDim.x, p.H, p.xcd_map), b = bh / p.H, h = bh - b * p.H;
   const u16* Q = (const u16*)p.q;
   const u16* K = (const u16*)p.k;
   const u16* V = (const u16*)p.v;
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_lean_kernel(MhaParams p) {
   u16* sOt = sQt + 32 * QS;
   float4* sSt = (float4*)(sOt + 32 * QS);  // [QP] (max, 1/sum, delta, -)
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = xcd_bh(blockIdx.x, gridDim.x, p.H, p.xcd_map), b = bh / p.H, h = bh - b * p.H;
   const u16* Q = (const u16*)p.q + (size_t)b * Lq * p.ldq + h * HD;
   const u16* DO = (const u16*)p.dout + (size_t)b * Lq * p.ldo + h * HD;
   stage_transposed(sQt, QS, Q, p.ldq, Lq, QP, t, nthr);
@@ -705,6 +719,10 @@ static int fill(MhaParams& p, int B, int H, int Lq, int Lk, int hd, int ldq, int
   TD_REQUIRE(B >= 1 && H >= 1 && Lq >= 1, "%s: bad sizes", who);
   TD_REQUIRE((double)B * H * Lq * Lk < 4294967295.0, "%s: probs tensor too large for the dropout index", who);
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
+  {
+    static const int xm = [] { const char* e_ = getenv("TD_MHA_XCD_MAP"); return e_ ? atoi(e_) : 1; }();
+    p.xcd_map = xm;
+  }
   p.drop_thresh = 0; p.drop_scale = 1.f; p.seed = seed; p.seed_dev = nullptr;
   if (dropout_p > 0.f) {
     TD_REQUIRE(dropout_p < 1.f, "%s: dropout_p must be < 1", who);
