@@ -962,20 +962,23 @@ def test_cross_attention_query_side_with_a_memory_that_needs_no_gradient():
     wo = r(F_, E)
     out = []
     for mem_grad in (True, False):
-        t_ = tgt.clone().requires_grad_(True)
-        m_ = mem.clone().requires_grad_(mem_grad)
-        ps = [p.clone().requires_grad_(True) for p in ps0]
-        anchor = Fk.cross_q1_memory(m_, pos)
-        x = t_
-        loss = 0.0
-        for _ in range(2):
-            o, _w = Fk.multihead_attention_q1(x, anchor, *ps, None, F_, S, H, need_weights=False, q_pos=qpos)
-            loss = loss + (o * wo).sum()
-            x = t_ + 0.1 * o
-        before = torch.cuda.memory_allocated()
-        torch.cuda.reset_peak_memory_stats()
-        loss.backward()
-        out.append(([t_.grad] + [p.grad for p in ps], torch.cuda.max_memory_allocated() - before, m_.grad))
+        peaks = []
+        for _rep in range(2):  # (the smaller peak of two runs: a run may be the one in which the zero-fill arena takes a new 128 MB chunk)
+            t_ = tgt.clone().requires_grad_(True)
+            m_ = mem.clone().requires_grad_(mem_grad)
+            ps = [p.clone().requires_grad_(True) for p in ps0]
+            anchor = Fk.cross_q1_memory(m_, pos)
+            x = t_
+            loss = 0.0
+            for _ in range(2):
+                o, _w = Fk.multihead_attention_q1(x, anchor, *ps, None, F_, S, H, need_weights=False, q_pos=qpos)
+                loss = loss + (o * wo).sum()
+                x = t_ + 0.1 * o
+            before = torch.cuda.memory_allocated()
+            torch.cuda.reset_peak_memory_stats()
+            loss.backward()
+            peaks.append(torch.cuda.max_memory_allocated() - before)
+        out.append(([t_.grad] + [p.grad for p in ps], min(peaks), m_.grad))
     (g1, peak1, mg1), (g0, peak0, mg0) = out
     assert mg1 is not None and mg0 is None
     for a, b in zip(g0, g1):
