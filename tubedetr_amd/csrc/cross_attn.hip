@@ -16,9 +16,12 @@
 // S x 8 dot products of length 256 against the memory rows as they lie in HBM, a softmax, and 8 weighted row sums - the
 // memory is read once per layer (twice: the second pass hits L2), nothing of size rows x 256 is written, and the key / value
 // projections, their 2 x (b*t*S) x 1536 activations, their input-gradient GEMMs and their weight-gradient jobs do not exist.
-// The kernels are HBM-bound by the memory rows; the arithmetic is fp32 on the VALU in both dtypes (24 FLOP per loaded byte).
+// The kernels are HBM-bound by the memory rows.  Two families: the templates right below do the arithmetic in fp32 on the VALU in
+// both dtypes (24 FLOP per loaded byte; the exact-fp32 parity mode, S > 256); in bf16 both products of a frame - and the gradient of
+// the shared memory over all layers - are v_mfma_f32_16x16x32_bf16 tiles (cross_q1_fwd_mfma_kernel, cross_q1_bwd_mfma_kernel,
+// cross_q1_dmem_kernel further down): the rows come from HBM once per layer and direction.
 //
-// Layout of a workgroup (256 threads, one frame): lane l of every wavefront owns channels 4l .. 4l+3; wavefront w walks the
+// Layout of a VALU workgroup (256 threads, one frame): lane l of every wavefront owns channels 4l .. 4l+3; wavefront w walks the
 // blocks of 8 (4) consecutive rows - their loads are issued back to back -; the 8 per-head partial dot products of a row are
 // reduced across the 64 lanes by a butterfly that halves the number of live values per step (ten DPP / permlane-swap exchanges
 // instead of 48 shuffles through the LDS crossbar).
