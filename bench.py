@@ -232,6 +232,13 @@ def main():
     ap.add_argument("--no-fast", action="store_true")
     ap.add_argument("--no-tsa", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: run in eval mode")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1: process-group backend.  nccl = RCCL over xGMI (one rank per GPU, the measured configuration); gloo = the collectives "
+                         "staged through the host - with --oversubscribe the way to run the whole N>1 control flow on a box with fewer GPUs than ranks")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="rehearsal: rank r uses device r %% (visible devices) instead of failing when there are fewer GPUs than ranks "
+                         "(RCCL refuses two ranks on one device: use --backend gloo); the JSON line is labelled, it is not a scaling measurement")
+    ap.add_argument("--dump-grads", default=None, help="rank 0 writes the averaged flat gradient buffer of the LAST timed step (and its layout) to this file (tests)")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without a launcher: print the launcher command line as JSON and exit")
     ap.add_argument("--text-stream", action="store_true", help="(default at N=1; accepted for older command lines)")
@@ -284,16 +291,23 @@ def main():
         raise SystemExit(f"bench: --gpus {a.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus {a.gpus}` (self-launching) or under "
                          f"torch.distributed.run --nproc-per-node {a.gpus}")
     n_dev = torch.cuda.device_count()
-    if local_rank >= n_dev:
-        raise SystemExit(f"bench: rank {rank} (local rank {local_rank}) has no device: --gpus {a.gpus} needs {a.gpus} GPUs on this node, {n_dev} visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if local_rank >= n_dev and not (a.oversubscribe and n_dev > 0):
+        raise SystemExit(f"bench: rank {rank} (local rank {local_rank}) has no device: --gpus {a.gpus} needs {a.gpus} GPUs on this node, {n_dev} visible "
+                         f"(--oversubscribe --backend gloo rehearses the N>1 path on fewer devices)")
+    if a.oversubscribe and a.backend == "nccl" and world > n_dev:
+        raise SystemExit("bench: --oversubscribe with more ranks than devices needs --backend gloo (RCCL refuses two ranks on one device)")
+    dev_index = local_rank % n_dev if a.oversubscribe else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1 or a.force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)  # (util/dist.py:210-247: the launcher's environment)
+        else:
+            torch.distributed.init_process_group("gloo")
 
     import tubedetr_amd
     from tubedetr_amd import _hip
@@ -323,10 +337,10 @@ def main():
     elif distributed:
         # replicas start from rank 0's weights (what DDP's constructor does), then exchange gradients through one flat
         # buffer (tubedetr_amd/distributed.py); the forward / backward of the step itself holds no collective
-        from tubedetr_amd.distributed import FlatGradAllReducer, sync_num_boxes
+        from tubedetr_amd.distributed import FlatGradAllReducer, broadcast_, sync_num_boxes
 
         for t_ in list(model.parameters()) + list(model.buffers()):
-            torch.distributed.broadcast(t_.data, 0)
+            broadcast_(t_.data, 0)
         late = [p_ for n_, p_ in model.named_parameters() if n_.startswith("backbone.") and p_.requires_grad] if staged else None
         reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32, late=late, collective=a.grad_collective)
         criterion.external_num_boxes = torch.ones(1, dtype=torch.float32, device=dev)
@@ -458,8 +472,15 @@ def main():
         from tubedetr_amd.ops import job_tables as jt_
         json.dump({"job_tables_host": [(s_[0].data_ptr(), s_[0].numel()) for s_ in jt_.slots + jt_.retired],
                    "job_tables_dev": [(s_[1].data_ptr(), s_[1].numel()) for s_ in jt_.slots + jt_.retired]}, open(os.environ["TD_BENCH_MEMMAP"] + ".ptrs", "w"))
+    host_idle_ms = None
     for i in range(a.warmup):
+        last_warm = i == a.warmup - 1 and i > 0
+        if last_warm:
+            torch.cuda.synchronize()  # the last warm-up step is enqueued on an IDLE device: how long the host needs by itself
+            th0 = time.perf_counter()
         step(i)
+        if last_warm:
+            host_idle_ms = (time.perf_counter() - th0) * 1e3
         if os.environ.get("TD_BENCH_TRACE"):
             torch.cuda.synchronize()
             _trace(f"warm-up step {i} done")
@@ -476,9 +497,15 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = tt.item()
+    if a.dump_grads and rank == 0 and reducer is not None:
+        torch.cuda.synchronize()
+        last = (a.warmup + a.steps - 1) % len(batches)
+        torch.save({"flat": reducer.flat.detach().cpu(), "names": [n_ for n_, p_ in model.named_parameters() if p_.requires_grad],
+                    "numels": [p_.numel() for p_ in reducer.params], "batch_seeds": [1000 * r_ + last for r_ in range(world)],
+                    "used": reducer._global_used, "world": world}, a.dump_grads)
     assert math.isfinite(loss.item()), "non-finite loss"
 
     roofline, cpu = None, None
@@ -579,11 +606,18 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
             "ms_per_step_min": round(step_ms[0], 2), "ms_per_step_median": round(step_ms[len(step_ms) // 2], 2), "ms_per_step_max": round(step_ms[-1], 2),
             "clips_per_step_per_gpu": B, "host_enqueue_ms_per_step": round(host_elapsed / a.steps * 1e3, 2),
+            "host_enqueue_ms_idle_device": None if host_idle_ms is None else round(host_idle_ms, 2),
+            "host_enqueue_note": "host_enqueue_ms_per_step is measured with the K steps enqueued back to back (the launch call of a replay returns only when the device "
+                                 "queue has room for its ~1 500 packets, i.e. about one step behind the device); host_enqueue_ms_idle_device is one step enqueued on an idle device",
             "peak_hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2**30, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "execution": execution,
             "gradient_exchange": (None if not distributed else ("torch DDP (find_unused_parameters)" if a.ddp else
                                   (f"staged flat {a.grad_collective} overlapped with the trunk backward, {a.grad_wire_dtype} on the wire" if staged else f"flat {a.grad_collective} after backward, {a.grad_wire_dtype} on the wire"))),
+            "process_group": (None if not distributed else {"backend": a.backend, "ranks": world, "devices_visible": n_dev,
+                                                            "oversubscribed": bool(a.oversubscribe and world > n_dev),
+                                                            "note": ("REHEARSAL of the N>1 control flow: several ranks share one device and the collectives go through the host - "
+                                                                     "not a scaling measurement") if (a.oversubscribe and world > n_dev) or a.backend != "nccl" else None}),
             "config": {"workload": f"{a.workload}: T={T} k={k} res={res} L={L}, {B} clip(s)/GPU/step, fast={not a.no_fast}, tsa={not a.no_tsa}, train-mode dropout={not a.eval_dropout_off}, "
                                    f"frames={'uint8 pixels, normalised on the device' if a.frames == 'u8' else 'host-normalised fp32'}",
                        "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random init (reference scheme), seed 42+rank"},

@@ -324,3 +324,78 @@ def test_reduce_scatter_all_gather_exchange_on_rccl():
             assert torch.equal(red2.flat, want)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("collective", ["all_reduce", "rs_ag"])
+def test_bench_main_at_world_size_2_on_one_gpu(tmp_path, collective):
+    """BASELINE config 4's ENTRY POINT, rehearsed on the one-GPU box: `python bench.py --gpus 2 --oversubscribe --backend gloo` runs
+    bench.main() end to end at world == 2 - self-launch under torch.distributed.run, broadcast of rank 0's weights, the step cut at the
+    trunk boundary and captured as two HIP graphs per rank, the early exchange between the two replays and the late one behind them,
+    MAX-over-ranks timing, ONE JSON line with n_gpus = 2 (main.py:372-376, util/dist.py:210-247).  Rank 0's averaged gradients of the
+    last step must equal the mean of the two ranks' single-process gradients, computed here with the same weights and clips."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "grads.pt")
+    steps, warmup, B = 2, 1, 2
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--oversubscribe", "--backend", "gloo", "--workload", "cfg1",
+           "--clips-per-gpu", str(B), "--steps", str(steps), "--warmup", str(warmup), "--roofline-steps", "0", "--cpu-frames", "0",
+           "--eval-dropout-off", "--grad-collective", collective, "--dump-grads", dump]
+    env = dict(os.environ, TD_ALLOW_RANDOM_TEXT_ENCODER="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["config"]["global_batch"] == 2 * B and out["config"]["parallelism"] == "dp2"
+    assert out["execution"].startswith("2 hip_graphs"), out["execution"]
+    assert out["gradient_exchange"].startswith(f"staged flat {collective}")
+    assert out["process_group"]["backend"] == "gloo" and out["process_group"]["oversubscribed"]
+    assert out["value"] > 0 and abs(out["value"] - 2 * B * steps / (out["ms_per_step"] * steps * 1e-3)) < 0.02 * out["value"]
+
+    # the expected average, in this process: same init (seed 42 = rank 0's, broadcast to rank 1), same clips (seeds 1000 * rank + step)
+    sys.path.insert(0, root)
+    import bench as bench_mod
+    import tubedetr_amd
+    from tubedetr_amd.functional import invalidate_prepared
+    from tubedetr_amd.harness import forward_step
+    from tubedetr_amd.models import build_model
+
+    got = torch.load(dump)
+    assert got["world"] == 2
+    T, res, k, L = bench_mod.WORKLOADS["cfg1"]
+    dev = torch.device("cuda:0")
+    torch.manual_seed(42)
+    model, criterion, weight_dict = build_model(tubedetr_amd.default_args(stride=k, fast=True, no_tsa=False, compute_dtype=torch.bfloat16, video_max_len_train=max(200, T)))
+    model.to(dev).eval()
+    tok = bench_mod.BatchTokenizer()
+    model.transformer.tokenizer = tok
+    params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    assert [n for n, _ in params] == got["names"] and [p.numel() for _, p in params] == got["numels"]
+    want = None
+    for seed in got["batch_seeds"]:
+        batch = bench_mod.make_batch(T, res, k, L, seed, dev, B, "u8")
+        tok.batch = batch
+        for _, p in params:
+            p.grad = None
+        invalidate_prepared()
+        loss, _, _, _ = forward_step(model, criterion, weight_dict, batch)
+        loss.backward()
+        g = [None if p.grad is None else p.grad.detach().float().clone() for _, p in params]
+        want = g if want is None else [a if b is None else (b if a is None else a + b) for a, b in zip(want, g)]
+    flat, off, checked = got["flat"].to(dev), 0, 0
+    for (n, p), w, used in zip(params, want, got["used"]):
+        a = flat[off : off + p.numel()].view_as(p)
+        off += p.numel()
+        if w is None:
+            assert not used, n  # RoBERTa's pooler: no rank used it
+            continue
+        ref = w / 2
+        scale = ref.abs().max().clamp_min(1e-4)
+        err = ((a - ref).abs().max() / scale).item()
+        assert err < 2e-2, (n, err)  # bf16 kernels whose weight gradients accumulate with fp32 atomics: same bound as the 1-rank tests
+        checked += 1
+    assert checked > 300

@@ -2794,8 +2794,10 @@ static int conv_gemm_launch(const void* src, const void* wmat, void* out, const 
   static const int tu_on = [] { const char* e_ = getenv("TD_CONV_TAP_UNIFORM"); return e_ ? atoi(e_) : 1; }();
   const int bk = dtype == TD_BF16 ? 64 : 32;
   // (a strided 1x1 - the downsample branch of a stage's first block - is the one-tap case of the same addressing)
-  const bool tu = tu_on && !pw && !d->aniso && (d->R * d->S > 1 || (d->stride > 1 && d->mode == 0)) && d->R * d->S <= 32 && d->C % bk == 0 &&
+  const bool tu = (tu_on || p.use_wtap) && !pw && !d->aniso && (d->R * d->S > 1 || (d->stride > 1 && d->mode == 0)) && d->R * d->S <= 32 && d->C % bk == 0 &&
                   (p.d.out_sp == 1 || d->mode == 0) && (d->mode == 0 || d->stride == 1);
+  // a tap -> column-block map (WeightSubset: the parity classes of a stride-2 input gradient) is honoured by the tap-uniform K walk only
+  TD_REQUIRE(tu || !p.use_wtap, "td_conv_gemm: a weight-column subset needs the tap-uniform addressing (C %% %d == 0, at most 32 taps)", bk);
   {
     // 256-row tiles (conv_gemm_big_kernel): MFMA-bound bf16 layers with enough workgroups to matter
     static const int big_on = [] { const char* e_ = getenv("TD_CONV_BIG"); return e_ ? atoi(e_) : 1; }();

@@ -34,6 +34,18 @@ def _all_reduce(t: torch.Tensor, op, group=None) -> None:
         dist.all_reduce(t, op=op, group=group)
 
 
+def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> None:
+    """dist.broadcast in place (what DistributedDataParallel's constructor does with rank 0's parameters and buffers, main.py:372-376);
+    device tensors go through the host under `gloo`, like ``_all_reduce``."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.broadcast(host, src, group=group)
+        if dist.get_rank(group) != src:
+            t.copy_(host)
+    else:
+        dist.broadcast(t, src, group=group)
+
+
 def _reduce_scatter_all_gather(buf: torch.Tensor, shard: torch.Tensor, op, group=None, async_op: bool = False):
     """Average / sum the 1-D ``buf`` over the ranks as an explicit reduce-scatter + all-gather pair on the flat buffer (what a ring
     all-reduce is made of, as two collectives the backend may schedule over all xGMI links independently; it is also where a
@@ -50,6 +62,12 @@ def _reduce_scatter_all_gather(buf: torch.Tensor, shard: torch.Tensor, op, group
         _reduce_scatter_all_gather(hb, torch.empty(max(1, m // world), dtype=hb.dtype), op, group)
         buf.copy_(hb)
         return None
+    if m and not (hasattr(dist, "reduce_scatter_tensor") and hasattr(dist, "all_gather_into_tensor")):
+        import warnings
+
+        warnings.warn("torch.distributed has no reduce_scatter_tensor / all_gather_into_tensor: the rs_ag exchange falls back to all_reduce")
+        w = dist.all_reduce(buf, op=op, group=group, async_op=async_op)
+        return [w] if async_op else None
     if m:
         sh = shard[: m // world]
         w1 = dist.reduce_scatter_tensor(sh, buf[:m], op=op, group=group, async_op=async_op)
@@ -93,10 +111,7 @@ class FlatGradAllReducer:
             off += p.numel()
         assert collective in ("all_reduce", "rs_ag")
         self.collective = collective  # "rs_ag": reduce-scatter + all-gather on the flat buffer instead of one all-reduce (same result)
-        self._shard = None
-        if collective == "rs_ag":
-            longest = max((b - a for a, b, _ in self.runs), default=n) if late else n
-            self._shard = torch.zeros(max(1, -(-max(longest, 1) // max(self.world, 1))), dtype=self.wire.dtype, device=dev)
+        self._shard = None  # rs_ag scratch: ceil(numel / world) elements, allocated at first use (never on the host-staged gloo path)
         self._pending: list = []
         self.always_communicate = False  # diagnostic: issue the collective even in a 1-rank group
         self._had_grad: Optional[List[bool]] = None     # which parameters had a local gradient at the last gather()
@@ -162,10 +177,15 @@ class FlatGradAllReducer:
         if not avg:
             self.flat.div_(self.world)
 
-    def _full_shard(self) -> torch.Tensor:
+    def _host_staged(self) -> bool:
+        return self.flat.is_cuda and dist.is_initialized() and dist.get_backend(self.group) == "gloo"
+
+    def _full_shard(self) -> Optional[torch.Tensor]:
+        if self._host_staged():
+            return None  # _reduce_scatter_all_gather stages the buffer through the host and brings its own scratch
         need = -(-self.numel // max(self.world, 1))
         if self._shard is None or self._shard.numel() < need:
-            self._shard = torch.zeros(need, dtype=self.wire.dtype, device=self.flat.device)
+            self._shard = torch.empty(need, dtype=self.wire.dtype, device=self.flat.device)
         return self._shard
 
     # ---- staged form: exchange what is final while the rest of backward still runs ----
@@ -198,7 +218,7 @@ class FlatGradAllReducer:
                 buf = self.wire[a:b]
             if self.collective == "rs_ag":
                 # (one scratch shard per run in flight: the runs of a stage are exchanged back to back on the backend's stream)
-                shard = torch.empty(max(1, -(-(b - a) // max(self.world, 1))), dtype=buf.dtype, device=buf.device) if self._pending else self._full_shard()
+                shard = None if self._host_staged() else (torch.empty(max(1, -(-(b - a) // max(self.world, 1))), dtype=buf.dtype, device=buf.device) if self._pending else self._full_shard())
                 # (async only where collectives of a group are stream-ordered - RCCL; gloo runs async operations on independent threads:
                 #  the gather could read the shard before the scatter has written it)
                 works = _reduce_scatter_all_gather(buf, shard, op, self.group, async_op=dist.get_backend(self.group) == "nccl")

@@ -671,6 +671,9 @@ class CrossMemFn(Function):
             assert sh.dmem is None
             E = sh.mem.shape[1]
             F_, H = next(iter(sh.deferred.values()))[0].shape[0], next(iter(sh.deferred.values()))[0].shape[1] // E
+            for l in range(sh.n_layers):
+                if l not in sh.deferred:  # (a layer outside the differentiated graph: its coefficient columns were never written)
+                    sh.coef[:, 16 * l : 16 * l + 16].zero_()
             d = ops.cross_q1_dmem(sh.coef, [sh.deferred.get(l) for l in range(sh.n_layers)], F_, sh.mem.shape[0] // F_, H, E)
             sh.coef, sh.deferred = None, {}
             return d, None
@@ -740,7 +743,13 @@ class CrossQ1Fn(Function):
         dwa = dwavg.contiguous().float() if dwavg is not None else None
         if sh.want_dmem and dt == torch.bfloat16 and _CROSS_DMEM_DEFER and sh.n_layers <= 8 and sh.dmem is None:
             if sh.coef is None:
-                sh.coef = torch.zeros((F * S, (16 * sh.n_layers + 31) // 32 * 32), dtype=dt, device=dev)
+                # every layer that runs overwrites all 16 of its columns for every row: only the padding columns need defined values
+                # (the layers' product is an MFMA over the whole padded width: 0 * NaN from uninitialised memory would poison it);
+                # columns of a layer whose backward never ran are zeroed in CrossMemFn.backward
+                width = (16 * sh.n_layers + 31) // 32 * 32
+                sh.coef = torch.empty((F * S, width), dtype=dt, device=dev)
+                if width > 16 * sh.n_layers:
+                    sh.coef[:, 16 * sh.n_layers :].zero_()
             d_u = ops.cross_q1_bwd_coef(u, sh.mem, sh.pos, probs, d_zext, dwa, sh.coef, 16 * ctx.layer, F, S, H, dropout_p=p_attn, seed=seed_attn)
             sh.deferred[ctx.layer] = (u, d_zext)
         else:

@@ -213,11 +213,14 @@ class TubeDETR(nn.Module):
                 n_slow = src.shape[0]
                 perm, inv = self._dedupe_index(durations, samples_fast.tensors.device)
                 assert n_slow == sum(math.ceil(d / k) for d in durations)
-                rest = NestedTensor(FrameSources([(_one_tensor(samples_fast.tensors), perm[n_slow:])], _valid(samples_fast.tensors)), samples_fast.mask[perm[n_slow:]])
-                with torch.no_grad():
-                    features_rest, _ = self.backbone(rest, want_pos=False)
-                src_rest, mask_rest = features_rest[-1].decompose()
-                src_fast_feat, mask_fast = torch.cat([src.detach(), src_rest])[inv], torch.cat([mask, mask_rest])[inv]
+                if perm.numel() == n_slow:  # stride 1: every fast frame is a slow frame - there is no other frame to run
+                    src_fast_feat, mask_fast = src.detach()[inv], mask[inv]
+                else:
+                    rest = NestedTensor(FrameSources([(_one_tensor(samples_fast.tensors), perm[n_slow:])], _valid(samples_fast.tensors)), samples_fast.mask[perm[n_slow:]])
+                    with torch.no_grad():
+                        features_rest, _ = self.backbone(rest, want_pos=False)
+                    src_rest, mask_rest = features_rest[-1].decompose()
+                    src_fast_feat, mask_fast = torch.cat([src.detach(), src_rest])[inv], torch.cat([mask, mask_rest])[inv]
             elif not merged:
                 with torch.no_grad():  # the fast branch does not back-propagate into the backbone (tubedetr.py:128-129)
                     features_fast, _ = self.backbone(samples_fast, want_pos=False) if self._joiner else self.backbone(samples_fast)  # its encoding is never used

@@ -245,6 +245,7 @@ class FusedAdamWEMA:
             step = max(step, float(st["step"]))
         self.step_dev.fill_(int(step))  # (one step counter: torch's per-parameter steps are equal for every parameter that has state)
         self._loaded_active = loaded if any(loaded) else None
+        self._active = self._segs = None  # the activity map of earlier steps is stale: the loaded one governs until the next step decides
         for g, saved in zip(self.param_groups, groups):
             g["lr"] = float(saved["lr"])
         self._lr_last = None
