@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
 
 #define TD_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
   TD_STAMP(0);
+  if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + 6] = wall_clock64();  // (100 MHz, the same base on every CU: workgroup timeline, tools/stamp_occupancy.py)
   __syncthreads();  // the K table is complete
   // prologue = the issue order of the steady state: weights of tile 0, activations of tile 0, weights of tile 1
   {
@@ -1180,6 +1181,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next chunk overwrites the region
   }
   TD_STAMP(5);
+  if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
 #undef TD_STAMP
 }
 

@@ -151,173 +151,11 @@ static int run_conv(const char* ws, const Tens& in, const Tens& out, int N, cons
   return TD_OK;
 }
 
-
-// ---- depth-first no-grad pass (round 5) ----
-// Layer by layer over all N frames every activation of layer2..4 is written to HBM and read back from HBM (a 1024-channel tensor of
-// 1 600 frames is 1.6 GB; the die-level Infinity Cache holds 256 MiB).  The no-grad pass keeps nothing, so its stages can run DEPTH
-// FIRST instead: a group of G frames goes through ALL blocks of a stage before the next group starts, the block-to-block tensors of
-// the group live in five small regions that every group reuses (h1, h2, downsample branch, two block outputs), and only the stage
-// boundaries are whole-N tensors.  G is sized so that (a) a 256-row-tile launch over the group is ONE round of the 256 CUs
-// (G * Ho * Wo ~ 65 536 rows, half of that where the layer has 512 output channels = two column tiles) and (b) the group's working set
-// fits the Infinity Cache (TD_TRUNK_DF_MB, default 192).  With `inplace` the 1x1 expansion writes its result over its residual
-// operand (every output element is produced by the lane that read the residual element at the same address; nothing else reads it
-// afterwards), which halves the largest part of the working set.  Same kernels, same per-row arithmetic: results are bit-identical to
-// the layer-by-layer pass.  TD_TRUNK_DF=0: off; =g2,g3,g4: explicit frames per group for layer2 / layer3 / layer4 (0 = whole N).
-struct DfConfig {
-  bool on;
-  int g[4];  // frames per group, per stage (stage 0 = layer1 never runs depth first: its blocks are single fused launches)
-  bool inplace;
-};
-static inline size_t tens_frame_bytes(const Tens& t, int es) { return (size_t)t.H * t.W * t.C * es; }
-static DfConfig df_config(const Plan& P, int N, int H, int W, int dtype, int save) {
-  DfConfig c;
-  c.on = false;
-  c.inplace = true;
-  for (int s = 0; s < 4; ++s) c.g[s] = N;
-  if (save || dtype != TD_BF16) return c;
-  const char* e = getenv("TD_TRUNK_DF");
-  if (e && e[0] == '0' && e[1] == 0) return c;
-  if (const char* ip = getenv("TD_TRUNK_DF_INPLACE")) c.inplace = atoi(ip) != 0;
-  const char* mb = getenv("TD_TRUNK_DF_MB");
-  const double budget = (mb ? atof(mb) : 192.0) * 1048576.0;
-  int expl[4] = {-1, -1, -1, -1};
-  if (e && e[0] && strcmp(e, "auto") != 0) sscanf(e, "%d,%d,%d", &expl[1], &expl[2], &expl[3]);
-  const FrameGroups fg(N, H, W, P.es);
-  for (int s = 1; s < 4; ++s) {
-    // shapes of the stage: its first block (strided: the largest h1 / input) and its last block
-    const BlockPlan *b0 = nullptr, *bl = nullptr;
-    for (auto& b : P.blocks)
-      if (b.stage == s) {
-        if (!b0) b0 = &b;
-        bl = &b;
-      }
-    if (!b0) continue;
-    size_t lim_elems = 0;  // largest per-frame tensor any launch of the stage touches (32-bit addressing)
-    for (const Tens* t : {&b0->in, &b0->h1, &b0->h2, &b0->idt, &b0->out}) lim_elems = std::max(lim_elems, frame_elems(*t));
-    int g;
-    if (expl[s] >= 0) {
-      g = expl[s] == 0 ? N : expl[s];
-    } else {
-      const int planes = bl->h2.C;
-      const double rows = 65536.0 / std::max(1, planes / 256);
-      g = std::max(1, (int)(rows / ((double)bl->out.H * bl->out.W)));
-      const double per_frame = (double)tens_frame_bytes(bl->out, P.es) * (c.inplace ? 1 : 2) + (double)tens_frame_bytes(bl->h1, P.es) + (double)tens_frame_bytes(bl->h2, P.es);
-      g = std::max(1, std::min(g, (int)(budget / per_frame)));
-    }
-    g = std::min(g, fg.step(lim_elems));
-    if (g < N) {
-      const int groups = (N + g - 1) / g;
-      g = (N + groups - 1) / groups;  // equal groups
-      c.on = true;
-    } else {
-      g = N;
-    }
-    c.g[s] = g;
-  }
-  if (e && e[0] && expl[1] >= 0) c.on = true;  // an explicit setting always takes the depth-first code path (tests: "0,0,0" = one group per stage)
-  return c;
-}
-// regions behind the layer-by-layer plan's ring: [H1 | H2 | IDT | IO_A | IO_B | stage outputs (whole N) of layer2, layer3, layer4]
-struct DfLayout {
-  size_t h1, h2, idt, io[2], sout[4], total;
-};
-static DfLayout df_layout(const Plan& P, const DfConfig& c, int N, size_t base) {
-  size_t mh1 = 0, mh2 = 0, midt = 0, mio = 0;
-  DfLayout L;
-  memset(&L, 0, sizeof(L));
-  for (auto& b : P.blocks) {
-    if (b.stage < 1) continue;
-    const size_t g = (size_t)c.g[b.stage];
-    mh1 = std::max(mh1, align256(g * tens_frame_bytes(b.h1, P.es)));
-    mh2 = std::max(mh2, align256(g * tens_frame_bytes(b.h2, P.es)));
-    if (b.conv[3] >= 0) midt = std::max(midt, align256(g * tens_frame_bytes(b.idt, P.es)));
-    mio = std::max(mio, align256(g * tens_frame_bytes(b.out, P.es)));
-  }
-  size_t off = base;
-  L.h1 = off; off += mh1;
-  L.h2 = off; off += mh2;
-  L.idt = off; off += midt;
-  L.io[0] = off; off += mio;
-  L.io[1] = off; off += mio;
-  for (int s = 1; s < 4; ++s) {
-    const BlockPlan* bl = nullptr;
-    for (auto& b : P.blocks)
-      if (b.stage == s) bl = &b;
-    L.sout[s] = off;
-    if (bl) off += align256((size_t)N * tens_frame_bytes(bl->out, P.es));
-  }
-  L.total = off;
-  return L;
-}
-static int conv_ptr(const void* in, const Tens& it, void* out, const Tens& ot, int n, const ConvSpec& c, const void* w, const float* bias, const void* residual,
-                    int relu, int dtype, td_stream_t st) {
-  td_conv_desc d = {n, it.H, it.W, it.C, ot.H, ot.W, c.k, c.k, c.stride, c.pad, 0, c.cout, c.cout, 1, 0, 0};
-  td_epilogue e;
-  memset(&e, 0, sizeof(e));
-  e.bias = bias;
-  e.residual = residual;
-  e.relu = relu;
-  return td_conv_gemm(in, w, out, &d, &e, dtype, st);
-}
-// stages >= 1 of the no-grad pass, depth first.  stage_in: the whole-N output of the last stage-0 block.
-static int run_depth_first(const Plan& P, const DfConfig& c, const DfLayout& L, char* base, const char* stage_in, int N, const void* const* w_fwd,
-                           const float* const* bias, int dtype, td_stream_t st, const char** feat_out) {
-  const int es = P.es;
-  const char* sin = stage_in;
-  for (int s = 1; s < 4; ++s) {
-    std::vector<const BlockPlan*> bs;
-    for (auto& b : P.blocks)
-      if (b.stage == s) bs.push_back(&b);
-    if (bs.empty()) continue;
-    char* sout = base + L.sout[s];
-    const int G = c.g[s];
-    for (int f0 = 0; f0 < N; f0 += G) {
-      const int n = std::min(G, N - f0);
-      const char* cur = sin + (size_t)f0 * tens_frame_bytes(bs[0]->in, es);
-      int cur_io = -1;  // the group's current block input lives outside the two block-output regions
-      for (size_t j = 0; j < bs.size(); ++j) {
-        const BlockPlan& b = *bs[j];
-        const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
-        char* h1 = base + L.h1;
-        char* h2 = base + L.h2;
-        int rc;
-        if ((rc = conv_ptr(cur, b.in, h1, b.h1, n, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, st))) return rc;
-        if ((rc = conv_ptr(h1, b.h1, h2, b.h2, n, P.convs[c2], w_fwd[c2], bias[c2], nullptr, 1, dtype, st))) return rc;
-        const char* idt = cur;
-        if (cd >= 0) {
-          char* di = base + L.idt;
-          if ((rc = conv_ptr(cur, b.in, di, b.idt, n, P.convs[cd], w_fwd[cd], bias[cd], nullptr, 0, dtype, st))) return rc;
-          idt = di;
-        }
-        char* out;
-        int out_io = cur_io;
-        if (j + 1 == bs.size()) {
-          out = sout + (size_t)f0 * tens_frame_bytes(b.out, es);
-          out_io = -1;
-        } else if (c.inplace && cd < 0 && cur_io >= 0) {
-          out = (char*)cur;  // over the residual operand
-        } else {
-          out_io = cur_io == 0 ? 1 : 0;
-          out = base + L.io[out_io];
-        }
-        if ((rc = conv_ptr(h2, b.h2, out, b.out, n, P.convs[c3], w_fwd[c3], bias[c3], idt, 1, dtype, st))) return rc;
-        cur = out;
-        cur_io = out_io;
-      }
-    }
-    sin = sout;
-  }
-  *feat_out = sin;
-  return TD_OK;
-}
-
 }  // namespace td
 using namespace td;
 
 extern "C" size_t td_resnet_fwd_ws_bytes(int N, int H, int W, const int* nblocks, int dtype, int save) {
-  const Plan P = make_plan(N, H, W, nblocks, dtype, save);
-  const DfConfig df = df_config(P, N, H, W, dtype, save);
-  return df.on ? df_layout(P, df, N, P.total).total : P.total;
+  return make_plan(N, H, W, nblocks, dtype, save).total;
 }
 
 extern "C" int td_resnet_num_convs(const int* nblocks) {
@@ -337,11 +175,7 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
     TD_REQUIRE(tot == N, "td_resnet_fwd: the sources contribute %lld frames, N = %d", tot, N);
   }
   Plan P = make_plan(N, H, W, nblocks, dtype, save);
-  const DfConfig df = df_config(P, N, H, W, dtype, save);
-  DfLayout dfl;
-  memset(&dfl, 0, sizeof(dfl));
-  if (df.on) dfl = df_layout(P, df, N, P.total);
-  TD_REQUIRE(ws_bytes >= (df.on ? dfl.total : P.total), "td_resnet_fwd: workspace too small (%zu < %zu)", ws_bytes, df.on ? dfl.total : P.total);
+  TD_REQUIRE(ws_bytes >= P.total, "td_resnet_fwd: workspace too small (%zu < %zu)", ws_bytes, P.total);
   char* base = (char*)ws;
   int rc;
   // a pass that keeps its activations for backward is walked by td_resnet_bwd as ONE workspace of whole tensors: it must fit the
@@ -394,13 +228,8 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   // in the network the fully fused layer1 is 0.3 ms per 8-clip step ahead.  TD_L1_FUSED: 0 = never, 1 = block 0 only,
   // 2 (default) = every frozen 64-plane block.
   static const int l1_fused = [] { const char* e = getenv("TD_L1_FUSED"); return e ? atoi(e) : 2; }();
-  size_t df_first = P.blocks.size();  // first block the depth-first part takes over (layer2's first)
   for (size_t bi = 0; bi < P.blocks.size(); ++bi) {
     auto& b = P.blocks[bi];
-    if (df.on && b.stage >= 1) {
-      df_first = bi;
-      break;
-    }
     const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
     if (l1_fused && (l1_fused >= 2 || cd >= 0) && dtype == TD_BF16 && !conv1_done && (!save || b.stage < first_train_stage) && b.stride == 1 && P.convs[c1].cout == 64 &&
         P.convs[c3].cout == 256 && ((P.convs[c1].cin == 64 && cd >= 0) || (P.convs[c1].cin == 256 && cd < 0)) &&
@@ -425,7 +254,7 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
       auto& nb = P.blocks[bi + 1];
       const ConvSpec &s3 = P.convs[c3], &s1 = P.convs[nb.conv[0]];
       const long long rows = (long long)N * b.out.H * b.out.W;
-      const bool fits = !(df.on && nb.stage >= 1) && s3.cin == 64 && s3.cout == 256 && s1.cin == 256 && s1.k == 1 && s1.stride == 1 && (s1.cout == 64 || (s1.cout == 128 && (chain_on & 2))) &&
+      const bool fits = s3.cin == 64 && s3.cout == 256 && s1.cin == 256 && s1.k == 1 && s1.stride == 1 && (s1.cout == 64 || (s1.cout == 128 && (chain_on & 2))) &&
                         (double)rows * 256 < groups.lim_elems && nb.h1.off != b.h2.off && nb.h1.off != b.out.off && nb.h1.off != b.in.off && (cd < 0 || nb.h1.off != b.idt.off);
       if (fits) {
         if ((rc = td_pw_chain(base + b.h2.off, w_fwd[c3], bias[c3], idt, base + b.out.off, w_fwd[nb.conv[0]], bias[nb.conv[0]], base + nb.h1.off, (int)rows,
@@ -439,12 +268,6 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   }
   const Tens& last = P.blocks.empty() ? P.pool : P.blocks.back().out;
   *feat = base + last.off;
-  if (df_first < P.blocks.size()) {
-    const Tens& sin = df_first > 0 ? P.blocks[df_first - 1].out : P.pool;
-    const char* f = nullptr;
-    if ((rc = run_depth_first(P, df, dfl, base, base + sin.off, N, w_fwd, bias, dtype, stream, &f))) return rc;
-    *feat = (void*)f;
-  }
   if (feat_hw) {
     feat_hw[0] = last.H;
     feat_hw[1] = last.W;
