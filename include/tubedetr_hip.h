@@ -186,14 +186,6 @@ typedef struct td_frame_source {
 int td_frames_to_nhwc(const td_frame_source* srcs, int n_srcs, int C, int H, int W, int Cpad, const float* mean,
                       const float* inv_std, void* y, int dtype, td_stream_t stream);
 
-/* Two chained pointwise layers in ONE persistent launch (torchvision Bottleneck.forward: conv3 + bn3 + identity + relu of a
- * layer1 block, then conv1 + bn1 + relu of the next block, models/backbone.py:94-98): out1 = relu(x W1^T + bias1 + residual)
- * with x [M][K1], W1 [N1][K1]; out2 = relu(out1 W2^T + bias2) with W2 [N2][N1].  out1 is written AND kept on chip as the second
- * layer's input, so the second layer reads nothing from HBM.  bf16, K1 = 64, N1 = 256, N2 = 64 or 128; prepared (FrozenBN-folded)
- * weights.  Used by td_resnet_fwd; exported for the parity test. */
-int td_pw_chain(const void* x, const void* w1, const float* bias1, const void* residual, void* out1, const void* w2,
-                const float* bias2, void* out2, int M, int K1, int N1, int N2, int dtype, td_stream_t stream);
-
 /* Native executor of the bottleneck-ResNet trunk (replaces the module-graph execution of torchvision resnet101 through
  * IntermediateLayerGetter, models/backbone.py:94-98, and its autograd backward).  Conv order in every array: stem,
  * then per block conv1, conv2, conv3[, downsample] (td_resnet_num_convs entries).  srcs: the N = sum of srcs[i].n input

@@ -2,12 +2,11 @@
 (8 clips of cfg3 per step = a 1 000-frame trunk forward, a 200-frame trunk backward), each against a plain PyTorch fp32
 evaluation of the same op on the same bf16-rounded operands:
 
-  conv_gemm_big_kernel<256, true>   layer3 3x3        M = 484 000, N = 256, K = 2304      forward and input gradient
-  conv_gemm_big_kernel<256, false>  layer3 conv1      M = 484 000, N = 256, K = 1024
-  pw_resident_kernel                layer3 conv3      M = 484 000, N = 1024, K = 256      + residual + ReLU
-  pw_resident_kernel                layer1 conv3      M = 7 744 000, N = 256, K = 64      + residual + ReLU
-  pw_chain_kernel                   layer1 conv3 -> next conv1, M = 7 744 000
-  conv_gemm_big_kernel / conv_gemm_kernel (tap-uniform)  the stride-2 layers of a stage's first block (3x3 and the 1x1 downsample)
+  conv_gemm_big8_kernel<true, *>    layer3 3x3        M = 484 000, N = 256, K = 2304      forward and input gradient
+  conv_gemm_big8_kernel<false, *>   layer3 conv1      M = 484 000, N = 256, K = 1024
+  pw_resident2_kernel               layer3 conv3      M = 484 000, N = 1024, K = 256      + residual + ReLU
+  pw_resident2_kernel               layer1 conv3      M = 7 744 000, N = 256, K = 64      + residual + ReLU
+  conv_gemm_big8(n)_kernel / conv_gemm_kernel (tap-uniform)  the stride-2 layers of a stage's first block (3x3 and the 1x1 downsample)
   conv_wgrad_wide_batch_kernel      the trunk's batched weight-gradient table at 200 slow frames (one job per layer shape)
 
 The forward-type results are compared on sampled row ranges (first / middle / last rows of the launch: tile 0, an interior
@@ -111,24 +110,6 @@ def test_pointwise_layers_at_bench_shape(shape):
         if res is not None:
             ref = ref + res[a:b].float()
         assert rel_err(y[a:b].float(), ref.relu()) < TOL, (shape[0], a)
-
-
-def test_layer1_chain_at_bench_shape():
-    from tubedetr_amd import ops
-
-    g = torch.Generator(device=dev()).manual_seed(7)
-    M = 7744000
-    x = _rand((M, 64), g, relu=True)
-    w1 = (torch.randn(256, 64, generator=g, device=dev()) / 8).to(torch.bfloat16)
-    w2 = (torch.randn(64, 256, generator=g, device=dev()) / 16).to(torch.bfloat16)
-    b1, b2 = torch.randn(256, generator=g, device=dev()), torch.randn(64, generator=g, device=dev())
-    res = _rand((M, 256), g, relu=True)
-    o1, o2 = ops.pw_chain(x, w1, b1, res, w2, b2)
-    for a, b in ((0, 4096), (M // 2, M // 2 + 4096), (M - 4000, M)):
-        r1 = (x[a:b].float() @ w1.float().t() + b1 + res[a:b].float()).relu()
-        assert rel_err(o1[a:b].float(), r1) < TOL
-        r2 = (o1[a:b].float() @ w2.float().t() + b2).relu()  # the second layer consumes the bf16-rounded first output
-        assert rel_err(o2[a:b].float(), r2) < TOL
 
 
 def _wgrad_ref(gy, x, R, stride, pad):

@@ -476,30 +476,6 @@ def test_conv3x3_256_row_tiles(cfg):
         assert rel_err(dx.float().permute(0, 3, 1, 2), dx_ref) < TOL[dt]
 
 
-@pytest.mark.parametrize("cfg", [(70001, 64), (33, 64), (140000, 128)])
-def test_pw_chain_equals_two_pointwise_layers(cfg):
-    """td_pw_chain (conv3 + identity + ReLU of a layer1 bottleneck and conv1 + ReLU of the next block in one persistent
-    launch, the 256-channel intermediate handed over through LDS) against the two layers run apart, ragged last tile."""
-    from tubedetr_amd import ops
-
-    M, N2 = cfg
-    dt = torch.bfloat16
-    g = torch.Generator().manual_seed(61)
-    x = torch.randn(M, 64, generator=g).to(dev(), dt)
-    w1 = (torch.randn(256, 64, generator=g) / 8).to(dev(), dt)
-    b1 = torch.randn(256, generator=g).to(dev())
-    res = torch.randn(M, 256, generator=g).to(dev(), dt)
-    w2 = (torch.randn(N2, 256, generator=g) / 16).to(dev(), dt)
-    b2 = torch.randn(N2, generator=g).to(dev())
-    o1, o2 = ops.pw_chain(x, w1, b1, res, w2, b2)
-    r1 = F.relu(x.float() @ w1.float().t() + b1 + res.float())
-    assert rel_err(o1, r1) < TOL[dt]
-    r2 = F.relu(o1.float() @ w2.float().t() + b2)  # the second layer consumes the bf16-rounded first output, like two launches do
-    assert rel_err(o2, r2) < TOL[dt]
-    a1 = ops.linear_fwd(x, w1, b1, residual=res, relu=True)
-    assert torch.equal(a1, o1)
-
-
 @pytest.mark.parametrize("dt", DT)
 def test_linear_sigmoid_alpha_dropout(dt):
     from tubedetr_amd import ops

@@ -153,6 +153,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define TD_NT 3
 #endif
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 ld16(const char* p) {
 #if TD_NT & 1
   const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
@@ -572,295 +573,21 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
 }
 
 // ------------------------------------------------------------------------------------------------
-// 256-row tiles for the MFMA-bound layers (bf16; every 3x3 of layer2..4, the 1x1 layers with K >= 512), forward and
-// input gradient.  Why a second instance: a 128 x 128 x 64 tile moves 32 KiB HBM/L2 -> LDS per 512 MFMA cycles of the CU,
-// i.e. it needs the full 64 B/clk/CU of the vector-memory path to keep the matrix pipes busy, and measured it sits at a
-// third of both.  Here one workgroup of EIGHT wavefronts (two per SIMD, the only workgroup of its CU: 2 x 64 KiB stages)
-// owns a 256 x 256 (or 256 x 128) tile: the same DMA instruction count per wavefront and tile as before feeds twice the
-// MFMAs (32 B/clk/CU at peak), the activation rows of a 256-channel layer are read exactly once, and each wavefront's
-// 128 x 64 sub-tile needs 12 KiB of LDS fragment reads per 32 MFMAs instead of 16.  Accumulators: 128 VGPRs per lane.
-// The epilogue walks the wavefront's rows in chunks of 16: transposed through a private 4-KiB LDS region (no workgroup
-// barrier between chunks), residual / mask operands of chunk c+1 requested while chunk c is stored.
-// TU / pointwise addressing exactly as in conv_gemm_kernel.
+// 256-row tiles for the MFMA-bound layers (bf16; every 3x3 of layer2..4, the 1x1 layers with K >= 512), forward and input
+// gradient.  Why a second instance next to conv_gemm_kernel: a 128 x 128 x 64 tile moves 32 KiB HBM/L2 -> LDS per 512 MFMA cycles of
+// the CU, i.e. it needs the full 64 B/clk/CU of the vector-memory path to keep the matrix pipes busy, and measured it sits at a
+// third of both.  Here one workgroup of EIGHT wavefronts (two per SIMD, the only workgroup of its CU: 2 x 64 KiB stages) owns a
+// 256 x 256 (conv_gemm_big8_kernel) or 256 x 128 (conv_gemm_big8n_kernel) tile: the same DMA instruction count per wavefront and
+// tile feeds twice the MFMAs (32 B/clk/CU at peak), the activation rows of a 256-channel layer are read exactly once, and each
+// wavefront's 128 x 64 sub-tile needs 12 KiB of LDS fragment reads per 32 MFMAs instead of 16.  Accumulators: 128 VGPRs per lane.
 // (Measured and dropped: FOUR wavefronts with 128 x 128 sub-tiles and 256 AGPR-pinned accumulators each - 192 instead of 256 KiB of
 // LDS traffic per K tile - ran the layer3 3x3 forward in 602 us against 493 us: one wavefront per SIMD cannot cover its own LDS
-// and barrier latencies with this schedule.)
-template <int BN, bool TU>
-__global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
-  using T = u16;
-  constexpr int ES = 2, BM = 256, BK = 64, NW = 8, VEC = 8;
-  constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);
-  constexpr int WGN = BN / 64, WGM = NW / WGN;
-  constexpr int WM = BM / WGM, WN = 64;
-  constexpr int TM = WM / 16, TN = WN / 16;
-  constexpr uint32_t OOB = 0xFFFFFFF0u;
-  __shared__ __attribute__((aligned(16))) char smem0[(BM + BN) * 128];
-  __shared__ __attribute__((aligned(16))) char smem1[(BM + BN) * 128];
-
-  const td_conv_desc& d = p.d;
-  const int t = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-  const int NT = d.Nc / BN;
-  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int mt = (seq / NT) * 8 + xcd, nt = seq - (seq / NT) * NT;
-  const int m0 = mt * BM, n0 = nt * BN;
-  if (m0 >= p.M) return;
-  const int lrow = lane >> 3;
-  const int chunk = (lane & 7) ^ lrow;
-  const int HoWo = d.Ho * d.Wo;
-  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-
-  uint32_t a_off[AI];   // pointwise: byte offset of the row
-  int a_base[AI];       // TU: pixel index of tap (0, 0)
-  uint32_t a_mask[AI];  // TU: taps inside the image
-  const int RS = d.R * d.S;
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int m = m0 + (i * NW + wave) * 8 + lrow;
-    const bool ok = m < p.M;
-    if constexpr (!TU) {
-      a_off[i] = ok ? (uint32_t)m * (uint32_t)p.K * ES : OOB;
-    } else {
-      const int mm = ok ? m : 0;
-      const int n = mm / HoWo;
-      const int rem = mm - n * HoWo;
-      const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-      const int hb = d.mode == 0 ? ho * d.stride - d.pad : ho + d.pad;
-      const int wb = d.mode == 0 ? wo * d.stride - d.pad : wo + d.pad;
-      a_base[i] = n * d.Hs * d.Ws + hb * d.Ws + wb;
-      uint32_t msk = 0;
-      for (int r = 0; r < d.R; ++r) {
-        const int hs = d.mode == 0 ? hb + r : hb - r;
-        for (int sx = 0; sx < d.S; ++sx) {
-          const int ws = d.mode == 0 ? wb + sx : wb - sx;
-          const bool in = (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
-          msk |= (in ? 1u : 0u) << (r * d.S + sx);
-        }
-      }
-      a_mask[i] = ok ? msk : 0u;
-    }
-  }
-  uint32_t b_off[BI];
-#pragma unroll
-  for (int i = 0; i < BI; ++i) b_off[i] = (uint32_t)(n0 + (i * NW + wave) * 8 + lrow) * (uint32_t)p.K * ES;  // Nc % BN == 0: always inside
-  const int lane_c = chunk * VEC;
-  // Position of the K walk: wave-uniform scalars, advanced once per tile WITHOUT control flow and handed from call to call by
-  // value.  (As ints captured by reference and updated under nested ifs they lived in scratch memory: a scratch load + s_waitcnt
-  // vmcnt(0) per update made the wavefront wait for the DMA loads it had just issued - 17 scratch accesses and 13 vmcnt waits
-  // per K tile of the 3x3 layers; the second resident wavefront of the SIMD covered most of it: 499 -> 493 us on the layer3 3x3.)
-  struct Walk { int kk, tap, ks, kc, pix; };  // kk: first column of the tile on the linear K axis; the rest: tap walk (TU)
-  const int step_s = d.mode == 0 ? 1 : -1, step_r = d.mode == 0 ? d.Ws - (d.S - 1) : -(d.Ws - (d.S - 1));
-  const bool tap_inner = TU && p.tap_inner;
-
-  auto issue_tile = [&](char* stage, Walk w) -> Walk {
-    char* stA = stage;
-    char* stB = stage + BM * 128;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      uint32_t off;
-      if constexpr (TU) {
-        const bool ok = (a_mask[i] >> (w.tap & 31)) & 1u;
-        off = ok ? (uint32_t)((a_base[i] + w.pix) * d.C + w.kc + lane_c) * ES : OOB;
-      } else {
-        off = a_off[i] != OOB ? a_off[i] + (uint32_t)(w.kk + lane_c) * ES : OOB;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stA + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
-    }
-    // weight columns of this tile: the K axis is [tap][channel]; in tap-inner order the walk is not linear
-    const uint32_t kw = (uint32_t)((tap_inner ? w.tap * d.C + w.kc : w.kk) + lane_c);
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const uint32_t off = b_off[i] + kw * ES;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(stB + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
-    }
-    w.kk += BK;
-    if constexpr (TU) {
-      // tap-inner order: all R*S taps of one 64-channel chunk back to back - the workgroup re-reads the SAME 128-byte line of every
-      // pixel of its window nine times within nine K tiles (32 KiB of activations per workgroup, 1 MiB per XCD: L2-resident)
-      // instead of coming back to a pixel's 512-byte row after four tiles of another tap (128 KiB per workgroup, 4 MiB per XCD =
-      // the whole L2: PMC FETCH_SIZE was 4.4x the source tensor).  tap-outer: all channel chunks of one tap, then the next tap.
-      const int kc1 = w.kc + BK;
-      const bool next_tap = tap_inner || kc1 >= d.C;       // this tile was the last one of its (tap, chunk run)
-      const int ks1 = w.ks + 1;
-      const bool wrap_s = ks1 == d.S;
-      const int tap1 = w.tap + 1;
-      const bool wrap_t = tap_inner && tap1 == RS;         // tap-inner: back to tap 0, next channel chunk
-      const int pix1 = w.pix + (wrap_s ? step_r : step_s);
-      w.kc = tap_inner ? (wrap_t ? kc1 : w.kc) : (next_tap ? 0 : kc1);
-      w.pix = next_tap ? (wrap_t ? 0 : pix1) : w.pix;
-      w.ks = next_tap ? ((wrap_s || wrap_t) ? 0 : ks1) : w.ks;
-      w.tap = next_tap ? (wrap_t ? 0 : tap1) : w.tap;
-      w.kc = __builtin_amdgcn_readfirstlane(w.kc);
-      w.pix = __builtin_amdgcn_readfirstlane(w.pix);
-      w.ks = __builtin_amdgcn_readfirstlane(w.ks);
-      w.tap = __builtin_amdgcn_readfirstlane(w.tap);
-    }
-    return w;
-  };
-
-  const int wy = wave / WGN, wx = wave - wy * WGN;
-  const int lr = lane & 15, lg = lane >> 4;
-  f32x4 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // One K tile = 2 k-steps x (TM / 4) groups of 4 activation fragments x 4 weight fragments = 16 MFMAs per group.  The
-  // fragments of group g + 1 are requested before the MFMAs of group g are issued and the scheduler may not move
-  // anything across a group boundary: at most 2 x 16 + 2 x 16 fragment registers are live next to the 128
-  // accumulators (left to itself the scheduler hoists all 24 fragment reads of the tile and spills accumulators).
-  // The pipeline runs ACROSS tiles: the barrier that publishes tile kt + 1 sits before the LAST group of tile kt, and
-  // the first fragments of tile kt + 1 are requested right behind it, so their LDS latency and the barrier skew are
-  // covered by 16 MFMAs instead of idling the matrix pipe at every tile head (3250 -> cycles per tile measured with
-  // tools/stamp_big.py; the floor is 2 waves x 64 MFMAs x 16.5 = 2112).
-  constexpr int GPK = TM / 4, NG = 2 * GPK;
-  static_assert(NG % 2 == 0, "fragment double buffer parity");
-  uint4 wf[2][TN], af[2][4];
-  auto load_w = [&](const char* stage, int ks, uint4 (&dst)[TN]) {
-    const char* stB = stage + BM * 128;
-    const int cidx = ks * 4 + lg;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int row = wx * WN + i * 16 + lr;
-      dst[i] = *(const uint4*)(stB + row * 128 + ((cidx ^ (row & 7)) << 4));
-    }
-  };
-  auto load_a = [&](const char* stage, int g, uint4 (&dst)[4]) {
-    const int ks = g / GPK, jh = (g - ks * GPK) * 4;
-    const int cidx = ks * 4 + lg;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = wy * WM + (jh + j) * 16 + lr;
-      dst[j] = *(const uint4*)(stage + row * 128 + ((cidx ^ (row & 7)) << 4));
-    }
-  };
-  // tile in `cur` (its group-0 fragments already requested into wf[0] / af[0]); `nxt` receives tile kt + 1
-  auto tile_body = [&](char* cur, char* nxt, bool has_next, Walk w) -> Walk {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g == 0 && has_next) w = issue_tile(nxt, w);  // every wavefront finished reading `nxt` (tile kt - 1) before the last barrier
-      if (g + 1 < NG) {
-        if ((g + 1) % GPK == 0) load_w(cur, (g + 1) / GPK, wf[((g + 1) / GPK) & 1]);
-        load_a(cur, g + 1, af[(g + 1) & 1]);
-      } else {
-        // own DMA of tile kt + 1 landed, own fragment reads of `cur` returned -> barrier -> both hold for every wavefront
-        // (the builtin, not inline asm: the compiler's own wait-count bookkeeping must see this wait, or it makes the
-        //  MFMAs below wait for the reads issued behind the barrier)
-        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        load_w(nxt, 0, wf[0]);  // after the last tile these read a stale stage: unused
-        load_a(nxt, 0, af[0]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const int ks = g / GPK, jh = (g - ks * GPK) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < TN; ++i) Mfma<T>::run(wf[ks & 1][i], af[g & 1][j], acc[i][jh + j]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    return w;
-  };
-
-  // ---- epilogue bookkeeping: chunks of 16 rows, 8 lanes x 16 bytes per 64-channel row segment ----
-  constexpr int CR = 16, NCH = WM / CR, EPL = 8, LPR = WN / EPL, RPI = 64 / LPR, NIT = CR / RPI, CPRW = WN / 4;
-  const int cc = lane % LPR, rsub = lane / LPR;
-  const int n = n0 + wx * WN + cc * EPL;
-  uint32_t offs[2][NIT];  // element offsets (the host checks rows * ldc < 2^31)
-  bool live[2][NIT];
-  uint4 res[2][NIT], msk[2][NIT];
-  auto fetch_chunk = [&](int c, int b) {
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int m = m0 + wy * WM + c * CR + it * RPI + rsub;
-      live[b][it] = m < p.M;
-      offs[b][it] = (uint32_t)min(m, p.M - 1) * (uint32_t)d.ldc + (uint32_t)n;
-      if (p.residual) res[b][it] = ld16(p.residual + offs[b][it] * ES);
-      if (p.mask_src) msk[b][it] = ld16(p.mask_src + offs[b][it] * ES);
-    }
-  };
-
-  const int nk = p.K / BK;
-#define TD_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-  TD_STAMP(0);
-  Walk walk = issue_tile(smem0, Walk{0, 0, 0, 0, 0});
-  __syncthreads();  // tile 0 landed
-  TD_STAMP(1);
-  load_w(smem0, 0, wf[0]);
-  load_a(smem0, 0, af[0]);
-#pragma unroll 1
-  for (int kt = 0; kt < nk; kt += 2) {
-    walk = tile_body(smem0, smem1, kt + 1 < nk, walk);
-    if (kt + 1 >= nk) break;
-    walk = tile_body(smem1, smem0, kt + 2 < nk, walk);
-  }
-  TD_STAMP(2);
-  fetch_chunk(0, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // every wavefront is done reading the stage buffers: they become the staging regions
-  TD_STAMP(3);
-  float* stg = (float*)((wave < 4 ? smem0 : smem1) + (wave & 3) * (CR * WN * 4));
-  const float alpha = p.alpha;
-  float bias[EPL];
-#pragma unroll
-  for (int r = 0; r < EPL; ++r) bias[r] = p.bias ? p.bias[n + r] : 0.f;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int b = c & 1;
-#pragma unroll
-    for (int jj = 0; jj < CR / 16; ++jj) {
-      const int row = jj * 16 + lr;
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int cx = (i * 4 + lg) ^ (row & (CPRW - 1));
-        const f32x4 a = acc[i][c * (CR / 16) + jj];
-        *(float4*)(stg + row * WN + cx * 4) = make_float4(a[0] * alpha, a[1] * alpha, a[2] * alpha, a[3] * alpha);
-      }
-    }
-    if (c + 1 < NCH) fetch_chunk(c + 1, b ^ 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = it * RPI + rsub;
-      const int sw = row & (CPRW - 1);
-      float v[EPL];
-#pragma unroll
-      for (int q = 0; q < EPL / 4; ++q) {
-        const float4 f = *(const float4*)(stg + row * WN + (((cc * (EPL / 4) + q) ^ sw) * 4));
-        v[4 * q + 0] = f.x + bias[4 * q + 0]; v[4 * q + 1] = f.y + bias[4 * q + 1];
-        v[4 * q + 2] = f.z + bias[4 * q + 2]; v[4 * q + 3] = f.w + bias[4 * q + 3];
-      }
-      if (p.residual) {
-        float r8[EPL];
-        unpack16<T>(res[b][it], r8);
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] += r8[r];
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (p.mask_src) {
-        float m8[EPL];
-        unpack16<T>(msk[b][it], m8);
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
-      }
-      if (live[b][it]) st16(p.out + offs[b][it] * ES, pack16<T>(v));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next chunk overwrites the region
-  }
-  TD_STAMP(5);
-#undef TD_STAMP
-}
-
-// ------------------------------------------------------------------------------------------------
-// The 256 x 256 tile again, on a PHASED main loop (round 4).  conv_gemm_big_kernel above keeps its eight wavefronts in lock
-// step: once per K tile every wavefront issues its 8 DMA pieces and their address arithmetic back to back, then drains its own
-// DMA (vmcnt(0)) in front of the tile's one barrier - both SIMD-resident wavefronts are away from the matrix pipe at the same
-// moment (2840 cycles per K tile measured against 2 x 64 MFMAs x 17 = 2176).  Here
+// and barrier latencies.)  TU / pointwise addressing exactly as in conv_gemm_kernel.
+//
+// The main loop is PHASED (round 4).  Its round-3 predecessor kept the eight wavefronts in lock step: once per K tile every
+// wavefront issued its 8 DMA pieces and their address arithmetic back to back, then drained its own DMA (vmcnt(0)) in front of the
+// tile's one barrier - both SIMD-resident wavefronts away from the matrix pipe at the same moment (2840 cycles per K tile measured
+// against 2 x 64 MFMAs x 17 = 2176; removed in round 5, the phased kernels were bit-identical to it).  Here
 //   * the wavefronts form two groups (0-3 / 4-7: one wavefront of each group per SIMD) that run the same instruction stream ONE
 //     BARRIER APART: a K tile is four phases of { load section | barrier | 16 MFMAs | barrier }, so while one group multiplies the
 //     other one reads its fragments and issues DMA - matrix beside memory on every SIMD, never matrix beside matrix;
@@ -878,7 +605,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big_kernel(GemmParams p) {
 // RAW - the issuing wavefront's vmcnt, then a barrier, then the read (one phase later for either group); WAR - a region is
 // re-staged no earlier than two barrier intervals after its last read was issued (the reads are retired by the lgkmcnt(0) right
 // behind the next barrier).  Tiles past the end of K are issued with out-of-range offsets (zero fill, no traffic) so that the
-// counts are the same in every iteration.  Addressing (tap-uniform / pointwise), tile order and epilogue as in conv_gemm_big_kernel.
+// counts are the same in every iteration.
 #ifndef TD_ABL
 #define TD_ABL 0  // timing ablations of conv_gemm_big8_kernel (tools/build_variant.sh; results are WRONG with any bit set): 1 (was: no K walk), 2 no DMA, 4 no fragment reads, 8 no s_setprio
 #endif
@@ -899,7 +626,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int I>
 using ic = std::integral_constant<int, I>;
 
-template <bool TU>
+template <bool TU, bool RES>  // RES: a residual operand in the epilogue (rare on this instance - the K = 512 expansions of layer4 -: its own instantiation keeps the loads out of everybody else's epilogue)
 __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
   using T = u16;
   constexpr int ES = 2, BM = 256, BN = 256, BK = 64, NW = 8, VEC = 8;
@@ -907,62 +634,25 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
   constexpr int STAGE = (BM + BN) * 128, WREG = BM * 128;  // one stage: activation rows, then weight rows (128 B per row)
   constexpr uint32_t OOB = 0xFFFFFFF0u;
   constexpr int MAXT = 160;  // K tiles + 4 look-ahead / round-up entries (host: K <= 64 * (MAXT - 4))
+  constexpr int STG = 16 * WN * ES;  // output transposition staging per wavefront: 16 rows x 64 channels of bf16 (2 KiB)
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   __shared__ __attribute__((aligned(16))) uint4 ktab[MAXT];  // per K tile: {activation byte offset of the tile's tap / columns, tap, weight byte offset, in-range mask}
+  __shared__ __attribute__((aligned(16))) char stg_all[NW * STG];  // (its own 16 KiB: the stage buffers take the NEXT tile's first pieces while this one is stored)
 
   const td_conv_desc& d = p.d;
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int NT = d.Nc / BN;
-  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int mt = (seq / NT) * 8 + xcd, nt = seq - (seq / NT) * NT;
-  const int m0 = mt * BM, n0 = nt * BN;
-  if (m0 >= p.M) return;
   const int lrow = lane >> 3;
   const int chunk = (lane & 7) ^ lrow;
   const int HoWo = d.Ho * d.Wo;
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const uint32_t out_bytes = (uint32_t)p.M * (uint32_t)d.ldc * ES;  // (host: M * ldc < 2^31)
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, out_bytes, 0x00020000);
   const int wy = wave >> 2, wx = wave & 3;  // wy is also the wavefront's group
-
-  // DMA piece q (0..3) of this wavefront on the activation side: tile rows xrow(q) .. + 8 = the part of QUARTER q (the rows the
-  // readers consume in phase q: M fragments 2q, 2q + 1 of both row groups) that this wavefront stages
-  uint32_t a_off[4];   // byte offset of the row (pointwise) / of tap (0, 0) of the row (TU; modulo 2^32)
-  uint32_t a_mask[4];  // bit (tap) set = the tap lies inside the image (pointwise: bit 0 = row below M)
   const int RS = d.R * d.S;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int m = m0 + (wave >> 2) * WM + q * 32 + (wave & 3) * 8 + lrow;
-    const bool ok = m < p.M;
-    if constexpr (!TU) {
-      a_off[q] = (uint32_t)m * (uint32_t)p.K * ES;
-      a_mask[q] = ok ? 1u : 0u;  // (the table's tap is 0 for pointwise tiles)
-    } else {
-      const int mm = ok ? m : 0;
-      const int n = mm / HoWo;
-      const int rem = mm - n * HoWo;
-      const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-      const int hb = d.mode == 0 ? ho * d.stride - d.pad : ho + d.pad;
-      const int wb = d.mode == 0 ? wo * d.stride - d.pad : wo + d.pad;
-      a_off[q] = (uint32_t)(n * d.Hs * d.Ws + hb * d.Ws + wb) * (uint32_t)d.C * ES;
-      uint32_t msk = 0;
-      for (int r = 0; r < d.R; ++r) {
-        const int hs = d.mode == 0 ? hb + r : hb - r;
-        for (int sx = 0; sx < d.S; ++sx) {
-          const int ws = d.mode == 0 ? wb + sx : wb - sx;
-          const bool in = (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
-          msk |= (in ? 1u : 0u) << (r * d.S + sx);
-        }
-      }
-      a_mask[q] = ok ? msk : 0u;
-    }
-  }
   const int lane_c = chunk * VEC;
-  uint32_t b_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) b_off[i] = ((uint32_t)(n0 + (i * NW + wave) * 8 + lrow) * (uint32_t)p.K + (uint32_t)lane_c) * ES;  // Nc % BN == 0: always inside
-#pragma unroll
-  for (int q = 0; q < 4; ++q) a_off[q] += (uint32_t)lane_c * ES;
   // The K walk is a TABLE in LDS, built once per workgroup: entry t = where tile t's 64 columns come from.  (As a running
   // (tap, channel, pixel) state advanced in the loop it was ~35 dependent scalar instructions per advance, two advances per tile:
   // 2697 -> 2239 cycles per K tile with the advance compiled out, tools/build_variant.sh abl1 - the scalar unit issues into the
@@ -985,6 +675,71 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
     }
     ktab[t] = make_uint4(xo, t < nk ? tap : 0u, wo, t < nk ? 0xFFFFFFFFu : 0u);
   }
+  // PERSISTENT, with the next tile's first pieces in flight under this tile's epilogue (round 5).  The workgroup walks output tiles
+  // vb = blockIdx.x, + gridDim.x, ... (the host launches one workgroup per CU when there are more tiles than CUs; gridDim.x is a
+  // multiple of 8, so a workgroup stays on its XCD's share of the rows).  What the 100 MHz wall clock said about the one-tile-per-
+  // workgroup form (tools/stamp_occupancy.py, tools/stamp_big.py; layer3 3x3, 800 frames, 62 us per tile and CU): K loop 50 us; per-
+  // lane row decoding with integer divisions and a test per tap ~4 us; landing time of the first pieces 2.2 us; epilogue 4.9 us
+  // (fp32 transposition in 16-row chunks through the stage buffers, two lgkmcnt(0) round trips per chunk) - 19 % of a tile with
+  // the matrix pipe idle.  Now: rows decoded with reciprocal multiplications; the accumulators leave through a wavefront-private
+  // 2-KiB bf16 staging region (bias / ReLU / rounding applied in the MFMA layout, 8-byte writes, 16-byte reads, both bank-conflict
+  // free under the chunk ^ row swizzle; DS operations of a wavefront execute in order, so no wait separates a chunk's reads from
+  // the next chunk's writes), and the twelve pieces of the NEXT tile's prologue are issued BEFORE the epilogue starts.
+  const int nvb = 8 * ((cdiv(p.M, BM) + 7) / 8) * NT;
+  const float rcp_howo = 1.f / (float)HoWo, rcp_wo = 1.f / (float)d.Wo;
+  auto divmod = [](int a, int dv, float rcp, int& q, int& r) {
+    q = (int)((float)a * rcp);
+    r = a - q * dv;
+    const int up = r >= dv, dn = r < 0;
+    q += up - dn;
+    r += (dn - up) * dv;
+  };
+  // tile (rows m0.., columns n0..) of virtual block vb; the blocks past the last row tile (grid rounded up to 8) can only be a
+  // workgroup's LAST ones
+  auto tile_m0 = [&](int vb) { const int seq = vb >> 3; return ((seq / NT) * 8 + (vb & 7)) * BM; };
+  auto tile_n0 = [&](int vb) { const int seq = vb >> 3; return (seq - (seq / NT) * NT) * BN; };
+  auto tile_ok = [&](int vb) { return vb < nvb && tile_m0(vb) < p.M; };
+
+  // DMA piece q (0..3) of this wavefront on the activation side: tile rows xrow(q) .. + 8 = the part of QUARTER q (the rows the
+  // readers consume in phase q: M fragments 2q, 2q + 1 of both row groups) that this wavefront stages
+  uint32_t a_off[4];   // byte offset of the row (pointwise) / of tap (0, 0) of the row (TU; modulo 2^32)
+  uint32_t a_mask[4];  // bit (tap) set = the tap lies inside the image (pointwise: bit 0 = row below M)
+  uint32_t b_off[4];
+  const bool small_filter = d.R <= 3 && d.S <= 3;
+  const int sgn = d.mode == 0 ? 1 : -1;  // forward: tap (r, s) reads pixel (hb + r, wb + s); input gradient: (hb - r, wb - s)
+  auto tile_addr = [&](int m0, int n0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + (wave >> 2) * WM + q * 32 + (wave & 3) * 8 + lrow;
+      const bool ok = m < p.M;
+      if constexpr (!TU) {
+        a_off[q] = (uint32_t)m * (uint32_t)p.K * ES + (uint32_t)lane_c * ES;
+        a_mask[q] = ok ? 1u : 0u;  // (the table's tap is 0 for pointwise tiles)
+      } else {
+        // (reciprocal multiplication + one correction step: exact for rows below 2^24, the host's condition for this instance)
+        const int mm = ok ? m : 0;
+        int n, rem, ho, wo;
+        divmod(mm, HoWo, rcp_howo, n, rem);
+        divmod(rem, d.Wo, rcp_wo, ho, wo);
+        const int hb = d.mode == 0 ? ho * d.stride - d.pad : ho + d.pad;
+        const int wb = d.mode == 0 ? wo * d.stride - d.pad : wo + d.pad;
+        a_off[q] = (uint32_t)(n * d.Hs * d.Ws + hb * d.Ws + wb) * (uint32_t)d.C * ES + (uint32_t)lane_c * ES;
+        uint32_t cols = 0, msk = 0;
+        if (small_filter) {  // (uniform) at most 3 x 3 taps: no loop, no branch per tap
+#pragma unroll
+          for (int sx = 0; sx < 3; ++sx) cols |= (sx < d.S && (unsigned)(wb + sgn * sx) < (unsigned)d.Ws ? 1u : 0u) << sx;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) msk |= (r < d.R && (unsigned)(hb + sgn * r) < (unsigned)d.Hs ? cols : 0u) << (r * d.S);
+        } else {
+          for (int sx = 0; sx < d.S; ++sx) cols |= ((unsigned)(wb + sgn * sx) < (unsigned)d.Ws ? 1u : 0u) << sx;
+          for (int r = 0; r < d.R; ++r) msk |= ((unsigned)(hb + sgn * r) < (unsigned)d.Hs ? cols : 0u) << (r * d.S);
+        }
+        a_mask[q] = ok ? msk : 0u;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b_off[i] = ((uint32_t)(n0 + (i * NW + wave) * 8 + lrow) * (uint32_t)p.K + (uint32_t)lane_c) * ES;  // Nc % BN == 0: always inside
+  };
   // one activation piece (quarter q) / one weight piece (i) of the tile described by table entry e into `stage`; branch-free: an
   // out-of-image tap, a row past M or a tile past K becomes the out-of-range offset through an all-ones / all-zeros mask
   auto issue_x = [&](char* stage, int q, const u32x4_t& e) {
@@ -1008,10 +763,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
 
   const int lr = lane & 15, lg = lane >> 4;
   f32x4 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read addresses (LDS byte offsets; the 16-byte chunk index is XOR-swizzled by row & 7 = lr & 7, the k-step flips bit 6)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
@@ -1070,34 +821,11 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };
-
-  // ---- epilogue bookkeeping (as conv_gemm_big_kernel) ----
-  constexpr int CR = 16, NCH = WM / CR, EPL = 8, LPR = WN / EPL, RPI = 64 / LPR, NIT = CR / RPI, CPRW = WN / 4;
-  const int cc = lane % LPR, rsub = lane / LPR;
-  const int n = n0 + wx * WN + cc * EPL;
-  uint32_t offs[2][NIT];
-  bool live[2][NIT];
-  uint4 res[2][NIT], msk[2][NIT];
-  auto fetch_chunk = [&](int c, int b) {
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int m = m0 + wy * WM + c * CR + it * RPI + rsub;
-      live[b][it] = m < p.M;
-      offs[b][it] = (uint32_t)min(m, p.M - 1) * (uint32_t)d.ldc + (uint32_t)n;
-      if (p.residual) res[b][it] = ld16(p.residual + offs[b][it] * ES);
-      if (p.mask_src) msk[b][it] = ld16(p.mask_src + offs[b][it] * ES);
-    }
-  };
-
-#define TD_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-  TD_STAMP(0);
-  if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + 6] = wall_clock64();  // (100 MHz, the same base on every CU: workgroup timeline, tools/stamp_occupancy.py)
-  __syncthreads();  // the K table is complete
-  // prologue = the issue order of the steady state: weights of tile 0, activations of tile 0, weights of tile 1
-  {
-    const u32x4_t e0 = lds_read16<0>(tab0);
+  // prologue of a tile = the issue order of the steady state: weights of tile 0, activations of tile 0, weights of tile 1 (twelve pieces)
+  auto prologue_issue = [&]() {
+    u32x4_t e0 = lds_read16<0>(tab0);
     ea = lds_read16<16>(tab0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0), "+v"(ea) : : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) issue_w(smem, i, e0);
@@ -1105,83 +833,154 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
     for (int q = 0; q < 4; ++q) issue_x(smem, q, e0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) issue_w(smem + STAGE, i, ea);
-  }
-  wait_vmcnt<7>();  // weights of tile 0 and activation quarter 0 have landed
-  __builtin_amdgcn_s_barrier();
-  if (wy == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind the first from here on
-  TD_STAMP(1);
-  // ONE loop over tile pairs and nothing else (an odd tile count is rounded up: the extra tile is zero fill without traffic) - an
-  // exit in the middle of the body makes the register allocator rename the accumulators across the two halves and spill them
-  const int npair = (nk + 1) / 2;
-#pragma unroll 1
-  for (int it = 0; it < npair; ++it) {
-    phase(ic<0>{}, ic<0>{}); phase(ic<0>{}, ic<1>{}); phase(ic<0>{}, ic<2>{}); phase(ic<0>{}, ic<3>{});
-    phase(ic<1>{}, ic<0>{}); phase(ic<1>{}, ic<1>{}); phase(ic<1>{}, ic<2>{}); phase(ic<1>{}, ic<3>{});
-  }
-  if (wy == 0) __builtin_amdgcn_s_barrier();  // pairs with the second group's last barrier
-  TD_STAMP(2);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // trailing zero-fill DMAs must not land in the staging regions below
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the asm MFMAs' results are read below: the hazard the compiler would pad for
+  };
+
+  // ---- epilogue addressing.  Write side: the MFMA layout - lane (lr, lg) holds channels i * 16 + lg * 4 .. + 4 of row lr of fragment
+  // (i, j): 8 bytes of bf16 at 16-byte chunk 2 i + (lg >> 1), half lg & 1.  Read side: 8 lanes x 16 bytes per 128-byte row, 8 rows per
+  // pass.  Chunk index XOR (row & 7) on both sides: the 8-byte writes of a wavefront spread over all 64 banks twice (rows r / r + 8),
+  // each 16-lane group of the 16-byte reads over the sixteen 16-byte slots of a 256-byte bank row. ----
+  const uint32_t stg0 = (uint32_t)(uintptr_t)(lds_ptr_t)stg_all + (uint32_t)wave * STG;
+  uint32_t swa[TN];
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(acc[i][j]));
-  fetch_chunk(0, 0);
-  __builtin_amdgcn_s_barrier();  // every wavefront is done with the stage buffers: they become the staging regions
-  TD_STAMP(3);
-  float* stg = (float*)(smem + (wave < 4 ? 0 : STAGE) + (wave & 3) * (CR * WN * 4));
+  for (int i = 0; i < TN; ++i) swa[i] = stg0 + (uint32_t)(lr * 128 + (((2 * i + (lg >> 1)) ^ (lr & 7)) << 4) + (lg & 1) * 8);
+  const int cc = lane & 7, rsub = lane >> 3;
+  const uint32_t sra = stg0 + (uint32_t)(rsub * 128 + ((cc ^ rsub) << 4));  // pass h: + h * 1024 (row h * 8 + rsub: the same row & 7)
   const float alpha = p.alpha;
-  float bias[EPL];
+
+#define TD_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)vb * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+  int vb = blockIdx.x;
+  if (!tile_ok(vb)) return;  // (uniform)
+  tile_addr(tile_m0(vb), tile_n0(vb));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // the K table is complete
+  prologue_issue();
+#pragma unroll 1
+  for (;;) {
+    const int m0 = tile_m0(vb), n0 = tile_n0(vb);
+    TD_STAMP(0);
+    if (p.dbg && t == 0) p.dbg[(size_t)vb * 8 + 6] = wall_clock64();  // (100 MHz, the same base on every CU: workgroup timeline, tools/stamp_occupancy.py)
 #pragma unroll
-  for (int r = 0; r < EPL; ++r) bias[r] = p.bias ? p.bias[n + r] : 0.f;
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int b = c & 1;
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    taddr = tab0 + 2 * 16;
+    f32x4 bs[TN];  // bias of this lane's channels in the MFMA layout: requested now, used after the K loop
 #pragma unroll
-    for (int jj = 0; jj < CR / 16; ++jj) {
-      const int row = jj * 16 + lr;
+    for (int i = 0; i < TN; ++i) bs[i] = p.bias ? *(const f32x4*)(p.bias + n0 + wx * WN + i * 16 + lg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // weights of K tile 0 and activation quarter 0 have landed (with stores of the previous tile's epilogue still in the queue the count
+    // is only stricter: loads retire in order among themselves, whatever else is outstanding)
+    wait_vmcnt<7>();
+    __builtin_amdgcn_s_barrier();
+    if (wy == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind the first from here on
+    TD_STAMP(1);
+    // ONE loop over tile pairs and nothing else (an odd tile count is rounded up: the extra tile is zero fill without traffic) - an
+    // exit in the middle of the body makes the register allocator rename the accumulators across the two halves and spill them
+    const int npair = (nk + 1) / 2;
+#pragma unroll 1
+    for (int it = 0; it < npair; ++it) {
+      phase(ic<0>{}, ic<0>{}); phase(ic<0>{}, ic<1>{}); phase(ic<0>{}, ic<2>{}); phase(ic<0>{}, ic<3>{});
+      phase(ic<1>{}, ic<0>{}); phase(ic<1>{}, ic<1>{}); phase(ic<1>{}, ic<2>{}); phase(ic<1>{}, ic<3>{});
+    }
+    if (wy == 0) __builtin_amdgcn_s_barrier();  // pairs with the second group's last barrier: every wavefront has read its last fragments
+    TD_STAMP(2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing zero-fill DMAs have landed: the stage buffers are free
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the asm MFMAs' results are read below: the hazard the compiler would pad for
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(acc[i][j]));
+    // (the bias registers are defined HERE, before the next tile's LDS-DMA pieces are issued: a register load still outstanding beside
+    //  them would be waited for with vmcnt(0) by the compiler, i.e. together with them)
+#pragma unroll
+    for (int i = 0; i < TN; ++i) asm volatile("" : "+v"(bs[i]));
+    const int vb_next = vb + (int)gridDim.x;
+    const bool more = tile_ok(vb_next);
+    if (more) {  // (uniform) the next tile's rows, and its first twelve pieces into the stage buffers every wavefront has left
+      tile_addr(tile_m0(vb_next), tile_n0(vb_next));
+      prologue_issue();
+    }
+    TD_STAMP(3);
+    // ---- epilogue: 16 rows (one M fragment) at a time ----
+    uint4 mk[2][2];
+    auto seg_off = [&](int j, int h) -> uint32_t {  // byte offset of this lane's 16-byte output segment of row h * 8 + rsub of fragment row j
+      const int m = m0 + wy * WM + j * 16 + h * 8 + rsub;
+      return m < p.M ? ((uint32_t)m * (uint32_t)d.ldc + (uint32_t)(n0 + wx * WN + cc * 8)) * ES : OOB;
+    };
+    auto fetch_mask = [&](int j, int b) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t off = seg_off(j, h);
+        mk[b][h] = off != OOB ? ld16(p.mask_src + off) : make_uint4(0, 0, 0, 0);
+      }
+    };
+    // fragment row j: bias / residual / ReLU / rounding in the MFMA layout, then four 8-byte writes into the staging rows
+    auto put = [&](int j) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        const int cx = (i * 4 + lg) ^ (row & (CPRW - 1));
-        const f32x4 a = acc[i][c * (CR / 16) + jj];
-        *(float4*)(stg + row * WN + cx * 4) = make_float4(a[0] * alpha, a[1] * alpha, a[2] * alpha, a[3] * alpha);
+        const f32x4 a = acc[i][j];
+        float v[4] = {a[0] * alpha + bs[i][0], a[1] * alpha + bs[i][1], a[2] * alpha + bs[i][2], a[3] * alpha + bs[i][3]};
+        if constexpr (RES) {  // 8 bytes per lane in the MFMA layout
+          const int m = m0 + wy * WM + j * 16 + lr;
+          if (m < p.M) {
+            const uint2 rr = *(const uint2*)(p.residual + ((size_t)m * d.ldc + n0 + wx * WN + i * 16 + lg * 4) * ES);
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          }
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        const uint32_t lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
+        asm volatile("ds_write_b64 %0, %1" ::"v"(swa[i]), "v"(u32x2_t{lo, hi}) : "memory");
       }
+    };
+    // Pipelined over the fragment rows with ONE staging buffer: DS operations of a wavefront execute in order, so the writes of row
+    // j + 1 may be issued right behind the reads of row j (which then return the old bytes), and lgkmcnt(4) - the four younger writes
+    // may still be outstanding - says that those reads have returned.  The arithmetic of row j + 1 covers the LDS round trip of row j.
+    if (p.mask_src) fetch_mask(0, 0);
+    put(0);
+    u32x4_t o0, o1;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(sra) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(o1) : "v"(sra) : "memory");
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int b = j & 1;
+      if (j + 1 < TM) {
+        if (p.mask_src) fetch_mask(j + 1, b ^ 1);
+        put(j + 1);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(o0), "+v"(o1) : : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1) : : "memory");
+      }
+      u32x4_t s0 = o0, s1 = o1;
+      if (j + 1 < TM) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(sra) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(o1) : "v"(sra) : "memory");
+      }
+      if (p.mask_src) {  // ReLU mask of the producing layer (input gradients): a select on the rounded values
+        float x8[8], m8[8];
+        unpack16<T>(make_uint4(s0.x, s0.y, s0.z, s0.w), x8);
+        unpack16<T>(mk[b][0], m8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x8[r] = m8[r] > 0.f ? x8[r] : 0.f;
+        const uint4 q0 = pack16<T>(x8);
+        s0 = u32x4_t{q0.x, q0.y, q0.z, q0.w};
+        unpack16<T>(make_uint4(s1.x, s1.y, s1.z, s1.w), x8);
+        unpack16<T>(mk[b][1], m8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x8[r] = m8[r] > 0.f ? x8[r] : 0.f;
+        const uint4 q1 = pack16<T>(x8);
+        s1 = u32x4_t{q1.x, q1.y, q1.z, q1.w};
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(s0, rs_out, (int)seg_off(j, 0), 0, 0);  // rows past M: out-of-range offset, dropped
+      __builtin_amdgcn_raw_buffer_store_b128(s1, rs_out, (int)seg_off(j, 1), 0, 0);
     }
-    if (c + 1 < NCH) fetch_chunk(c + 1, b ^ 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = it * RPI + rsub;
-      const int sw = row & (CPRW - 1);
-      float v[EPL];
-#pragma unroll
-      for (int q = 0; q < EPL / 4; ++q) {
-        const float4 f = *(const float4*)(stg + row * WN + (((cc * (EPL / 4) + q) ^ sw) * 4));
-        v[4 * q + 0] = f.x + bias[4 * q + 0]; v[4 * q + 1] = f.y + bias[4 * q + 1];
-        v[4 * q + 2] = f.z + bias[4 * q + 2]; v[4 * q + 3] = f.w + bias[4 * q + 3];
-      }
-      if (p.residual) {
-        float r8[EPL];
-        unpack16<T>(res[b][it], r8);
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] += r8[r];
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (p.mask_src) {
-        float m8[EPL];
-        unpack16<T>(msk[b][it], m8);
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
-      }
-      if (live[b][it]) st16(p.out + offs[b][it] * ES, pack16<T>(v));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next chunk overwrites the region
+    TD_STAMP(5);
+    if (p.dbg && t == 0) p.dbg[(size_t)vb * 8 + 7] = wall_clock64();
+    if (!more) break;
+    vb = vb_next;
   }
-  TD_STAMP(5);
-  if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
 #undef TD_STAMP
 }
 
@@ -1456,201 +1255,27 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8n_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent, weight-stationary instance for the HBM-bound pointwise layers with K <= 256 (bottleneck conv3 forward,
-// conv1 dgrad: [M][K] x [Nc][K]^T with M in the 10^4..10^6 range).  In the tiled kernel above two thirds of such a
-// workgroup's HBM->LDS traffic is the weight tile it re-reads for every 64 rows, and with one K tile in flight per
-// workgroup the chip holds too few bytes in flight to cover the HBM latency (2.9 TB/s measured).  Here one workgroup per
-// CU keeps its 128 x K weight tile in LDS for the whole launch and walks the M tiles of its group: the activation tile
-// of the NEXT M tile is DMA'd while the current one is multiplied and stored, and the residual / mask rows are
-// requested at the top of the step.  The 128-row-of-N tiles of one M tile run on CUs of the same XCD at the same
-// time, so the activation tile comes from HBM once per XCD.  bf16, fused bias + residual + ReLU + mask epilogue.
-template <int NKT, bool RES, bool MSK>
-__global__ __launch_bounds__(256, 2) void pw_resident_kernel(GemmParams p, int MT, int P) {
-  using T = u16;
-  constexpr int ES = 2;
-  constexpr uint32_t OOB = 0xFFFFFFF0u;
-  constexpr int WM = 32, WN = 64, TM = 2, TN = 4;
-  constexpr int CPRW = WN / 4, EPL = 8, LPR = WN / EPL, RPI = 64 / LPR, NIT = WM / RPI;
-  constexpr int NOPS = NIT * ((RES ? 1 : 0) + (MSK ? 1 : 0));  // operand loads per lane per step
-  __shared__ __attribute__((aligned(16))) char sA0[32768];
-  __shared__ __attribute__((aligned(16))) char sA1[32768];
-  const td_conv_desc& d = p.d;
-  const int t = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-  const int NT = d.Nc >> 7;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int GPX = P / NT;                      // M-tile groups per XCD
-  const int nt = local % NT, gl = local / NT;
-  if (gl >= GPX) return;
-  const int gid = xcd * GPX + gl, G = 8 * GPX;
-  const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
-  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const int n0 = nt * 128;
-  // source row of output row m: m itself, or - strided 1x1 (the downsample branch of a stage's first block, forward) - the
-  // pixel (ho * stride, wo * stride) of its image
-  const int HoWo = d.Ho * d.Wo;
-  const bool strided = d.stride != 1;
-  auto issue_A = [&](char* buf, int mt) {
-    const int m0 = mt * 64;
-    uint32_t row[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + (i * 4 + wave) * 8 + lrow;
-      int src_row = m;
-      if (strided) {
-        const int img = m / HoWo, rem = m - img * HoWo;
-        const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-        src_row = (img * d.Hs + ho * d.stride) * d.Ws + wo * d.stride;
-      }
-      row[i] = (mt < MT && m < p.M) ? (uint32_t)src_row * (uint32_t)p.K * ES : OOB;
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const uint32_t off = row[i] != OOB ? row[i] + (uint32_t)(kt * 64 + chunk * 8) * ES : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(buf + kt * 8192 + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
-      }
-  };
-  const int wy = wave >> 1, wx = wave & 1;
-  const int lr = lane & 15, lg = lane >> 4;
-  const int cc = lane % LPR, rsub = lane / LPR;
-  const int n = n0 + wx * WN + cc * EPL;
-  float bias[EPL];
-#pragma unroll
-  for (int r = 0; r < EPL; ++r) bias[r] = p.bias ? p.bias[n + r] : 0.f;
-  // the weight tile of this workgroup never changes: its MFMA fragments (row n = lane%16 of each 16-row block, 8
-  // consecutive k per lane group) live in registers for the whole launch - 16-byte loads straight from global, no LDS
-  uint4 wfr[NKT][2][TN];
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        wfr[kt][ks][i] = *(const uint4*)(p.w + ((size_t)(n0 + wx * WN + i * 16 + lr) * p.K + kt * 64 + ks * 32 + lg * 8) * ES);
-  int mt = gid;
-  issue_A(sA0, mt);
-  const uint32_t drop_seed = p.drop_thresh ? effective_seed(p.seed, p.seed_dev) : 0u;
-
-  auto step = [&](char* cur, char* nxt, int mt) {
-    // (1) epilogue operands of this tile (rows clamped: every lane always issues, the wait counts below are constants)
-    size_t offs[NIT];
-    bool live[NIT];
-    uint4 res[NIT], msk[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int m = mt * 64 + wy * WM + it * RPI + rsub;
-      live[it] = m < p.M;
-      offs[it] = (size_t)min(m, p.M - 1) * d.ldc + n;
-      if constexpr (RES) res[it] = ld16(p.residual + offs[it] * ES);
-      if constexpr (MSK) msk[it] = ld16(p.mask_src + offs[it] * ES);
-    }
-    // (2) next activation tile, then wait for the current one: only the loads issued in (1) and (2) may still be in
-    //     flight (loads complete in order; stores of the previous tile can only make this wait stricter)
-    issue_A(nxt, mt + G);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NKT + NOPS) : "memory");
-    __builtin_amdgcn_s_barrier();
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int cidx = ks * 4 + lg;
-        uint4 af[TM];
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          const int row = wy * WM + j * 16 + lr;
-          af[j] = *(const uint4*)(cur + kt * 8192 + row * 128 + ((cidx ^ (row & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) Mfma<T>::run(wfr[kt][ks][i], af[j], acc[i][j]);
-      }
-    // (3) every wave is done with the activation tile: its buffer becomes the transposition staging area
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    float* stg = (float*)(cur + wave * (WM * WN * 4));
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int row = j * 16 + lr;
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int c = (i * 4 + lg) ^ (row & (CPRW - 1));
-        const f32x4 a = acc[i][j];
-        *(float4*)(stg + row * WN + c * 4) = make_float4(a[0], a[1], a[2], a[3]);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = it * RPI + rsub;
-      const int sw = row & (CPRW - 1);
-      float v[EPL];
-#pragma unroll
-      for (int q = 0; q < EPL / 4; ++q) {
-        const float4 f = *(const float4*)(stg + row * WN + (((cc * (EPL / 4) + q) ^ sw) * 4));
-        v[4 * q + 0] = f.x + bias[4 * q + 0]; v[4 * q + 1] = f.y + bias[4 * q + 1];
-        v[4 * q + 2] = f.z + bias[4 * q + 2]; v[4 * q + 3] = f.w + bias[4 * q + 3];
-      }
-      if constexpr (RES) {
-        float r8[EPL];
-        unpack16<T>(res[it], r8);
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] += r8[r];
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      if constexpr (MSK) {
-        float m8[EPL];
-        unpack16<T>(msk[it], m8);
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] = m8[r] > 0.f ? v[r] : 0.f;
-      }
-      if (p.drop_thresh) {  // (same element index as conv_gemm_kernel's epilogue and td_dropout: the backward regenerates this mask)
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] = dropout_keep(drop_seed, (uint32_t)(offs[it] + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
-      }
-      if (live[it]) st16(p.out + offs[it] * ES, pack16<T>(v));
-    }
-    // (4) staging reads done before the next step's DMA lands in this buffer
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
-  while (mt < MT) {
-    step(sA0, sA1, mt);
-    mt += G;
-    if (mt >= MT) break;
-    step(sA1, sA0, mt);
-    mt += G;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-OOB) prefetch must not outlive the workgroup's LDS
-}
-
-// ------------------------------------------------------------------------------------------------
-// pw_resident_kernel again (round 4), re-pipelined.  What bounded the first form (5.0 - 5.4 TB/s of its algorithmic bytes) was
-// not bytes but requests in flight: per step a workgroup issued one activation tile + this tile's residual / mask rows, then
-// spent the rest of the step - MFMAs, an accumulator transposition through the activation buffer itself, three more barriers,
-// the stores - with nothing new on its way.  Here
+// Persistent, weight-stationary instance for the HBM-bound pointwise layers with K <= 256 (bottleneck conv3 forward, conv1 input
+// gradient, the encoder's 256 -> 2048 FFN layer: [M][K] x [Nc][K]^T with M in the 10^4..10^6 range).  In the tiled kernel above two
+// thirds of such a workgroup's HBM -> LDS traffic is the weight tile it re-reads for every 64 rows, and with one K tile in flight per
+// workgroup the chip holds too few bytes in flight to cover the HBM latency (2.9 TB/s measured).  Here two workgroups per CU keep
+// their 128 x K weight tile as MFMA fragments IN REGISTERS for the whole launch and walk the 64-row M tiles of their group; the
+// 128-row-of-N tiles of one M tile run on CUs of the same XCD at the same time, so the activation tile comes from HBM once per XCD.
+// bf16, fused bias + residual + ReLU + mask (+ dropout) epilogue.  What bounds such a kernel is not bytes but requests in flight
+// (the round-3 form, pw_resident_kernel, issued one activation tile + this tile's residual / mask rows per step and then spent the
+// rest of the step - MFMAs, an accumulator transposition through the activation buffer itself, three more barriers, the stores -
+// with nothing new on its way: 5.0 - 5.4 TB/s of its algorithmic bytes; removed in round 5, this kernel was bit-identical to it):
 //   * the accumulator transposition has its own 4 KiB per wavefront (16 rows at a time; 2 x 32 KiB slots + 16 KiB = 80 KiB: still
 //     two workgroups per CU), so the activation slot of tile t is free right after the barrier that follows its MFMAs: tile t + 2
 //     is requested into it BEFORE the epilogue of tile t - two activation tiles in flight on a two-slot ring;
 //   * residual / mask rows are requested ONE TILE AHEAD into a second register set (inline-asm loads with counted waits; the
 //     compiler's own bookkeeping across the loop back edge would drain the queue), except for the residual + mask instances with
-//     K = 256, whose 128 weight-fragment registers leave no room: they request this tile's rows before the MFMAs, as before;
-//   * two barriers per step instead of four.
+//     K = 256, whose 128 weight-fragment registers leave no room: they request this tile's rows before the MFMAs;
+//   * two barriers per step.
 // (Measured and dropped: the LDS-free epilogue of v_permlane16_swap - it stores 16 rows x 64 bytes per instruction instead of
 // 8 rows x 128: 4.0 instead of 5.3 TB/s on the layer3 conv3 shape.  Half-line requests are what an HBM-bound kernel cannot afford.)
 // Counted waits are derived from LOADS only (loads retire in issue order among themselves; stores in flight can only make a
-// wait stricter).  Same tile order, same arithmetic and rounding as pw_resident_kernel: bit-identical results.
+// wait stricter).
 template <int NKT, bool RES, bool MSK>
 __global__ __launch_bounds__(256, 2) void pw_resident2_kernel(GemmParams p, int MT, int P) {
   using T = u16;
@@ -1840,205 +1465,6 @@ __global__ __launch_bounds__(256, 2) void pw_resident2_kernel(GemmParams p, int 
     mt += G;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (out-of-range) requests must not outlive the workgroup's LDS / registers
-}
-
-// ------------------------------------------------------------------------------------------------
-// Two chained pointwise layers in one persistent launch: out1 = relu(x W1^T + b1 + residual) (the conv3 + identity of a
-// layer1 bottleneck: K1 = 64 -> N1 = 256) and out2 = relu(out1 W2^T + b2) (conv1 of the NEXT bottleneck: 256 -> 64 / 128).
-// Both are HBM-bound and out1 (4 GB at 8 clips) is their dominant stream: run apart, the second layer reads all of it
-// again.  Here a workgroup owns whole rows (64 per step, all 256 channels), keeps both weight matrices as MFMA fragments in
-// registers, writes the out1 tile to HBM AND (as bf16, chunk-swizzled) to LDS, and multiplies it by W2 from there - the
-// second layer costs its 64 / 128-channel output and 32 MFMAs per wavefront and step, no input traffic.
-struct ChainParams {
-  const char* x;       // [M][64] bf16
-  const char* w1;      // [256][64] bf16 (FrozenBN folded)
-  const float* b1;
-  const char* res;     // [M][256] bf16
-  char* out1;          // [M][256] bf16
-  const char* w2;      // [N2][256] bf16
-  const float* b2;
-  char* out2;          // [M][N2] bf16
-  int M;
-  uint32_t x_bytes;
-};
-
-template <int N2T>  // second layer: 64 * N2T output channels, 16 * N2T per wavefront
-__global__ __launch_bounds__(256, 2) void pw_chain_kernel(ChainParams p, int MT) {
-  using T = u16;
-  constexpr int ES = 2, K1 = 64, N1 = 256, N2 = 64 * N2T;
-  constexpr uint32_t OOB = 0xFFFFFFF0u;
-  constexpr int TM = 4, TN = 4;                       // first layer, per wavefront: 64 rows x 64 channels
-  constexpr int EPL = 8, LPR = 64 / EPL, RPI = 64 / LPR, NIT = 64 / RPI, CPRW = 16;  // 8 lanes per 64-channel row segment, 8 rows per instruction
-  __shared__ __attribute__((aligned(16))) char sA0[8192];
-  __shared__ __attribute__((aligned(16))) char sA1[8192];
-  __shared__ __attribute__((aligned(16))) float sStg[4][32 * 64];   // per wavefront: 32 rows x 64 channels fp32, chunk-swizzled
-  __shared__ __attribute__((aligned(16))) char sT[64 * 512];        // out1 tile, bf16 [64][256], 16-byte chunks swizzled by (row & 7)
-  const int t = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-  const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  auto issue_A = [&](char* buf, int mt) {  // 64 rows x 128 B: two DMA instructions per wavefront
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = mt * 64 + (i * 4 + wave) * 8 + lrow;
-      const uint32_t off = (mt < MT && m < p.M) ? ((uint32_t)m * K1 + (uint32_t)(chunk * 8)) * ES : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(buf + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
-    }
-  };
-  const int lr = lane & 15, lg = lane >> 4;
-  const int cc = lane % LPR, rsub = lane / LPR;
-  const int n1 = wave * 64 + cc * EPL;  // first output channel of this lane's 16-byte segment
-  float bias1[EPL];
-#pragma unroll
-  for (int r = 0; r < EPL; ++r) bias1[r] = p.b1 ? p.b1[n1 + r] : 0.f;
-  // both weight matrices as MFMA A-operand fragments in registers for the whole launch
-  // (second layer: the first 16 channels of this wavefront stay in registers, a second 16-channel block - N2 = 128 - is
-  //  re-read from L2 in every step once the first layer's accumulators are gone: 64 more persistent registers would spill)
-  uint4 w1f[2][TN], w2f[8];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int i = 0; i < TN; ++i) w1f[ks][i] = *(const uint4*)(p.w1 + ((size_t)(wave * 64 + i * 16 + lr) * K1 + ks * 32 + lg * 8) * ES);
-  const char* w2row = p.w2 + ((size_t)(wave * 16 * N2T + lr) * N1 + lg * 8) * ES;
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) w2f[ks] = *(const uint4*)(w2row + (size_t)ks * 32 * ES);
-  float bias2[N2T][4];
-#pragma unroll
-  for (int i = 0; i < N2T; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias2[i][r] = p.b2 ? p.b2[wave * 16 * N2T + i * 16 + 4 * lg + r] : 0.f;
-  const int G = gridDim.x;
-  int mt = blockIdx.x;
-  issue_A(sA0, mt);
-
-  auto step = [&](char* cur, char* nxt, int mt) {
-    const int m0 = mt * 64;
-    // (1) residual rows of this tile (clamped: every lane always issues, the wait count below is a constant)
-    uint32_t offs[NIT];
-    bool live[NIT];
-    uint4 res[NIT];  // rows 0..31 are requested here, rows 32..63 behind the first layer's MFMAs (register pressure)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int m = m0 + it * RPI + rsub;
-      live[it] = m < p.M;
-      offs[it] = (uint32_t)min(m, p.M - 1) * N1 + (uint32_t)n1;
-      if (it < NIT / 2) res[it] = ld16(p.res + (size_t)offs[it] * ES);
-    }
-    // (2) next activation tile, then wait for the current one (loads complete in order: only (1) and (2) may be in flight)
-    issue_A(nxt, mt + G);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NIT / 2) : "memory");
-    __builtin_amdgcn_s_barrier();
-    // (3) first layer: 64 rows x this wavefront's 64 channels
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int cidx = ks * 4 + lg;
-      uint4 af[TM];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int row = j * 16 + lr;
-        af[j] = *(const uint4*)(cur + row * 128 + ((cidx ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) Mfma<T>::run(w1f[ks][i], af[j], acc[i][j]);
-    }
-#pragma unroll
-    for (int it = NIT / 2; it < NIT; ++it) res[it] = ld16(p.res + (size_t)offs[it] * ES);
-    // (4) epilogue of the first layer in two halves of 32 rows through this wavefront's private staging area
-    float* stg = sStg[wave];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int row = jj * 16 + lr;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int c = (i * 4 + lg) ^ (row & (CPRW - 1));
-          const f32x4 a = acc[i][2 * h + jj];
-          *(float4*)(stg + row * 64 + c * 4) = make_float4(a[0], a[1], a[2], a[3]);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int q = 0; q < NIT / 2; ++q) {
-        const int it = h * (NIT / 2) + q;
-        const int row = q * RPI + rsub;  // row inside the half
-        const int sw = row & (CPRW - 1);
-        float v[EPL], r8[EPL];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const float4 f = *(const float4*)(stg + row * 64 + (((cc * 2 + u) ^ sw) * 4));
-          v[4 * u + 0] = f.x + bias1[4 * u + 0]; v[4 * u + 1] = f.y + bias1[4 * u + 1];
-          v[4 * u + 2] = f.z + bias1[4 * u + 2]; v[4 * u + 3] = f.w + bias1[4 * u + 3];
-        }
-        unpack16<T>(res[it], r8);
-#pragma unroll
-        for (int r = 0; r < EPL; ++r) v[r] = fmaxf(v[r] + r8[r], 0.f);
-        const uint4 o = pack16<T>(v);
-        if (live[it]) st16(p.out1 + (size_t)offs[it] * ES, o);
-        const int trow = h * 32 + row;  // row inside the 64-row tile
-        *(uint4*)(sT + trow * 512 + (((wave * 8 + cc) ^ (trow & 7)) << 4)) = o;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the second half overwrites the area
-    }
-    uint4 w2g[N2T > 1 ? 8 : 1];  // second 16-channel block of W2 (N2 = 128): requested before the barrier, used behind it
-    if constexpr (N2T > 1) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) w2g[ks] = *(const uint4*)(w2row + ((size_t)16 * N1 + (size_t)ks * 32) * ES);
-    }
-    __builtin_amdgcn_s_barrier();  // the bf16 out1 tile is complete
-    // (5) second layer: 64 rows x 16 * N2T channels per wavefront, K = 256 from the LDS tile
-    f32x4 acc2[N2T][TM];
-#pragma unroll
-    for (int i = 0; i < N2T; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int cidx = ks * 4 + lg;
-      uint4 af[TM];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int row = j * 16 + lr;
-        af[j] = *(const uint4*)(sT + row * 512 + ((cidx ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < TM; ++j) Mfma<T>::run(w2f[ks], af[j], acc2[0][j]);
-      if constexpr (N2T > 1) {
-#pragma unroll
-        for (int j = 0; j < TM; ++j) Mfma<T>::run(w2g[ks], af[j], acc2[1][j]);
-      }
-    }
-    // lane: 4 consecutive channels of row j*16 + lr -> 8-byte stores
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = m0 + j * 16 + lr;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int i = 0; i < N2T; ++i) {
-        float v4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v4[r] = fmaxf(acc2[i][j][r] + bias2[i][r], 0.f);
-        store4<T>(p.out2, (size_t)m * N2 + wave * 16 * N2T + i * 16 + 4 * lg, v4);
-      }
-    }
-    // the next step's barrier (2) also orders this step's LDS-tile reads before the next tile's writes
-  };
-
-  while (mt < MT) {
-    step(sA0, sA1, mt);
-    mt += G;
-    if (mt >= MT) break;
-    step(sA1, sA0, mt);
-    mt += G;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-OOB) prefetch must not outlive the workgroup's LDS
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2727,15 +2153,15 @@ static int conv_gemm_launch(const void* src, const void* wmat, void* out, const 
   }
   TD_REQUIRE(d->ldc >= d->Nc, "td_conv_gemm: ldc < Nc");
   hipStream_t st = (hipStream_t)stream;
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+  }();
   {
-    // persistent weight-stationary instance (see pw_resident_kernel): bf16 pointwise layers with short K and many rows
+    // persistent weight-stationary instance (see pw_resident2_kernel): bf16 pointwise layers with short K and many rows
     static const int persist = [] { const char* e_ = getenv("TD_PW_PERSIST"); return e_ ? atoi(e_) : 1; }();
     static const int persist_dropout = [] { const char* e_ = getenv("TD_PW_PERSIST_DROPOUT"); return e_ ? atoi(e_) : 1; }();  // (A/B: 0 = dropout epilogues on the tiled kernel)
-    static const int n_cu = [] {
-      int dev = 0, cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      return cus;
-    }();
     // dense rows, or the strided 1x1 of a downsample branch in forward geometry (the kernel derives the source pixel per row)
     const bool pw0 = d->R == 1 && d->S == 1 && d->pad == 0 && p.d.out_sp == 1 && !d->aniso &&
                      ((d->stride == 1 && d->Hs == d->Ho && d->Ws == d->Wo) ||
@@ -2743,7 +2169,7 @@ static int conv_gemm_launch(const void* src, const void* wmat, void* out, const 
     const int NTp = d->Nc / 128, Pp = 2 * n_cu / 8;
     const bool shape_ok = pw0 && !p.w_ld && dtype == TD_BF16 && p.K % 64 == 0 && p.K <= 256 && d->Nc % 128 == 0 &&
                           (NTp == 1 || NTp == 2 || NTp == 4 || NTp == 8 || NTp == 16) && Pp >= NTp && d->ldc % 8 == 0 && !p.sigmoid &&
-                          p.alpha == 1.f && n_cu % 8 == 0 && (!p.drop_thresh || persist_dropout);
+                          p.alpha == 1.f && n_cu % 8 == 0 && (!p.drop_thresh || persist_dropout) && (double)p.M * d->ldc < 2147483000.0;
     const int MTp = cdiv(p.M, 64);
     const int groups = shape_ok ? 8 * (Pp / NTp) : 1;
     if (persist && shape_ok && MTp >= persist_min_tiles() * groups && !(persist == 2 && p.mask_src) && !(persist == 3 && d->mode != 0)) {
@@ -2759,19 +2185,12 @@ static int conv_gemm_launch(const void* src, const void* wmat, void* out, const 
       const int nkt = p.K / 64;
       const bool hr = p.residual != nullptr, hm = p.mask_src != nullptr;
       dim3 g2(2 * n_cu);  // two resident workgroups per CU (64 KiB of LDS each)
-      static const int v2 = [] { const char* e_ = getenv("TD_PW_PERSIST_V2"); return e_ ? atoi(e_) : 1; }();  // (A/B: 0 = the first form)
-      const bool use2 = v2 && (double)p.M * d->ldc < 2147483647.0 && p.alpha == 1.f;
-#define TD_PWR(NK)                                                                                      \
-  do {                                                                                                  \
-    if (use2) {                                                                                         \
-      if (hr && hm) pw_resident2_kernel<NK, true, true><<<g2, 256, 0, st>>>(p, MTp, Pp);               \
-      else if (hr) pw_resident2_kernel<NK, true, false><<<g2, 256, 0, st>>>(p, MTp, Pp);               \
-      else if (hm) pw_resident2_kernel<NK, false, true><<<g2, 256, 0, st>>>(p, MTp, Pp);               \
-      else pw_resident2_kernel<NK, false, false><<<g2, 256, 0, st>>>(p, MTp, Pp);                      \
-    } else if (hr && hm) pw_resident_kernel<NK, true, true><<<g2, 256, 0, st>>>(p, MTp, Pp);           \
-    else if (hr) pw_resident_kernel<NK, true, false><<<g2, 256, 0, st>>>(p, MTp, Pp);                  \
-    else if (hm) pw_resident_kernel<NK, false, true><<<g2, 256, 0, st>>>(p, MTp, Pp);                  \
-    else pw_resident_kernel<NK, false, false><<<g2, 256, 0, st>>>(p, MTp, Pp);                         \
+#define TD_PWR(NK)                                                                               \
+  do {                                                                                           \
+    if (hr && hm) pw_resident2_kernel<NK, true, true><<<g2, 256, 0, st>>>(p, MTp, Pp);          \
+    else if (hr) pw_resident2_kernel<NK, true, false><<<g2, 256, 0, st>>>(p, MTp, Pp);          \
+    else if (hm) pw_resident2_kernel<NK, false, true><<<g2, 256, 0, st>>>(p, MTp, Pp);          \
+    else pw_resident2_kernel<NK, false, false><<<g2, 256, 0, st>>>(p, MTp, Pp);                 \
   } while (0)
       if (nkt == 1) TD_PWR(1);
       else if (nkt == 2) TD_PWR(2);
@@ -2801,13 +2220,14 @@ static int conv_gemm_launch(const void* src, const void* wmat, void* out, const 
   // a tap -> column-block map (WeightSubset: the parity classes of a stride-2 input gradient) is honoured by the tap-uniform K walk only
   TD_REQUIRE(tu || !p.use_wtap, "td_conv_gemm: a weight-column subset needs the tap-uniform addressing (C %% %d == 0, at most 32 taps)", bk);
   {
-    // 256-row tiles (conv_gemm_big_kernel): MFMA-bound bf16 layers with enough workgroups to matter
+    // 256-row tiles (conv_gemm_big8_kernel / conv_gemm_big8n_kernel): MFMA-bound bf16 layers with enough workgroups to matter
     static const int big_on = [] { const char* e_ = getenv("TD_CONV_BIG"); return e_ ? atoi(e_) : 1; }();
     static const int big_min = [] { const char* e_ = getenv("TD_CONV_BIG_MIN_WG"); return e_ ? atoi(e_) : 160; }();
     const int bnb = d->Nc % 256 == 0 ? 256 : 128;
     const int wgs = cdiv(p.M, 256) * (d->Nc / bnb);
     if (big_on && dtype == TD_BF16 && (pw || tu) && p.d.out_sp == 1 && !p.use_wtap && !p.w_ld && d->Nc % 128 == 0 && p.K % 64 == 0 && p.K >= 512 && d->ldc % 8 == 0 && !p.sigmoid &&
-        !p.drop_thresh && wgs >= big_min && (double)p.M * d->ldc < 2147483647.0) {
+        !p.drop_thresh && wgs >= big_min && (double)p.M * d->ldc < 2147483000.0 &&  // (rows past M leave through an out-of-range offset: the tensor must end below it)
+        p.K <= 64 * 154 && p.M < (1 << 24)) {  // (the K table's 160 entries; rows decoded with float reciprocals.  Anything larger runs on 128 x 128 tiles)
       if (prof) {
         prof_begin(tu ? TD_PROF_GEMM_256 : TD_PROF_GEMM_256_PW, dtype, 2.0 * p.M * d->Nc * p.K, st, p.M, d->Nc, p.K, d->R, d->stride, d->mode);
         double by = ((double)d->N * d->Hs * d->Ws * d->C + (double)d->Nc * p.K + (double)p.M * d->Nc) * 2.0;
@@ -2818,19 +2238,16 @@ static int conv_gemm_launch(const void* src, const void* wmat, void* out, const 
       static const int tap_inner = [] { const char* e_ = getenv("TD_CONV_TAP_INNER"); return e_ ? atoi(e_) : 1; }();
       p.tap_inner = tu && tap_inner && d->R * d->S > 1;
       dim3 gb(8 * cdiv(cdiv(p.M, 256), 8) * (d->Nc / bnb));
-      static const int phased = [] { const char* e_ = getenv("TD_CONV_BIG_PHASED"); return e_ ? atoi(e_) : 1; }();  // (A/B: 0 = the lock-step main loop)
-      if (bnb == 256 && phased && p.K <= 64 * 156) {
-        if (tu) conv_gemm_big8_kernel<true><<<gb, 512, 0, st>>>(p);
-        else conv_gemm_big8_kernel<false><<<gb, 512, 0, st>>>(p);
-      } else if (bnb == 256) {
-        if (tu) conv_gemm_big_kernel<256, true><<<gb, 512, 0, st>>>(p);
-        else conv_gemm_big_kernel<256, false><<<gb, 512, 0, st>>>(p);
-      } else if (phased && p.K <= 64 * 154 && p.M < (1 << 24)) {
+      static const int persist8 = [] { const char* e_ = getenv("TD_CONV_BIG_PERSIST"); return e_ ? atoi(e_) : 1; }();  // (A/B: 0 = one workgroup per tile)
+      if (bnb == 256) {
+        const dim3 gp(persist8 && n_cu % 8 == 0 ? std::min((unsigned)n_cu, gb.x) : gb.x);
+        if (tu && p.residual) conv_gemm_big8_kernel<true, true><<<gp, 512, 0, st>>>(p);
+        else if (tu) conv_gemm_big8_kernel<true, false><<<gp, 512, 0, st>>>(p);
+        else if (p.residual) conv_gemm_big8_kernel<false, true><<<gp, 512, 0, st>>>(p);
+        else conv_gemm_big8_kernel<false, false><<<gp, 512, 0, st>>>(p);
+      } else {
         if (tu) conv_gemm_big8n_kernel<true><<<gb, 512, 0, st>>>(p);
         else conv_gemm_big8n_kernel<false><<<gb, 512, 0, st>>>(p);
-      } else {
-        if (tu) conv_gemm_big_kernel<128, true><<<gb, 512, 0, st>>>(p);
-        else conv_gemm_big_kernel<128, false><<<gb, 512, 0, st>>>(p);
       }
       if (prof) prof_end(st);
       return check_launch("td_conv_gemm(256-row tiles)");
@@ -3225,32 +2642,4 @@ static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, vo
   }
   if (prof) prof_end(st);
   return TD_OK;
-}
-
-extern "C" int td_pw_chain(const void* x, const void* w1, const float* bias1, const void* residual, void* out1, const void* w2,
-                           const float* bias2, void* out2, int M, int K1, int N1, int N2, int dtype, td_stream_t stream) {
-  TD_REQUIRE(x && w1 && residual && out1 && w2 && out2 && M >= 1, "td_pw_chain: bad arguments");
-  TD_REQUIRE(dtype == TD_BF16 && K1 == 64 && N1 == 256 && (N2 == 64 || N2 == 128), "td_pw_chain: bf16, 64 -> 256 -> 64 | 128 channels only");
-  TD_REQUIRE((double)M * N1 < 2147483647.0, "td_pw_chain: tensor exceeds 2^31 elements");
-  static const int n_cu = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus;
-  }();
-  ChainParams p;
-  p.x = (const char*)x; p.w1 = (const char*)w1; p.b1 = bias1; p.res = (const char*)residual; p.out1 = (char*)out1;
-  p.w2 = (const char*)w2; p.b2 = bias2; p.out2 = (char*)out2; p.M = M;
-  p.x_bytes = (uint32_t)((size_t)M * K1 * 2);
-  const int MT = cdiv(M, 64);
-  hipStream_t st = (hipStream_t)stream;
-  const bool prof = prof_on();
-  if (prof) {
-    prof_begin(TD_PROF_PW_RESIDENT, dtype, 2.0 * M * ((double)N1 * K1 + (double)N2 * N1), st, M, N1, K1, 1, 1, 0);
-    prof_set_bytes(((double)M * (K1 + 2.0 * N1 + N2) + (double)N1 * K1 + (double)N2 * N1) * 2.0);
-  }
-  dim3 grid(std::min(2 * n_cu, MT));
-  if (N2 == 64) pw_chain_kernel<1><<<grid, 256, 0, st>>>(p, MT);
-  else pw_chain_kernel<2><<<grid, 256, 0, st>>>(p, MT);
-  if (prof) prof_end(st);
-  return check_launch("td_pw_chain");
 }

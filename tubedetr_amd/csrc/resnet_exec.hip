@@ -218,20 +218,16 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
                                 std::min(step, N - f0), P.stem.H, P.stem.W, 64, dtype, stream)))
         return rc;
   }
-  // conv3 of a layer1 block + conv1 of the block behind it as ONE launch (td_pw_chain): 64 -> 256 -> 64 (| 128 into layer2)
-  static const int chain_on = [] { const char* e = getenv("TD_PW_CHAIN"); return e ? atoi(e) : 3; }();  // bit 0: inside layer1, bit 1: into layer2
-  bool conv1_done = false;  // this block's conv1 was produced by the previous block's chained launch
   // frozen 64-plane bottlenecks (layer1: stages below first_train_stage are never back-propagated, so none of their inner
   // tensors is needed again) run as ONE launch each (bottleneck.hip).  Measured at 1 000 frames of 88 x 88 (tools/fused_l1_time.py):
   // block 0 (64 input channels + downsample) 2.09 ms fused vs 4.24 ms layer by layer; the 256-channel blocks 3.29 ms (resident-tile
-  // variant) vs 3.72 ms - the layer-by-layer path gets 0.9 ms of that back per block through its conv3 -> conv1 chain (td_pw_chain),
-  // in the network the fully fused layer1 is 0.3 ms per 8-clip step ahead.  TD_L1_FUSED: 0 = never, 1 = block 0 only,
-  // 2 (default) = every frozen 64-plane block.
+  // variant) vs 3.72 ms.  TD_L1_FUSED: 0 = never (exact-fp32 mode and A/B: layer by layer), 1 = block 0 only, 2 (default) = every
+  // frozen 64-plane block.
   static const int l1_fused = [] { const char* e = getenv("TD_L1_FUSED"); return e ? atoi(e) : 2; }();
   for (size_t bi = 0; bi < P.blocks.size(); ++bi) {
     auto& b = P.blocks[bi];
     const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
-    if (l1_fused && (l1_fused >= 2 || cd >= 0) && dtype == TD_BF16 && !conv1_done && (!save || b.stage < first_train_stage) && b.stride == 1 && P.convs[c1].cout == 64 &&
+    if (l1_fused && (l1_fused >= 2 || cd >= 0) && dtype == TD_BF16 && (!save || b.stage < first_train_stage) && b.stride == 1 && P.convs[c1].cout == 64 &&
         P.convs[c3].cout == 256 && ((P.convs[c1].cin == 64 && cd >= 0) || (P.convs[c1].cin == 256 && cd < 0)) &&
         (fg || (double)N * b.out.H * b.out.W * 256 < 2147483647.0)) {
       const int step = fg ? fg->step(frame_elems(b.out)) : N;
@@ -242,27 +238,12 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
           return rc;
       continue;
     }
-    if (!conv1_done && (rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream, fg))) return rc;
-    conv1_done = false;
+    if ((rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream, fg))) return rc;
     if ((rc = run_conv(base, b.h1, b.h2, N, P.convs[c2], w_fwd[c2], bias[c2], nullptr, 1, dtype, stream, fg))) return rc;
     const char* idt = base + b.in.off;
     if (cd >= 0) {
       if ((rc = run_conv(base, b.in, b.idt, N, P.convs[cd], w_fwd[cd], bias[cd], nullptr, 0, dtype, stream, fg))) return rc;
       idt = base + b.idt.off;
-    }
-    if (chain_on && dtype == TD_BF16 && bi + 1 < P.blocks.size()) {
-      auto& nb = P.blocks[bi + 1];
-      const ConvSpec &s3 = P.convs[c3], &s1 = P.convs[nb.conv[0]];
-      const long long rows = (long long)N * b.out.H * b.out.W;
-      const bool fits = s3.cin == 64 && s3.cout == 256 && s1.cin == 256 && s1.k == 1 && s1.stride == 1 && (s1.cout == 64 || (s1.cout == 128 && (chain_on & 2))) &&
-                        (double)rows * 256 < groups.lim_elems && nb.h1.off != b.h2.off && nb.h1.off != b.out.off && nb.h1.off != b.in.off && (cd < 0 || nb.h1.off != b.idt.off);
-      if (fits) {
-        if ((rc = td_pw_chain(base + b.h2.off, w_fwd[c3], bias[c3], idt, base + b.out.off, w_fwd[nb.conv[0]], bias[nb.conv[0]], base + nb.h1.off, (int)rows,
-                              64, 256, s1.cout, dtype, stream)))
-          return rc;
-        conv1_done = true;
-        continue;
-      }
     }
     if ((rc = run_conv(base, b.h2, b.out, N, P.convs[c3], w_fwd[c3], bias[c3], idt, 1, dtype, stream, fg))) return rc;
   }

@@ -344,18 +344,6 @@ def rows_segment_sum(inp: Tensor, idx: Tensor, seg_ptr: Tensor, out: Tensor, out
     return out
 
 
-def pw_chain(x: Tensor, w1: Tensor, b1: Tensor, residual: Tensor, w2: Tensor, b2: Tensor):
-    """out1 = relu(x @ w1^T + b1 + residual), out2 = relu(out1 @ w2^T + b2) in one persistent launch (td_pw_chain: conv3 of a
-    layer1 bottleneck + conv1 of the next).  bf16; x [M,64], w1 [256,64], w2 [64|128, 256]."""
-    M, K1 = x.shape
-    N1, N2 = w1.shape[0], w2.shape[0]
-    out1 = torch.empty((M, N1), dtype=x.dtype, device=x.device)
-    out2 = torch.empty((M, N2), dtype=x.dtype, device=x.device)
-    check(_hip.lib().td_pw_chain(ptr(x), ptr(w1), ptr(b1), ptr(residual), ptr(out1), ptr(w2), ptr(b2), ptr(out2), M, K1, N1, N2, dtype_code(x.dtype), stream_ptr()),
-          "td_pw_chain")
-    return out1, out2
-
-
 def linear_wgrad(g: Tensor, x: Tensor, *, out: Optional[Tensor] = None, splits: int = 0, dbias: Optional[Tensor] = None) -> Tensor:
     """dW [N,K] fp32 (+)= g^T @ x   with g [M,N], x [M,K]; optionally dbias [N] fp32 += column sums of g (same launch)."""
     M, K = x.shape
