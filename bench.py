@@ -37,8 +37,8 @@ Extra legs (rank 0, after the timed region, not part of `value`):
                  roof it sits closer to.  `traffic` / `mfma_util` are NOT measured by this process: they are the
                  rocprofv3 PMC results committed under profiles/ (counters cannot be read from inside the timed process).
                  `roofline` is the family with the largest share of the step, the others follow in `other_mfma_kernels`.
-  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on the host cores on a bounded
-                 sample (a T=`--cpu-frames` clip of the same resolution, fwd+bwd, one warm-up + median of 3 passes) and scaled to T=100.
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference algorithm) timed on the host cores: fwd+bwd of a T=`--cpu-frames` clip of the
+                 same resolution (default 100 = the benchmarked clip, ~18 s per pass), one short warm-up + median of 3 passes.
 """
 from __future__ import annotations
 
@@ -67,8 +67,8 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 # algorithmic TFLOP per clip fwd+bwd
 ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
 DEFAULT_CLIPS_PER_GPU = 16
-PMC_TRAFFIC = "r04_pmc_traffic.json"
-PMC_MFMA = "r04_pmc_mfma.json"
+PMC_TRAFFIC = "r05_pmc_traffic.json"
+PMC_MFMA = "r05_pmc_mfma.json"
 
 
 def make_batch(T, res, k, L, seed, device, clips=1, frames="u8"):
@@ -128,8 +128,9 @@ def cpu_model_name() -> str:
 
 
 def cpu_baseline(T_sample, res, k, L, T_full):
-    """Reference algorithm on the host cores (oracle port), fwd+bwd of a T_sample-frame clip: one warm-up pass, then the
-    median of THREE measured passes (always three: the sample is sized so that they fit the budget), scaled to T_full frames."""
+    """Reference algorithm on the host cores (oracle port), fwd+bwd of a T_sample-frame clip: one warm-up pass on a SHORT clip (thread
+    pool, allocator), then the median of THREE measured passes.  Default T_sample = T_full (100): a measured pass of the benchmarked
+    clip, nothing scaled; a shorter sample is scaled and labelled so."""
     from oracle.tubedetr_oracle import OracleConfig, train_step
     from oracle.weights import fill_state, state_spec, synthetic_batch
 
@@ -137,9 +138,9 @@ def cpu_baseline(T_sample, res, k, L, T_full):
     torch.set_num_threads(cores)
     cfg = OracleConfig(stride=k)
     sd = fill_state(state_spec(cfg), 1, requires_grad=True)
-    batch = synthetic_batch(T=T_sample, res=res, k=k, L=L, seed=5)
     times = []
-    for it in range(4):  # pass 0 = warm-up (allocator, thread pool), passes 1-3 are measured
+    for it in range(4):  # pass 0 = warm-up on 2 k frames, passes 1-3 are measured
+        batch = synthetic_batch(T=(2 * k if it == 0 else T_sample), res=res, k=k, L=L, seed=5)
         for v in sd.values():
             v.grad = None
         t0 = time.time()
@@ -151,10 +152,13 @@ def cpu_baseline(T_sample, res, k, L, T_full):
     times.sort()
     med = times[len(times) // 2]
     per_clip = med * (T_full / T_sample)
+    scaled = T_sample != T_full
     return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": cores, "cpu": cpu_model_name(), "host_logical_cpus": os.cpu_count(),
-            "kind": "port", "kind_detail": f"port, scaled from T={T_sample} to T={T_full} (not a measured T={T_full} pass)",
+            "kind": "port", "kind_detail": (f"port, scaled from T={T_sample} to T={T_full} (not a measured T={T_full} pass)" if scaled else
+                                            f"port, measured passes of the T={T_full} clip (nothing scaled)"),
             "sample": f"fwd+bwd of a T={T_sample} clip (k={k}, res={res}, L={L}) by the CPU oracle, median {med:.1f}s of {len(times)} passes "
-                      f"({', '.join(f'{t_:.1f}' for t_ in times)}) after one warm-up pass, scaled x{T_full}/{T_sample} to T={T_full}"}
+                      f"({', '.join(f'{t_:.1f}' for t_ in times)}) after one warm-up pass on a {2 * k}-frame clip"
+                      + (f", scaled x{T_full}/{T_sample} to T={T_full}" if scaled else "")}
 
 
 def launcher_argv(n_gpus, bench_args, port):
@@ -213,7 +217,7 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=DEFAULT_CLIPS_PER_GPU, help="videos per GPU per step (the reference's --batch_size, main.py:63)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--roofline-steps", type=int, default=1)
-    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU-baseline sample clip (0 = skip); 32 frames: ~6 s per pass, 4 passes")
+    ap.add_argument("--cpu-frames", type=int, default=100, help="frames of the CPU-baseline sample clip (0 = skip); 100 = the benchmarked clip itself: ~18 s per pass, 3 passes")
     ap.add_argument("--keep-prepared-weights", action="store_true", help="diagnostic: reuse prepared bf16 weights across steps")
     ap.add_argument("--dedupe", action="store_true",
                     help="do not recompute the slow frames inside the fast pass (exact, slow = video[::k]); off by default so the timed step "
@@ -525,15 +529,16 @@ def main():
                 eager_step(a.warmup + a.steps + i)  # event-timed launches are issued eagerly (not from the graph)
             torch.cuda.synchronize()
             code = _hip.TD_BF16 if cdt == torch.bfloat16 else _hip.TD_F32
-            tname = "unsigned short" if cdt == torch.bfloat16 else "float"
             peak = PEAK_BF16_TFLOPS if cdt == torch.bfloat16 else 157.3
-            fams = {0: f"td::conv_gemm_kernel<{tname}, 128, 128, *, *>", 3: f"td::conv_gemm_kernel<{tname}, 64, 128, *, *>",
-                    1: f"td::conv_gemm_kernel<{tname}, 128, 64, *, *>", 2: "td::conv_wgrad_*batch_kernel", 4: "td::pw_resident_kernel<*>",
-                    5: "td::conv_gemm_big_kernel<*, true>", 6: "td::conv_gemm_big_kernel<*, false>",
-                    7: "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>", 8: "td::cross_q1_*_kernel", 9: "td::conv_wgrad_kernel<unsigned short>"}
-            # * = all pipeline depths, pointwise and generic instances; 2 = wide-tile + 128x128 batched weight-gradient launches; 5 / 6 = the 256-row
-            # tile kernel on spatial (MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers; 7 = the LDS-resident fused stem / layer1 blocks;
-            # 8 = the decoder's time-aligned cross-attention frame core (fp32 VALU arithmetic: its FLOPs are not MFMA FLOPs, bound = HBM)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from kernel_families import FAMILY_OF_PROF_ID, prof_key
+
+            fams = {fam: prof_key(fam, fp32=cdt != torch.bfloat16) for fam in FAMILY_OF_PROF_ID}
+            # family keys = the name stems of the kernels that form them (tools/kernel_families.py, shared with the PMC aggregation): 0 / 1 / 3 the
+            # 128x128 / 128x64 / 64x128 tile instances (all pipeline depths, pointwise / tap-uniform / two-source); 2 wide-tile + 128x128 batched weight
+            # gradients; 4 the persistent 1x1; 5 / 6 the 256-row tile kernels on spatial (MFMA-bound) and on pointwise K >= 512 layers; 7 the LDS-resident
+            # fused stem / layer1 blocks; 8 the decoder's time-aligned cross-attention core (bf16: MFMA tiles, a few MFMAs per kilobyte of memory rows -
+            # bound = HBM); 9 the per-layer weight gradients.  `kernel` in the JSON = the exact kernel names of the family in the committed PMC pass.
             pmc, mfma = _load_profile_json(PMC_TRAFFIC), _load_profile_json(PMC_MFMA)
             # an (event, event) pair around nothing: what the bracketing itself adds to every launch (reported, NOT subtracted)
             cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
@@ -568,7 +573,8 @@ def main():
                     mu = mfma.get(kname, {}).get("mfma_util") if isinstance(mfma.get(kname), dict) else None
                     if mu is not None and traffic is None and traffic_why and traffic_why.startswith("stale"):
                         mu = None  # the same passes: stale with the traffic figure
-                    rec = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
+                    exact = (t_ or {}).get("kernels") or (mfma.get(kname, {}).get("kernels") if isinstance(mfma.get(kname), dict) else None)
+                    rec = {"bound": "hbm" if hbm_bound else "mfma", "kernel": " + ".join(exact) if exact else kname, "family": kname,
                            "achieved": round(gbs if hbm_bound else tfl, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tfl / peak), 4),
                            "traffic": traffic, "traffic_null_reason": traffic_why,

@@ -425,3 +425,36 @@ def test_bench_batch_bf16_step_follows_fp32_per_clip(n_clips):  # frames still s
     bad = [(s_[0], s_[1], s_[2], s_[4]) for s_ in stats if (s_[1] < 0.97 or abs(s_[2]) > 0.15) and s_[4] > 0.25 * med]
     bad += [(s_[0], s_[1], s_[2], s_[4]) for s_ in stats if s_[4] <= 0.25 * med and s_[3] * s_[4] > 0.05 * med]
     assert not bad, bad[:10]
+
+
+def test_deterministic_mode_fp32_step_is_bit_reproducible_at_the_headline_size():
+    """TD_DETERMINISTIC=1: forward + criterion + backward of the exact-fp32 mode at cfg3 (T=100, k=4, res=352, L=30), twice: every loss
+    and every parameter gradient bit-identical between the two runs (weight gradients reduced by one workgroup per output tile instead
+    of fp32 atomics between row splits; LayerNorm / bias gradients by one workgroup per column block)."""
+    import tubedetr_amd
+    from tubedetr_amd.functional import invalidate_prepared
+    from tubedetr_amd.harness import batch_to, forward_step
+
+    c = FULL["cfg3"]
+    cfg, sd, batch = _inputs(c)
+    model, criterion, weight_dict, Tok = _model(cfg, sd, torch.float32)
+    model.transformer.tokenizer = Tok(batch["input_ids"], batch["attention_mask"])
+    b = batch_to(batch, torch.device("cuda:0"))
+    params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    runs = []
+    tubedetr_amd.set_deterministic(True)
+    try:
+        for _ in range(2):
+            for _, p in params:
+                p.grad = None
+            invalidate_prepared()
+            loss, ld, _, _ = forward_step(model, criterion, weight_dict, b)
+            loss.backward()
+            torch.cuda.synchronize()
+            runs.append((loss.item(), {k: v.item() for k, v in ld.items()}, {n: p.grad.detach().clone() for n, p in params if p.grad is not None}))
+    finally:
+        tubedetr_amd.set_deterministic(False)
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    assert len(runs[0][2]) > 300 and runs[0][2].keys() == runs[1][2].keys()
+    differing = [n for n in runs[0][2] if not torch.equal(runs[0][2][n], runs[1][2][n])]
+    assert not differing, differing[:8]

@@ -128,3 +128,28 @@ def test_ten_step_training_trajectory_fp32_vs_oracle_and_bf16_band():
     for i, (a, b) in enumerate(zip(l16, l32)):
         assert abs(a - b) <= 0.10 * abs(b), (i, a, b)
     assert l16[-1] < 0.5 * l16[0]
+
+
+def test_deterministic_mode_makes_the_fp32_trajectory_bit_reproducible():
+    """TD_DETERMINISTIC=1 (tubedetr_amd.set_deterministic): two runs of the same ten optimizer steps in the exact-fp32 mode give
+    IDENTICAL losses, weights and EMA copies, bit for bit - the regression anchor a parity mode needs (without it the weight
+    gradients, LayerNorm's dgamma / dbeta and the bias gradients are combined with fp32 atomics in arrival order and two runs
+    differ at rounding level, which AdamW's sign-like first steps turn into 0.1 - 2 % of the loss by step ten)."""
+    import tubedetr_amd
+    from oracle.tubedetr_oracle import OracleConfig
+    from oracle.weights import fill_state, state_spec, synthetic_batch
+
+    cfg = OracleConfig(stride=2)
+    batch = synthetic_batch(T=6, res=64, k=2, L=5, seed=3)
+    sd0 = fill_state(state_spec(cfg), 11)
+    tubedetr_amd.set_deterministic(True)
+    try:
+        la, wa, ea = _hip_run(cfg, sd0, batch, torch.float32)
+        lb, wb, eb = _hip_run(cfg, sd0, batch, torch.float32)
+    finally:
+        tubedetr_amd.set_deterministic(False)
+    assert la == lb, (la, lb)
+    assert la[-1] < 0.5 * la[0]
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+        assert torch.equal(ea[k], eb[k]), k

@@ -21,26 +21,9 @@ import re
 import sys
 
 
-def family(name):
-    m = re.search(r"td::conv_gemm_kernel<([^,]+), (\d+), (\d+), (\d+), (true|false)", name)
-    if m:
-        return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, *, *>"
-    if "td::pw_resident_kernel" in name or "td::pw_resident2_kernel" in name:
-        return "td::pw_resident_kernel<*>"
-    m = re.search(r"td::conv_gemm_big(?:8n?)?_kernel<(?:\d+, )?(true|false)>", name)  # lock-step and phased (256 x 256, 256 x 128) instances: one family
-    if m:  # the 256-row tile kernel on spatial (3x3, MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers
-        return f"td::conv_gemm_big_kernel<*, {m.group(1)}>"
-    if "td::stem_pool_kernel" in name or re.search(r"td::bottleneck_(fused|resident|resident3|first3)_kernel", name):
-        return "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>"
-    if "td::cross_q1_" in name:
-        return "td::cross_q1_*_kernel"
-    if "td::conv_wgrad_wide_batch_kernel" in name or "td::conv_wgrad_batch_kernel" in name:
-        return "td::conv_wgrad_*batch_kernel"
-    m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)
-    if m:
-        return f"td::{m.group(1)}<{m.group(2)}>"
-    m = re.search(r"(?<![a-z_])(td::[a-z0-9_]+)", name)
-    return m.group(1) if m else None
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from kernel_families import family  # noqa: E402  (one definition shared with bench.py)
 
 
 def agg(src, dst):
@@ -83,12 +66,13 @@ def agg(src, dst):
 
 
 def mfma(src, dst, command=""):
-    per = {}
+    per, names = {}, {}
     for r in csv.DictReader(open(src)):
         f = family(r["kernel"])
         if f is None:
             continue
         d = per.setdefault(f, {})
+        names.setdefault(f, set()).add(r["kernel"])
         a = d.setdefault(r["counter"], [0, 0.0, 0])
         a[0] += int(r["dispatches"])
         a[1] += float(r["sum"])
@@ -117,6 +101,7 @@ def mfma(src, dst, command=""):
     for f in sorted(per):
         u = util([f])
         if u:
+            u["kernels"] = sorted(names.get(f, []))
             res[f] = u
     # north_star: ">= 40 % MFMA utilisation on the space-time decoder attention (incl. its K/V projections)".  The attention
     # kernels are separable by name; the K/V projections run on the shared GEMM kernel, so the group is reported as the

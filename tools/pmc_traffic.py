@@ -7,26 +7,12 @@ usage: python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE.csv gpurun_out/pmc_
 import csv, json, re, sys
 
 
-def family(name):
-    m = re.search(r"td::conv_gemm_kernel<([^,]+), (\d+), (\d+), (\d+), (true|false)", name)
-    if m:
-        return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, *, *>"  # stages and pointwise flag merged
-    if "td::pw_resident_kernel" in name or "td::pw_resident2_kernel" in name:
-        return "td::pw_resident_kernel<*>"
-    m = re.search(r"td::conv_gemm_big(?:8n?)?_kernel<(?:\d+, )?(true|false)>", name)  # lock-step and phased (256 x 256, 256 x 128) instances: one family
-    if m:  # the 256-row tile kernel on spatial (3x3, MFMA-bound) and on pointwise K >= 512 (HBM-bound) layers
-        return f"td::conv_gemm_big_kernel<*, {m.group(1)}>"
-    if "td::stem_pool_kernel" in name or re.search(r"td::bottleneck_(fused|resident|resident3|first3)_kernel", name):
-        return "td::stem_pool_kernel<*> + td::bottleneck_fused_kernel<*>"
-    if "td::cross_q1_" in name:
-        return "td::cross_q1_*_kernel"
-    if "td::conv_wgrad_wide_batch_kernel" in name or "td::conv_wgrad_batch_kernel" in name:
-        return "td::conv_wgrad_*batch_kernel"
-    m = re.search(r"td::(conv_wgrad(?:_batch)?_kernel)<([^,>]+)", name)
-    if m:
-        return f"td::{m.group(1)}<{m.group(2)}>"
-    m = re.search(r"(?<![a-z_])(td::[a-z0-9_]+)", name)
-    return m.group(1) if m else None
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from kernel_families import family  # noqa: E402  (one definition shared with bench.py)
+
+
+NAMES = {}  # family -> exact kernel names seen (as rocprofv3 prints them: the names of the committed kernel-stats CSV)
 
 
 def load(path):
@@ -38,6 +24,7 @@ def load(path):
         a = out.setdefault(f, [0, 0.0])
         a[0] += int(r["dispatches"])
         a[1] += float(r["sum"])
+        NAMES.setdefault(f, set()).add(r["kernel"])
     return out
 
 
@@ -51,7 +38,7 @@ def main():
     for f in sorted(set(F) | set(W)):
         nf, sf = F.get(f, [0, 0.0])
         nw, sw = W.get(f, [0, 0.0])
-        res[f] = {"dispatches": nf or nw,
+        res[f] = {"kernels": sorted(NAMES.get(f, [])), "dispatches": nf or nw,
                   "fetch_bytes_per_launch": round(sf * 1024 * 2 / nf) if nf else None,
                   "write_bytes_per_launch": round(sw * 1024 / nw) if nw else None}
     json.dump(res, open(dst, "w"), indent=1)

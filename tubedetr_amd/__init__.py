@@ -1,11 +1,26 @@
 """tubedetr_amd - MI355X-native (gfx950) engine for TubeDETR's video-text encoder + space-time decoder hot path.
 
 Drop-in for the reference's ``models`` package: ``tubedetr_amd.models.build_model(args)``.  See DESIGN.md."""
+import os
 from argparse import Namespace
 
 import torch
 
-__all__ = ["default_args", "models"]
+__all__ = ["default_args", "models", "set_deterministic"]
+
+
+def set_deterministic(on: bool = True) -> None:
+    """Run-to-run bit-reproducible steps (the exact-fp32 parity mode's regression anchor; also settable as TD_DETERMINISTIC=1 in the
+    environment).  The library's reductions that are normally split over workgroups and combined with fp32 atomics - weight gradients
+    over the rows, LayerNorm's dgamma / dbeta, bias column sums - run as one sequential reduction per output element (the C side reads
+    the variable at every call), and torch's own index / embedding backward kernels are switched to their deterministic forms.  Slow:
+    a 12 100-row weight gradient is then reduced by one workgroup per 128 x 128 tile."""
+    os.environ["TD_DETERMINISTIC"] = "1" if on else "0"
+    torch.use_deterministic_algorithms(bool(on), warn_only=True)
+
+
+if os.environ.get("TD_DETERMINISTIC") == "1":
+    set_deterministic(True)
 
 
 def default_args(**overrides) -> Namespace:

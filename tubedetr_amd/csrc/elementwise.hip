@@ -563,11 +563,13 @@ extern "C" int td_add_layernorm_bwd(const void* dy, const void* s, const float* 
     // ~8 rows per wavefront, at most 1024 workgroups (each ends with 2 * cols atomics)
     unsigned gv = (rows + 31) / 32;
     if (gv > 1024) gv = 1024;
+    if (deterministic()) gv = 1;  // one workgroup: dgamma / dbeta get ONE atomic per column (into the caller's zeros), in a fixed order
     if (cols == 256) add_layernorm_bwd_v4_kernel<1><<<gv, 256, 0, st>>>((const u16*)dy, (const u16*)s, mean, rstd, gamma, (const u16*)extra, (u16*)ds, dgamma, dbeta, rows);
     else add_layernorm_bwd_v4_kernel<3><<<gv, 256, 0, st>>>((const u16*)dy, (const u16*)s, mean, rstd, gamma, (const u16*)extra, (u16*)ds, dgamma, dbeta, rows);
     return check_launch("td_add_layernorm_bwd");
   }
   if (g > 256) g = 256;
+  if (deterministic()) g = 1;
   TD_DISPATCH(dtype,
               (add_layernorm_bwd_kernel<u16><<<g, 256, 0, st>>>((const u16*)dy, (const u16*)s, mean, rstd, gamma, (const u16*)extra, (u16*)ds, dgamma, dbeta, rows, cols)),
               (add_layernorm_bwd_kernel<float><<<g, 256, 0, st>>>((const float*)dy, (const float*)s, mean, rstd, gamma, (const float*)extra, (float*)ds, dgamma, dbeta, rows, cols)),
@@ -584,6 +586,7 @@ extern "C" int td_colsum(const void* g, float* out, int rows, int cols, int ld, 
     const int gx = (cols + 32 * vec - 1) / (32 * vec);
     int rpb = (int)(((long long)rows * gx + 511) / 512);  // ~512 workgroups
     if (rpb < 64) rpb = 64;
+    if (deterministic()) rpb = rows;  // one workgroup per column block
     dim3 grid(gx, (rows + rpb - 1) / rpb);
     TD_DISPATCH(dtype, (colsum_vec_kernel<u16><<<grid, 256, 0, st>>>((const u16*)g, out, rows, cols, ld, rpb)),
                 (colsum_vec_kernel<float><<<grid, 256, 0, st>>>((const float*)g, out, rows, cols, ld, rpb)), "td_colsum");
@@ -592,6 +595,7 @@ extern "C" int td_colsum(const void* g, float* out, int rows, int cols, int ld, 
   // enough row chunks to fill the chip: ~1024 workgroups, at least 8 rows each
   int rpb = (int)(((long long)rows * ((cols + 255) / 256) + 1023) / 1024);
   if (rpb < 8) rpb = 8;
+  if (deterministic()) rpb = rows;
   dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
   TD_DISPATCH(dtype, (colsum_kernel<u16><<<grid, 256, 0, st>>>((const u16*)g, out, rows, cols, ld, rpb)),
               (colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)g, out, rows, cols, ld, rpb)), "td_colsum");

@@ -2430,6 +2430,7 @@ static int wgrad_fill(WgradParams& p, const void* g, const void* src, const td_c
     }
     if (splits < 1) splits = 1;
   }
+  if (deterministic()) splits = 1;  // one workgroup per output tile walks the whole reduction: no atomics between splits, a fixed summation order
   p.mper = cdiv(cdiv(p.M, splits), mk) * mk;
   *splits_io = cdiv(p.M, p.mper);
   return TD_OK;

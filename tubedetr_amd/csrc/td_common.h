@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/tubedetr_hip.h"
@@ -37,6 +38,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 }
 __device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint32_t* ctr) {
   return ctr ? mix32(mix32(seed ^ 0xA511E9B3u) + ctr[0] * 0xC2B2AE3Du) : seed;
+}
+
+// TD_DETERMINISTIC=1 (read at every call: a test may switch it): reductions that are normally split over workgroups and combined
+// with fp32 atomics - weight gradients over M, LayerNorm's dgamma / dbeta, bias column sums - run as ONE sequential reduction per
+// output element, so that two runs of the same step are bit-identical (the exact-fp32 parity mode's regression anchor; slow).
+inline bool deterministic() {
+  const char* e = getenv("TD_DETERMINISTIC");
+  return e && e[0] == '1';
 }
 
 // bench-only launch timing (api.cpp)
