@@ -311,3 +311,33 @@ def test_bench_self_launches_its_ranks():
     if not torch.cuda.is_available():  # no device here: the launched ranks must explain themselves and the exit code must propagate
         r = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode != 0 and "needs 2 GPUs on this node" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_rehearsal_flags_reach_the_ranks_and_fail_cleanly_without_a_device():
+    """--oversubscribe / --backend gloo (the one-GPU rehearsal of BASELINE config 4's entry point, tests/test_distributed_gpu.py) are
+    ordinary flags: the self-launcher hands them to the ranks; with NO device at all the ranks still say what is missing; RCCL with
+    more ranks than devices is refused before any process group exists."""
+    import subprocess
+    import sys
+
+    import bench
+
+    argv = bench.launcher_argv(2, ["--gpus", "2", "--oversubscribe", "--backend", "gloo", "--dump-grads", "/tmp/x.pt"], 29778)
+    i = argv.index(os.path.abspath(bench.__file__))
+    assert argv[i + 1:] == ["--gpus", "2", "--oversubscribe", "--backend", "gloo", "--dump-grads", "/tmp/x.pt"]
+    if not torch.cuda.is_available():
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--oversubscribe", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "has no device" in r.stderr and r.stdout.strip() == ""
+
+
+def test_set_deterministic_switches_the_library_and_torch():
+    import tubedetr_amd
+
+    try:
+        tubedetr_amd.set_deterministic(True)
+        assert os.environ["TD_DETERMINISTIC"] == "1" and torch.are_deterministic_algorithms_enabled()
+    finally:
+        tubedetr_amd.set_deterministic(False)
+    assert os.environ["TD_DETERMINISTIC"] == "0" and not torch.are_deterministic_algorithms_enabled()
