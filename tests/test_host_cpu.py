@@ -159,3 +159,37 @@ def test_cross_attention_projections_commute_to_the_query_side():
     out = ctx @ mha.out_proj.weight.detach().t() + mha.out_proj.bias.detach()
     assert torch.allclose(out, ref[0].detach(), atol=1e-10)
     assert torch.allclose(p.mean(1), ref_w[:, 0].detach(), atol=1e-12)
+
+
+def test_roofline_families_are_named_by_kernels_of_the_committed_profile():
+    """Every kernel family bench.py reports (tools/kernel_families.py, shared with the PMC aggregation) is made of kernels that occur in the
+    committed kernel-stats CSV of the round, and every name stem in a family's key is a substring of such a kernel name - the bench line
+    cannot name a kernel that is no longer launched.  The PMC JSONs bench.py reads carry the exact names per family."""
+    import csv
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    sys.path.insert(0, root)
+    from kernel_families import FAMILY_OF_PROF_ID, family
+
+    import bench
+
+    tag = bench.PMC_TRAFFIC.split("_")[0]
+    names = [r["Name"] for r in csv.DictReader(open(os.path.join(root, "profiles", f"{tag}_bench_cfg3x16_kernel_stats.csv")))]
+    by_family = {}
+    for n in names:
+        by_family.setdefault(family(n), []).append(n)
+    for fam_id, key in FAMILY_OF_PROF_ID.items():
+        assert by_family.get(key), f"family {fam_id} ({key}): no kernel of the committed profile belongs to it"
+        for stem in key.split(" + "):
+            stem = stem.split("<")[0]
+            assert any(stem in n for n in by_family[key]), (key, stem)
+    traffic = json.load(open(os.path.join(root, "profiles", bench.PMC_TRAFFIC)))
+    mfma = json.load(open(os.path.join(root, "profiles", bench.PMC_MFMA)))
+    for fam_id, key in FAMILY_OF_PROF_ID.items():
+        for src in (traffic, mfma):
+            assert key in src and src[key]["kernels"], (key, "missing from the PMC aggregate")
+            assert all(k in names for k in src[key]["kernels"]), key  # exact names of the kernel-stats CSV
