@@ -29,7 +29,7 @@ timeout 900 python bench.py --steps 20 --warmup 5 > $O/${tag}_bench_cfg3x16.json
 kill $SMI 2>/dev/null
 V="--steps 10 --warmup 3 --cpu-frames 0 --roofline-steps 0"
 timeout 600 python bench.py $V > $O/${tag}_bench_variant_default.json 2>/dev/null
-TD_HIP_LIB=$R/tubedetr_amd/lib/libtubedetr_hip_r4.so timeout 600 python bench.py $V > $O/${tag}_bench_variant_round4_gemm_kernels.json 2>/dev/null
+[ -f $R/tubedetr_amd/lib/libtubedetr_hip_r4.so ] && TD_HIP_LIB=$R/tubedetr_amd/lib/libtubedetr_hip_r4.so timeout 600 python bench.py $V > $O/${tag}_bench_variant_round4_gemm_kernels.json 2>/dev/null  # (tools/build_round4_gemm_variant.sh builds it)
 TD_CONV_BIG_PERSIST=0 timeout 600 python bench.py $V > $O/${tag}_bench_variant_big8_one_tile_per_workgroup.json 2>/dev/null
 timeout 600 python bench.py $V --clips-per-gpu 1 > $O/${tag}_bench_variant_b1.json 2>/dev/null
 timeout 600 python bench.py $V --clips-per-gpu 8 > $O/${tag}_bench_variant_b8.json 2>/dev/null
