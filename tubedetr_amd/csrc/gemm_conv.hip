@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || NST == 3) ? 2 : 3) vo
 // behind the next barrier).  Tiles past the end of K are issued with out-of-range offsets (zero fill, no traffic) so that the
 // counts are the same in every iteration.
 #ifndef TD_ABL
-#define TD_ABL 0  // timing ablations of conv_gemm_big8_kernel (tools/build_variant.sh; results are WRONG with any bit set): 1 (was: no K walk), 2 no DMA, 4 no fragment reads, 8 no s_setprio
+#define TD_ABL 0  // timing ablations of conv_gemm_big8_kernel (tools/build_variant.sh; results are WRONG with any bit set): 1 (was: no K walk), 2 no DMA, 4 no fragment reads, 8 no s_setprio, 16 stage buffers pre-filled with pseudo-random values (with 2: MFMAs on toggling operands without any L2 -> LDS traffic), 32 activation pieces of taps 1.. out of range
 #endif
 template <int OFF>
 __device__ __forceinline__ u32x4_t lds_read16(uint32_t addr) {
@@ -626,6 +626,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int I>
 using ic = std::integral_constant<int, I>;
 
+#ifndef TD_BIG8_AUX_W
+#define TD_BIG8_AUX_W 0  // cache-policy bits of the weight / activation LDS-DMA loads of conv_gemm_big8_kernel (A/B builds: 2 = nt)
+#endif
+#ifndef TD_BIG8_AUX_X
+#define TD_BIG8_AUX_X 0
+#endif
 template <bool TU, bool RES>  // RES: a residual operand in the epilogue (rare on this instance - the K = 512 expansions of layer4 -: its own instantiation keeps the loads out of everybody else's epilogue)
 __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
   using T = u16;
@@ -685,6 +691,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
   // 2-KiB bf16 staging region (bias / ReLU / rounding applied in the MFMA layout, 8-byte writes, 16-byte reads, both bank-conflict
   // free under the chunk ^ row swizzle; DS operations of a wavefront execute in order, so no wait separates a chunk's reads from
   // the next chunk's writes), and the twelve pieces of the NEXT tile's prologue are issued BEFORE the epilogue starts.
+#if TD_ABL & 16  // (with 2: no LDS-DMA, but the stage buffers hold pseudo-random bf16 values around 1.0 - the matrix pipes then toggle as on real data)
+  for (int i = t; i < 2 * STAGE / 4; i += 512) ((uint32_t*)smem)[i] = 0x3F803F80u ^ (mix32((uint32_t)i * 0x9E3779B1u + blockIdx.x) & 0x007F007Fu);
+#endif
   const int nvb = 8 * ((cdiv(p.M, BM) + 7) / 8) * NT;
   const float rcp_howo = 1.f / (float)HoWo, rcp_wo = 1.f / (float)d.Wo;
   auto divmod = [](int a, int dv, float rcp, int& q, int& r) {
@@ -743,14 +752,17 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
   // one activation piece (quarter q) / one weight piece (i) of the tile described by table entry e into `stage`; branch-free: an
   // out-of-image tap, a row past M or a tile past K becomes the out-of-range offset through an all-ones / all-zeros mask
   auto issue_x = [&](char* stage, int q, const u32x4_t& e) {
-    const uint32_t ok = (0u - ((a_mask[q] >> (e.y & 31)) & 1u)) & e.w;
+    uint32_t ok = (0u - ((a_mask[q] >> (e.y & 31)) & 1u)) & e.w;
+#if TD_ABL & 32  // (timing only) activation rows fetched for tap 0 of every channel chunk only, the other taps' pieces are out-of-range (zero fill, no L2 traffic): what staging a chunk's rows ONCE for all nine taps could save at most
+    ok &= e.y == 0 ? 0xFFFFFFFFu : 0u;
+#endif
     uint32_t off = a_off[q] + e.x;  // a_off (TU) = byte offset of tap (0, 0) of the row (mod 2^32: may be "negative")
     off = (off & ok) | (OOB & ~ok);
 #if TD_ABL & 2
     asm volatile("" ::"v"(off));
     return;
 #endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stage + ((wave >> 2) * WM + q * 32 + (wave & 3) * 8) * 128), 16, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(stage + ((wave >> 2) * WM + q * 32 + (wave & 3) * 8) * 128), 16, off, 0, 0, TD_BIG8_AUX_X);
   };
   auto issue_w = [&](char* stage, int i, const u32x4_t& e) {
     const uint32_t off = ((b_off[i] + e.z) & e.w) | (OOB & ~e.w);
@@ -758,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
     asm volatile("" ::"v"(off));
     return;
 #endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(stage + WREG + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(stage + WREG + (i * NW + wave) * 1024), 16, off, 0, 0, TD_BIG8_AUX_W);
   };
 
   const int lr = lane & 15, lg = lane >> 4;
