@@ -997,318 +997,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv_gemm_big8_kernel for the 3x3 / stride 1 / pad 1 layers, with the activation rows of a channel chunk staged ONCE for all nine
-// taps (round 5).  Why: at the package power cap a quarter of conv_gemm_big8_kernel's time is what its LDS-DMA traffic costs, mostly in
-// clock (profiles/r05_big8_ablation_power.log: same MFMA + fragment-read stream on standing random operands, no L2 -> LDS traffic:
-// 271 instead of 365 us, 2.30 instead of 1.93 GHz at the same 1 400 W), and half of those bytes are the activation rows, fetched
-// once per tap: in tap-inner order the nine K tiles of a 64-channel chunk read the SAME pixels, shifted.  Here a chunk's pixels
-// are staged once, in PADDED coordinates:
-//     L(img, y, x) = img (H + 1)(W + 1) + y (W + 1) + x           (one zero slot behind every image row, one zero row behind every image)
-// so that tap (dy, dx) of output pixel L reads slot L + dy (W + 1) + dx - and every out-of-image tap lands on a zero slot by
-// construction (x + dx = -1 is the zero slot of the row above, = W this row's, y + dy = -1 / H a zero row).  The zero slots cost
-// nothing: the DMA lane that would fill one passes an out-of-range offset (zero fill).  A tile's 256 consecutive output pixels span at
-// most 352 slots incl. the halo (host check); the block of chunk c + 1 (44 KiB, six 1-KiB pieces per wavefront) is requested during
-// chunk c, one piece in phase 1 of its tiles 1 .. 6, into the other of two buffers.  Fragment reads address slot P + shift(tap):
-// five VALU operations per M fragment and K tile (the 16-byte chunk swizzle depends on the slot's low bits), no validity masks.
-// Weights: two 32-KiB stages, staged two tiles ahead in phases 2 / 3 exactly as in conv_gemm_big8_kernel; a load section's only
-// counted wait is vmcnt(4) at the end of phase 3 - loads retire in order, so the four youngest (the weights of tile kt + 2) may be in
-// flight and everything older - the weights of tile kt + 1, any activation piece - has landed.  The K walk needs no table: the tap is
-// a compile-time constant of the unrolled body (two chunks = 18 tiles = 72 phases), the chunk a loop counter.
-// Same wave-group skew, barriers, MFMA clusters, persistent tile walk and epilogue as conv_gemm_big8_kernel; same accumulation order:
-// bit-identical results.  LDS: 2 x 44 + 2 x 32 KiB = 152 KiB (the epilogue's staging is the head of the second activation buffer).
-template <bool RES>
-__global__ __launch_bounds__(512, 1) void conv_gemm_big8h_kernel(GemmParams p) {
-  using T = u16;
-  constexpr int ES = 2, BM = 256, BN = 256, BK = 64, NW = 8, VEC = 8;
-  constexpr int WM = 128, WN = 64, TM = 8, TN = 4;
-  constexpr int AROWS = 352, ABYTES = AROWS * 128, NPIECE = AROWS / 8, NPC = 6;  // slots per chunk buffer; 1-KiB pieces; pieces per wavefront (44 of 48 distinct)
-  constexpr int WBYTES = BN * 128;                                                 // one K tile of weights
-  // LDS map: [weights stage 0][weights stage 1][activation buffer 0][activation buffer 1].  The offset field of a DS instruction holds 16
-  // bits: the weight reads reach their stage through it, the activation reads carry their buffer's offset inside the slot arithmetic
-  // (a multiple of 1 KiB >> 3 leaves the slot's low bits alone)
-  constexpr int WOFF0 = 0, WOFF1 = WBYTES, AOFF0 = 2 * WBYTES, AOFF1 = 2 * WBYTES + ABYTES;
-  static_assert(AOFF0 % 1024 == 0 && AOFF1 % 1024 == 0 && WOFF1 + 3 * 2048 < 65536, "LDS map");
-  constexpr uint32_t OOB = 0xFFFFFFF0u;
-  constexpr int STG = 16 * WN * ES;
-  __shared__ __attribute__((aligned(16))) char smem[2 * ABYTES + 2 * WBYTES];
-
-  const td_conv_desc& d = p.d;
-  const int t = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-  const int NT = d.Nc / BN;
-  const int lrow = lane >> 3;
-  const int lane_c = ((lane & 7) ^ lrow) * VEC;  // (DMA destinations are lane-linear: the chunk swizzle is applied on the SOURCE side; a piece starts at a multiple of 8 slots)
-  const int H = d.Hs, W = d.Ws, C = d.C, W1 = W + 1, IP = (H + 1) * W1, HW = H * W;
-  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-  const uint32_t out_bytes = (uint32_t)p.M * (uint32_t)d.ldc * ES;  // (host: M * ldc < 2^31)
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, out_bytes, 0x00020000);
-  const int wy = wave >> 2, wx = wave & 3;  // wy is also the wavefront's group
-  const int nchunk = C / BK;                // (host: even)
-  const int sgn = d.mode == 0 ? 1 : -1;     // forward: tap (r, s) reads pixel (y + r - 1, x + s - 1); input gradient: (y + 1 - r, x + 1 - s)
-  const int nvb = 8 * ((cdiv(p.M, BM) + 7) / 8) * NT;
-  const float rcp_hw = 1.f / (float)HW, rcp_w = 1.f / (float)W, rcp_ip = 1.f / (float)IP, rcp_w1 = 1.f / (float)W1;
-  auto divmod = [](int a, int dv, float rcp, int& q, int& r) {  // a >= 0, exact below 2^24 (host)
-    q = (int)((float)a * rcp);
-    r = a - q * dv;
-    const int up = r >= dv, dn = r < 0;
-    q += up - dn;
-    r += (dn - up) * dv;
-  };
-  auto padded_of = [&](int m) {  // output pixel (row of the GEMM) -> its padded slot
-    int img, rem, y, x;
-    divmod(m, HW, rcp_hw, img, rem);
-    divmod(rem, W, rcp_w, y, x);
-    return img * IP + y * W1 + x;
-  };
-  auto tile_m0 = [&](int vb) { const int seq = vb >> 3; return ((seq / NT) * 8 + (vb & 7)) * BM; };
-  auto tile_n0 = [&](int vb) { const int seq = vb >> 3; return (seq - (seq / NT) * NT) * BN; };
-  auto tile_ok = [&](int vb) { return vb < nvb && tile_m0(vb) < p.M; };
-
-  // per tile: source offsets of this wavefront's six activation pieces (piece k covers slots (k * 8 + wave) * 8 .. + 8, the last four
-  // of the 48 repeat their wavefront's previous piece), a validity bit per piece, the padded slot << 4 of the lane's eight fragment
-  // rows, the weight rows' offsets
-  uint32_t a_off[NPC], a_ok = 0, pf4[TM], b_off[4];
-  auto tile_addr = [&](int m0, int n0) {
-    const int Lbase = padded_of(m0) - (W + 2);
-    a_ok = 0;
-#pragma unroll
-    for (int k = 0; k < NPC; ++k) {
-      const int pid = k * NW + wave < NPIECE ? k * NW + wave : (k - 1) * NW + wave;  // (k = 5: pieces 40 .. 43 exist for wavefronts 0 .. 3; 4 .. 7 repeat their piece 32 + wave)
-      const int Lr = Lbase + pid * 8 + lrow;
-      int img, rem, y, x;
-      divmod(max(Lr, 0), IP, rcp_ip, img, rem);
-      divmod(rem, W1, rcp_w1, y, x);
-      const bool ok = Lr >= 0 && img < d.N && y < H && x < W;
-      a_off[k] = (uint32_t)(((img * H + y) * W + x) * C + lane_c) * ES;
-      a_ok |= (ok ? 1u : 0u) << k;
-    }
-#pragma unroll
-    for (int f = 0; f < TM; ++f) {
-      const int m = min(m0 + wy * WM + f * 16 + (lane & 15), p.M - 1);
-      pf4[f] = (uint32_t)(padded_of(m) - Lbase) << 4;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b_off[i] = ((uint32_t)(n0 + (i * NW + wave) * 8 + lrow) * (uint32_t)p.K + (uint32_t)lane_c) * ES;
-  };
-  // piece k of channel chunk c into the activation buffer at byte offset `abase`
-  auto issue_x = [&](int abase, int k, int c) {
-    const int pid = k * NW + wave < NPIECE ? k * NW + wave : (k - 1) * NW + wave;
-    const uint32_t ok = (0u - ((a_ok >> k) & 1u)) & (c < nchunk ? 0xFFFFFFFFu : 0u);
-    const uint32_t off = ((a_off[k] + (uint32_t)c * (BK * ES)) & ok) | (OOB & ~ok);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(smem + abase + pid * 1024), 16, off, 0, 0, 0);
-  };
-  // weight piece i of K tile (tap j, chunk c) into the weight stage at byte offset `wbase`; the K axis of the matrix is [tap][channel]
-  auto issue_w = [&](int wbase, int i, int j, int c) {
-    const uint32_t ok = c < nchunk ? 0xFFFFFFFFu : 0u;
-    const uint32_t off = ((b_off[i] + (uint32_t)(j * C + c * BK) * ES) & ok) | (OOB & ~ok);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(smem + wbase + (i * NW + wave) * 1024), 16, off, 0, 0, 0);
-  };
-
-  const int lr = lane & 15, lg = lane >> 4;
-  f32x4 acc[TN][TM];
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-  const uint32_t lg16 = (uint32_t)lg << 4;
-  const uint32_t wa0 = lds0 + (uint32_t)((wx * WN + lr) * 128 + ((lg ^ (lr & 7)) << 4));
-  u32x4_t wreg[2][TN], xreg[2][2];  // [k-step][N fragment], [M fragment of the phase][k-step]
-  // slot shift << 4 of tap (r, s): sgn ((r - 1)(W + 1) + (s - 1)) (the lane's slots count from the block's first row, W + 2 slots before
-  // the tile's first pixel: slot + shift >= 0); built from two scalars where it is used - nine more live values is what the register
-  // allocator does not have in this loop
-  const int W1s = sgn * W1 * 16, s16 = sgn * 16;
-
-  // one phase: tap J (compile time) of chunk c, weights in stage S, activations in buffer CB
-  auto phase = [&](auto J_, auto S_, auto CB_, auto P_, int c) {
-    constexpr int J = decltype(J_)::value, S = decltype(S_)::value, CB = decltype(CB_)::value, P = decltype(P_)::value;
-    constexpr int WOFF = S == 0 ? WOFF0 : WOFF1, AOFF = CB == 0 ? AOFF0 : AOFF1, AOTH = CB == 0 ? AOFF1 : AOFF0;
-    // ---- load section ----
-    if constexpr (P == 0) {
-      wreg[0][0] = lds_read16<WOFF + 0 * 2048>(wa0); wreg[0][1] = lds_read16<WOFF + 1 * 2048>(wa0);
-      wreg[0][2] = lds_read16<WOFF + 2 * 2048>(wa0); wreg[0][3] = lds_read16<WOFF + 3 * 2048>(wa0);
-    }
-    uint32_t ad[2];
-    const int shift = (J / 3 - 1) * W1s + (J % 3 - 1) * s16 + (AOFF >> 3);
-#pragma unroll
-    for (int fi = 0; fi < 2; ++fi) {
-      // (the slot register is "re-defined" by an empty asm: the 8 x 9 x 2 read addresses of a chunk pair are loop invariants the optimiser
-      //  would otherwise hoist out of the chunk loop - 144 registers - and spill)
-      asm volatile("" : "+v"(pf4[2 * P + fi]));
-      const uint32_t A4 = pf4[2 * P + fi] + (uint32_t)shift;
-      ad[fi] = ((A4 << 3) + (A4 & 0x70u)) ^ lg16;  // buffer offset + slot * 128 + ((lg ^ (slot & 7)) << 4)
-    }
-    xreg[0][0] = lds_read16<0>(ad[0] + lds0);
-    xreg[1][0] = lds_read16<0>(ad[1] + lds0);
-    if constexpr (P == 0) {
-      wreg[1][0] = lds_read16<WOFF + 0 * 2048>(wa0 ^ 64u); wreg[1][1] = lds_read16<WOFF + 1 * 2048>(wa0 ^ 64u);
-      wreg[1][2] = lds_read16<WOFF + 2 * 2048>(wa0 ^ 64u); wreg[1][3] = lds_read16<WOFF + 3 * 2048>(wa0 ^ 64u);
-    }
-    xreg[0][1] = lds_read16<0>((ad[0] ^ 64u) + lds0);
-    xreg[1][1] = lds_read16<0>((ad[1] ^ 64u) + lds0);
-    // the other activation buffer was last read in tile 8 of the previous chunk: from phase 1 of tile 1 on (>= 2 barrier intervals) it
-    // takes the next chunk's block, one piece per tile
-    if constexpr (P == 1 && J >= 1 && J <= NPC) issue_x(AOTH, J - 1, c + 1);
-    // this tile's weight fragments were read in phase 0: its stage takes the weights of the tile after the next
-    if constexpr (P == 2) { issue_w(WOFF, 0, (J + 2) % 9, c + (J + 2) / 9); issue_w(WOFF, 1, (J + 2) % 9, c + (J + 2) / 9); }
-    if constexpr (P == 3) { issue_w(WOFF, 2, (J + 2) % 9, c + (J + 2) / 9); issue_w(WOFF, 3, (J + 2) % 9, c + (J + 2) / 9); wait_vmcnt<4>(); }
-    __builtin_amdgcn_s_barrier();
-    // ---- MFMA section ----
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][2 * P + j]) : "v"(wreg[ks][i]), "v"(xreg[j][ks]));  // accumulate in place
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-  };
-  auto tile = [&](auto J_, auto S_, auto CB_, int c) {
-    phase(J_, S_, CB_, ic<0>{}, c); phase(J_, S_, CB_, ic<1>{}, c); phase(J_, S_, CB_, ic<2>{}, c); phase(J_, S_, CB_, ic<3>{}, c);
-  };
-  // prologue of an output tile = the issue order of the steady state: weights of K tile 0, the activation block of chunk 0, weights of
-  // K tile 1 (fourteen pieces)
-  auto prologue_issue = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_w(WOFF0, i, 0, 0);
-#pragma unroll
-    for (int k = 0; k < NPC; ++k) issue_x(AOFF0, k, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_w(WOFF1, i, 1, 0);
-  };
-
-  // ---- epilogue addressing (as conv_gemm_big8_kernel; the staging rows are the head of the second activation buffer) ----
-  const uint32_t stg0 = lds0 + (uint32_t)AOFF1 + (uint32_t)wave * STG;
-  uint32_t swa[TN];
-#pragma unroll
-  for (int i = 0; i < TN; ++i) swa[i] = stg0 + (uint32_t)(lr * 128 + (((2 * i + (lg >> 1)) ^ (lr & 7)) << 4) + (lg & 1) * 8);
-  const int cc = lane & 7, rsub = lane >> 3;
-  const uint32_t sra = stg0 + (uint32_t)(rsub * 128 + ((cc ^ rsub) << 4));
-  const float alpha = p.alpha;
-
-  int vb = blockIdx.x;
-  if (!tile_ok(vb)) return;  // (uniform)
-  tile_addr(tile_m0(vb), tile_n0(vb));
-  prologue_issue();
-#pragma unroll 1
-  for (;;) {
-    const int m0 = tile_m0(vb), n0 = tile_n0(vb);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bs[TN];  // bias of this lane's channels in the MFMA layout: requested now, used after the K loop
-#pragma unroll
-    for (int i = 0; i < TN; ++i) bs[i] = p.bias ? *(const f32x4*)(p.bias + n0 + wx * WN + i * 16 + lg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    // weights of K tile 0 and the activation block of chunk 0 have landed (the four youngest loads - the weights of K tile 1 - and, counted
-    // with them, the bias loads may be in flight; stores of the previous tile's epilogue only make the count stricter)
-    wait_vmcnt<4>();
-    __builtin_amdgcn_s_barrier();  // (also: every wavefront has left the previous tile's epilogue - its staging rows are activation buffer 1)
-    if (wy == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind the first from here on
-#pragma unroll 1
-    for (int c = 0; c < nchunk; c += 2) {
-      tile(ic<0>{}, ic<0>{}, ic<0>{}, c); tile(ic<1>{}, ic<1>{}, ic<0>{}, c); tile(ic<2>{}, ic<0>{}, ic<0>{}, c);
-      tile(ic<3>{}, ic<1>{}, ic<0>{}, c); tile(ic<4>{}, ic<0>{}, ic<0>{}, c); tile(ic<5>{}, ic<1>{}, ic<0>{}, c);
-      tile(ic<6>{}, ic<0>{}, ic<0>{}, c); tile(ic<7>{}, ic<1>{}, ic<0>{}, c); tile(ic<8>{}, ic<0>{}, ic<0>{}, c);
-      tile(ic<0>{}, ic<1>{}, ic<1>{}, c + 1); tile(ic<1>{}, ic<0>{}, ic<1>{}, c + 1); tile(ic<2>{}, ic<1>{}, ic<1>{}, c + 1);
-      tile(ic<3>{}, ic<0>{}, ic<1>{}, c + 1); tile(ic<4>{}, ic<1>{}, ic<1>{}, c + 1); tile(ic<5>{}, ic<0>{}, ic<1>{}, c + 1);
-      tile(ic<6>{}, ic<1>{}, ic<1>{}, c + 1); tile(ic<7>{}, ic<0>{}, ic<1>{}, c + 1); tile(ic<8>{}, ic<1>{}, ic<1>{}, c + 1);
-    }
-    if (wy == 0) __builtin_amdgcn_s_barrier();  // pairs with the second group's last barrier: every wavefront has read its last fragments
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing zero-fill pieces have landed: every buffer is free
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the asm MFMAs' results are read below: the hazard the compiler would pad for
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(acc[i][j]));
-#pragma unroll
-    for (int i = 0; i < TN; ++i) asm volatile("" : "+v"(bs[i]));
-    const int vb_next = vb + (int)gridDim.x;
-    const bool more = tile_ok(vb_next);
-    if (more) {  // (uniform) the next tile's addresses, and its prologue into activation buffer 0 and the weight stages: nobody reads them any more
-      tile_addr(tile_m0(vb_next), tile_n0(vb_next));
-      prologue_issue();
-    }
-    // ---- epilogue: 16 rows (one M fragment) at a time, as conv_gemm_big8_kernel ----
-    uint4 mk[2][2];
-    auto seg_off = [&](int j, int h) -> uint32_t {
-      const int m = m0 + wy * WM + j * 16 + h * 8 + rsub;
-      return m < p.M ? ((uint32_t)m * (uint32_t)d.ldc + (uint32_t)(n0 + wx * WN + cc * 8)) * ES : OOB;
-    };
-    auto fetch_mask = [&](int j, int b) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const uint32_t off = seg_off(j, h);
-        mk[b][h] = off != OOB ? ld16(p.mask_src + off) : make_uint4(0, 0, 0, 0);
-      }
-    };
-    auto put = [&](int j) {
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const f32x4 a = acc[i][j];
-        float v[4] = {a[0] * alpha + bs[i][0], a[1] * alpha + bs[i][1], a[2] * alpha + bs[i][2], a[3] * alpha + bs[i][3]};
-        if constexpr (RES) {
-          const int m = m0 + wy * WM + j * 16 + lr;
-          if (m < p.M) {
-            const uint2 rr = *(const uint2*)(p.residual + ((size_t)m * d.ldc + n0 + wx * WN + i * 16 + lg * 4) * ES);
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-          }
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        const uint32_t lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
-        asm volatile("ds_write_b64 %0, %1" ::"v"(swa[i]), "v"(u32x2_t{lo, hi}) : "memory");
-      }
-    };
-    if (p.mask_src) fetch_mask(0, 0);
-    put(0);
-    u32x4_t o0, o1;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(sra) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(o1) : "v"(sra) : "memory");
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int b = j & 1;
-      if (j + 1 < TM) {
-        if (p.mask_src) fetch_mask(j + 1, b ^ 1);
-        put(j + 1);
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(o0), "+v"(o1) : : "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1) : : "memory");
-      }
-      u32x4_t s0 = o0, s1 = o1;
-      if (j + 1 < TM) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(sra) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(o1) : "v"(sra) : "memory");
-      }
-      if (p.mask_src) {
-        float x8[8], m8[8];
-        unpack16<T>(make_uint4(s0.x, s0.y, s0.z, s0.w), x8);
-        unpack16<T>(mk[b][0], m8);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x8[r] = m8[r] > 0.f ? x8[r] : 0.f;
-        const uint4 q0 = pack16<T>(x8);
-        s0 = u32x4_t{q0.x, q0.y, q0.z, q0.w};
-        unpack16<T>(make_uint4(s1.x, s1.y, s1.z, s1.w), x8);
-        unpack16<T>(mk[b][1], m8);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x8[r] = m8[r] > 0.f ? x8[r] : 0.f;
-        const uint4 q1 = pack16<T>(x8);
-        s1 = u32x4_t{q1.x, q1.y, q1.z, q1.w};
-      }
-      __builtin_amdgcn_raw_buffer_store_b128(s0, rs_out, (int)seg_off(j, 0), 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(s1, rs_out, (int)seg_off(j, 1), 0, 0);
-    }
-    if (!more) break;
-    vb = vb_next;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // The phased main loop for 128 output channels (layer2's 3x3 layers and its conv1): 256 x 128 tiles, THREE 48-KiB stages.
 // Same two wavefront groups one barrier apart, same counted waits and table walk as conv_gemm_big8_kernel; what differs:
 //   * wavefront tile 64 x 64 (4 M x 2 N wavefronts), so a K tile is TWO phases of 16 MFMAs (M fragments 2p, 2p + 1);
@@ -2563,23 +2251,7 @@ static int conv_gemm_launch(const void* src, const void* wmat, void* out, const 
       p.tap_inner = tu && tap_inner && d->R * d->S > 1;
       dim3 gb(8 * cdiv(cdiv(p.M, 256), 8) * (d->Nc / bnb));
       static const int persist8 = [] { const char* e_ = getenv("TD_CONV_BIG_PERSIST"); return e_ ? atoi(e_) : 1; }();  // (A/B: 0 = one workgroup per tile)
-      // 3x3 / stride 1 / pad 1: a channel chunk's rows staged once for all nine taps (conv_gemm_big8h_kernel).  Needs an even number of
-      // 64-channel chunks, the tile's padded block within 352 slots, padded indices below 2^24 (float row decode).  TD_CONV_BIG_HALO=0: A/B
-      const char* halo_env = getenv("TD_CONV_BIG_HALO");  // (read per call: the bit-identity check switches it inside one process)
-      const int halo_on = halo_env ? atoi(halo_env) : 1;
-      bool halo = false;
-      if (halo_on && bnb == 256 && tu && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Hs == d->Ho && d->Ws == d->Wo && d->C % 128 == 0 &&
-          !d->aniso && p.K == 9 * d->C) {
-        const int W_ = d->Ws, H_ = d->Hs;
-        const int rows_x = (255 + W_ - 1) / W_, imgs_x = (255 + H_ * W_ - 1) / (H_ * W_);  // image-row / image boundaries 256 consecutive pixels can cross
-        const int extent = 255 + rows_x + imgs_x * (W_ + 1) + 1 + 2 * (W_ + 2);
-        halo = extent <= 352 && (double)d->N * (H_ + 1) * (W_ + 1) < 16000000.0;
-      }
-      if (halo) {
-        const dim3 gp(persist8 && n_cu % 8 == 0 ? std::min((unsigned)n_cu, gb.x) : gb.x);
-        if (p.residual) conv_gemm_big8h_kernel<true><<<gp, 512, 0, st>>>(p);
-        else conv_gemm_big8h_kernel<false><<<gp, 512, 0, st>>>(p);
-      } else if (bnb == 256) {
+      if (bnb == 256) {
         const dim3 gp(persist8 && n_cu % 8 == 0 ? std::min((unsigned)n_cu, gb.x) : gb.x);
         if (tu && p.residual) conv_gemm_big8_kernel<true, true><<<gp, 512, 0, st>>>(p);
         else if (tu) conv_gemm_big8_kernel<true, false><<<gp, 512, 0, st>>>(p);
