@@ -155,3 +155,47 @@ def test_trunk_weight_gradient_table_at_bench_shape():
         ref = _wgrad_ref(gy, x, R, st, pad) * scale.view(-1, 1, 1, 1)
         assert got.shape == ref.shape
         assert rel_err(got, ref) < 2e-3, shp  # fp32 results of identical bf16 operands: only the summation order differs
+
+
+def test_layer4_layers_on_the_256_row_kernel_at_bench_shape():
+    """The members of conv_gemm_big8_kernel that layer3's shapes do not reach (round 5's persistent form walks them differently): two
+    column tiles per row tile (layer4's 3x3: 512 output channels), the residual instantiation (layer4's conv3: K = 512 -> 2048 with the
+    identity added in the MFMA layout), and residual + ReLU mask together (the input gradient of layer4's conv1: 512 -> 2048 channels)."""
+    from tubedetr_amd import ops
+
+    g = torch.Generator(device=dev()).manual_seed(19)
+    N, H, W, C = FRAMES_FWD, 11, 11, 512
+    # 3x3, 512 -> 512: forward (bias + ReLU) and input gradient (ReLU mask)
+    x = _rand((N, H, W, C), g, relu=True)
+    w = (torch.randn(C, C, 3, 3, generator=g, device=dev()) / math.sqrt(9 * C)).to(torch.bfloat16).float()
+    bias = torch.randn(C, generator=g, device=dev())
+    wf, wd, b_out, _ = ops.weight_prep(w, torch.bfloat16, bias=bias)
+    y = ops.conv_fwd(x, wf, b_out, 3, 3, 1, 1, relu=True)
+    fr = _frames_sample(N)
+    ref = F.relu(F.conv2d(x[fr].float().permute(0, 3, 1, 2), w, bias, padding=1)).permute(0, 2, 3, 1)
+    assert rel_err(y[fr].float(), ref) < TOL
+    gy = _rand((N, H, W, C), g)
+    act = _rand((N, H, W, C), g, relu=True)
+    dx = ops.conv_dgrad(gy, wd, (H, W), 3, 3, 1, 1, mask_src=act)
+    ref = F.conv_transpose2d(gy[fr].float().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * (act[fr].float() > 0)
+    assert rel_err(dx[fr].float(), ref) < TOL
+    # conv3: rows x 512 -> 2048 with residual + ReLU (pointwise K >= 512: the 256-row kernel's residual instantiation)
+    M = N * H * W
+    h2 = _rand((M, 512), g, relu=True)
+    w3 = (torch.randn(2048, 512, generator=g, device=dev()) / math.sqrt(512)).to(torch.bfloat16)
+    b3 = torch.randn(2048, generator=g, device=dev())
+    res = _rand((M, 2048), g, relu=True)
+    out = ops.linear_fwd(h2, w3, b3, residual=res, relu=True)
+    for a, b in ((0, 4096), (M // 2 - 1000, M // 2 + 3000), (M - 4096, M)):
+        ref = (h2[a:b].float() @ w3.float().t() + b3 + res[a:b].float()).relu()
+        assert rel_err(out[a:b].float(), ref) < TOL, a
+    # input gradient of conv1 (2048 -> 512 forward): g [M, 512] x W [512, 2048] + residual (the identity branch's gradient), masked by the block input
+    gh1 = _rand((M, 512), g)
+    w1 = (torch.randn(512, 2048, generator=g, device=dev()) / math.sqrt(2048)).to(torch.bfloat16).float()
+    _, w1d, _, _ = ops.weight_prep(w1.view(512, 2048, 1, 1), torch.bfloat16)
+    gres = _rand((M, 2048), g)
+    xin = _rand((M, 2048), g, relu=True)
+    dxin = ops.conv_dgrad(gh1.view(N, H, W, 512), w1d, (H, W), 1, 1, 1, 0, residual=gres.view(N, H, W, 2048), mask_src=xin.view(N, H, W, 2048)).view(M, 2048)
+    for a, b in ((0, 4096), (M // 2 - 1000, M // 2 + 3000), (M - 4096, M)):
+        ref = (gh1[a:b].float() @ w1 + gres[a:b].float()) * (xin[a:b].float() > 0)
+        assert rel_err(dxin[a:b].float(), ref) < TOL, a
