@@ -123,9 +123,13 @@ def test_ten_step_training_trajectory_fp32_vs_oracle_and_bf16_band():
         n_cmp += 1
     print("parameters compared", n_cmp, "worst cosine of a ten-step update", worst_w, "smallest EMA margin (1 - err / tol)", worst_e)
     assert n_cmp > 250 and worst_w > 0.9, (n_cmp, worst_w, worst_e)
-    # bf16 (most of its kernels exist in bf16 only): the same ten steps stay within 10 % of the fp32 trajectory at every step
-    # (measured: up to 8 % mid-way, 4 % at the end) and reach the same loss level - they train
-    for i, (a, b) in enumerate(zip(l16, l32)):
+    # bf16 (most of its kernels exist in bf16 only): the same ten steps stay within 10 % of the ORACLE's trajectory at every step and reach
+    # the same loss level - they train.  Measured (round 5): 0.2 / 0.1 / 1.4 / 0.4 / 1.2 / 1.5 / 5.0 / 8.3 / 4.2 / 4.7 % - the bf16 trajectory lags by
+    # a fraction of a step on the steep part of the curve.  The reference is the oracle, not the fp32 HIP run above: the bf16 trajectory is
+    # bit-reproducible at this size and so is the oracle's, while the free-running fp32 HIP losses wander by +-0.3 % from run to run
+    # (fp32 atomics; test_deterministic_mode_... below) - against THEM the same bf16 numbers measured 9.1 .. 9.4 %, a bound that a bad draw
+    # of the fp32 run could have crossed.
+    for i, (a, b) in enumerate(zip(l16, l_ref)):
         assert abs(a - b) <= 0.10 * abs(b), (i, a, b)
     assert l16[-1] < 0.5 * l16[0]
 
