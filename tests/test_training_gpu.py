@@ -157,3 +157,13 @@ def test_deterministic_mode_makes_the_fp32_trajectory_bit_reproducible():
     for k in wa:
         assert torch.equal(wa[k], wb[k]), k
         assert torch.equal(ea[k], eb[k]), k
+    # ... and, with every reduction sequential, it follows the ORACLE's trajectory far more closely than the free-running mode does (whose
+    # bound above is 1e-3 for three steps and 5 % after): measured 0 / 0 / 1e-7 / 4e-6 / 1.7e-4 for the first five losses, then 1.5e-3 / 3.9e-3 /
+    # 1.16e-2 / 6.2e-3 / 5.7e-3 (round 5; two different fp32 implementations under AdamW still part ways - later, and less)
+    sd = fill_state(state_spec(cfg), 11, requires_grad=True)
+    torch.set_num_threads(16)
+    l_ref, _, _ = _oracle_run(cfg, sd, batch)
+    print("oracle       ", [round(x, 5) for x in l_ref])
+    print("deterministic", [round(x, 5) for x in la])
+    for i, (a, b) in enumerate(zip(la, l_ref)):
+        assert abs(a - b) <= (2e-5 if i < 4 else (1e-3 if i < 5 else 2.5e-2)) * abs(b), (i, a, b)
