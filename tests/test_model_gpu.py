@@ -31,6 +31,16 @@ def _load(model, cfg, seed):
     return sd
 
 
+def _same_argmax(got, ref, tie=1e-6):
+    """Attention indices bit-exact - except in rows whose maximum the reference itself holds more than once (to within ``tie``): there
+    the index is decided by the last bit of either implementation.  It happens in exactly one fixture: without time encodings
+    (--no_time_embed) all time queries of a clip are identical in the first decoder layer, its temporal self-attention is uniform
+    (1 / t in every column) and the reference's own argmax over such a row is 0, 2 or 4 depending on the row."""
+    ga, ra = got.argmax(-1), ref.argmax(-1)
+    ref_at_got = np.take_along_axis(ref, ga[..., None], -1)[..., 0]
+    return bool(((ga == ra) | (ref.max(-1) - ref_at_got <= tie)).all())
+
+
 def _compare_with_golden(model, criterion, weight_dict, batch, gold):
     from tubedetr_amd.harness import FixedTokenizer, batch_to, forward_step
 
@@ -49,14 +59,20 @@ def _compare_with_golden(model, criterion, weight_dict, batch, gold):
             assert cache[k] is None, k
             continue
         assert np.array_equal(cache[k].cpu().numpy().astype(bool), gold["cache." + k]), k
-    layers = out["aux_outputs"] + [out]
+    layers = out.get("aux_outputs", []) + [out]
+    assert len(layers) == gold["out.pred_boxes"].shape[0]  # (one entry without --aux_loss)
     for key in ("pred_boxes", "pred_sted", "weights", "ca_weights"):
+        if "out." + key not in gold.files:  # --no_sted / --no_guided_attn: the reference's output dict has no such key (tubedetr.py:233-237)
+            assert key not in out, key
+            continue
         got = np.stack([cpu(o[key]) for o in layers])
         err = np.abs(got - gold["out." + key]).max()
         assert err < LOGIT_TOL, (key, err)
     for key in ("weights", "ca_weights"):  # attention indices bit-exact
+        if "out." + key not in gold.files:
+            continue
         got = np.stack([cpu(o[key]) for o in layers])
-        assert np.array_equal(got.argmax(-1), gold["out." + key].argmax(-1)), key
+        assert _same_argmax(got, gold["out." + key]), key
 
     names = sorted(ld)
     assert names == list(gold["loss.names"])
@@ -91,10 +107,10 @@ def test_model_matches_reference_golden_fp32(name):
 
 
 @pytest.mark.parametrize("name", ["v_gating_T6_res64_k2", "v_pool_T6_res64_k3", "v_transformer_T4_res64_k2", "v_noslow_T6_res64_k2", "v_stride0_T5-3_res64",
-                                  "v_learned_T6_res64_k2"])
+                                  "v_learned_T6_res64_k2", "v_boxesonly_T6_res64_k2", "v_notime_T6-5_res64_k2"])
 def test_ablation_flags_match_reference_golden_fp32(name):
     """main.py's ablation flags (--fast_mode gating | pool | transformer | noslow, --stride 0, --learn_time_embed,
-    --position_embedding learned; SURVEY.md 8a'): accepted, computed on this library's kernels + stock PyTorch ops for the
+    --position_embedding learned, --no_sted + --no_guided_attn + --no_aux_loss, --no_time_embed; SURVEY.md 8a'): accepted, computed on this library's kernels + stock PyTorch ops for the
     variant's own arithmetic, and checked against the reference's own outputs, losses and gradients (the CPU oracle does
     not restate the variants: these vectors pin the product directly)."""
     import tubedetr_amd
