@@ -49,6 +49,9 @@ VARIANTS = {
     "v_learned_T6_res64_k2": (dict(T=6, res=64, k=2, L=4, seed=26), dict(stride=2), dict(learn_time_embed=True, position_embedding="learned")),
     # head / loss switches of main.py (--no_sted, --no_guided_attn, --no_aux_loss: the output dict and the loss dict lose keys) and --no_time_embed
     "v_boxesonly_T6_res64_k2": (dict(T=6, res=64, k=2, L=4, seed=27, pad_w=7), dict(stride=2, sted=False, guided_attn=False, aux_loss=False), dict()),
+    # --freeze_backbone --freeze_text_encoder (the trunk's and RoBERTa's backward disappear from the graph), --sigma 2 and non-default loss coefficients
+    "v_frozen_T6_res64_k2": (dict(T=6, res=64, k=2, L=5, seed=29, pad_w=5), dict(stride=2, sigma=2.0, bbox_loss_coef=3.0, giou_loss_coef=1.5, sted_loss_coef=7.0, guided_attn_loss_coef=0.5),
+                             dict(freeze_backbone=True, freeze_text_encoder=True)),
     "v_notime_T6-5_res64_k2": (dict(T=6, res=64, k=2, L=4, seed=28, durations=[6, 5], text_pad=1), dict(stride=2, no_time_embed=True), dict()),
 }
 WEIGHT_SEED = 7

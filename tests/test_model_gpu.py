@@ -77,6 +77,7 @@ def _compare_with_golden(model, criterion, weight_dict, batch, gold):
     names = sorted(ld)
     assert names == list(gold["loss.names"])
     np.testing.assert_allclose([ld[k].item() for k in names], gold["loss.values"], rtol=1e-3, atol=1e-4)
+    assert abs(loss.item() - float(gold["loss.total"])) <= 1e-3 * abs(float(gold["loss.total"]))  # (the weighted sum: weight_dict's coefficients)
 
     loss.backward()
     params = dict(model.named_parameters())
@@ -107,10 +108,11 @@ def test_model_matches_reference_golden_fp32(name):
 
 
 @pytest.mark.parametrize("name", ["v_gating_T6_res64_k2", "v_pool_T6_res64_k3", "v_transformer_T4_res64_k2", "v_noslow_T6_res64_k2", "v_stride0_T5-3_res64",
-                                  "v_learned_T6_res64_k2", "v_boxesonly_T6_res64_k2", "v_notime_T6-5_res64_k2"])
+                                  "v_learned_T6_res64_k2", "v_boxesonly_T6_res64_k2", "v_notime_T6-5_res64_k2", "v_frozen_T6_res64_k2"])
 def test_ablation_flags_match_reference_golden_fp32(name):
     """main.py's ablation flags (--fast_mode gating | pool | transformer | noslow, --stride 0, --learn_time_embed,
-    --position_embedding learned, --no_sted + --no_guided_attn + --no_aux_loss, --no_time_embed; SURVEY.md 8a'): accepted, computed on this library's kernels + stock PyTorch ops for the
+    --position_embedding learned, --no_sted + --no_guided_attn + --no_aux_loss, --no_time_embed, --freeze_backbone + --freeze_text_encoder + --sigma 2 + other loss
+    coefficients; SURVEY.md 8a'): accepted, computed on this library's kernels + stock PyTorch ops for the
     variant's own arithmetic, and checked against the reference's own outputs, losses and gradients (the CPU oracle does
     not restate the variants: these vectors pin the product directly)."""
     import tubedetr_amd

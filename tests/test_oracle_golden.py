@@ -20,7 +20,8 @@ def roberta_free_threads():
 
 # the head / loss switches and --no_time_embed are restated by the oracle too (OracleConfig.sted / guided_attn / aux_loss / no_time_embed):
 # their vectors live with the ablation variants (the output and loss dicts lose keys) and pin the oracle like the four base cases
-ORACLE_VARIANTS = ["v_boxesonly_T6_res64_k2", "v_notime_T6-5_res64_k2"]
+# (v_frozen: --sigma 2 and non-default loss coefficients; its freeze flags only remove gradients the vectors then do not list)
+ORACLE_VARIANTS = ["v_boxesonly_T6_res64_k2", "v_notime_T6-5_res64_k2", "v_frozen_T6_res64_k2"]
 
 
 @pytest.mark.parametrize("name", list(CASES) + ORACLE_VARIANTS)
