@@ -54,7 +54,8 @@ int td_abi_version(void);
 #define TD_PROF_FUSED 7       /* LDS-resident chains: fused stem (stem.hip), fused frozen bottlenecks (bottleneck.hip) */
 #define TD_PROF_CROSS_Q1 8    /* time-aligned cross-attention frame core (cross_attn.hip): HBM-bound by the memory rows */
 #define TD_PROF_WGRAD_SINGLE 9 /* one weight gradient per launch (td_conv_wgrad[_bias]); TD_PROF_WGRAD = the batched launches */
-#define TD_PROF_FAMILIES 10
+#define TD_PROF_CHAIN 10 /* chained conv3 -> next-block conv1 pairs of layer3 (chain.hip): HBM-bound, the block output never read back */
+#define TD_PROF_FAMILIES 11
 int td_prof_enable(int on);
 int td_prof_collect(int family, int dtype, long long* launches, double* ms, double* flops);
 /* Sum of the ALGORITHMIC HBM bytes of the same launches (each operand / result tensor counted once per launch). */
@@ -207,6 +208,15 @@ int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const float* mean, co
  * Used by td_resnet_fwd; exported for the parity test. */
 int td_bottleneck_fused(const void* x, void* out, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                         const float* b3, const void* wd, const float* bd, int N, int H, int W, int Cin, int dtype, td_stream_t stream);
+/* Chained pointwise pair across two consecutive bottlenecks of one stage (bf16, planes = 256: layer3):
+ *   out[M][4P] = relu(y2[M][P] w3[4P][P]^T + b3 + residual[M][4P])   conv3 + FrozenBN + identity + ReLU of block j
+ *   h1[M][P]   = relu(out w1[P][4P]^T + b1)                           conv1 + FrozenBN + ReLU of block j + 1
+ * in ONE launch: `out` is written (it is the next identity and, in a saved pass, the saved activation) but never read back.
+ * Bit-identical to td_conv_gemm(conv3, residual, relu) followed by td_conv_gemm(conv1, relu).  Replaces the two calls
+ * torchvision's Bottleneck.forward makes on either side of a block boundary (models/backbone.py:97-98) in both trunk passes
+ * (models/tubedetr.py:127-134).  Used by td_resnet_fwd; exported for the parity test. */
+int td_pw_chain2(const void* y2, const void* w3, const float* b3, const void* residual, void* out, const void* w1, const float* b1,
+                 void* h1, int M, int planes, int dtype, td_stream_t stream);
 /* stem_pairs = 1 (bf16, even W): the stem runs in its pixel-pair form - the frames are laid down with 4 channels per
  * pixel (3 + one zero), two horizontally adjacent pixels form one 8-channel element, and the 7x7 stride-2 convolution
  * becomes a 7x4 convolution with stride (2, 1) and padding (3, 2) over them: K = 224 instead of 392 (3 channels padded to 8),

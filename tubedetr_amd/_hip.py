@@ -11,7 +11,7 @@ import os
 import torch
 
 TD_F32, TD_BF16 = 0, 1
-EXPECTED_ABI = 8  # td_abi_version() of the library these signatures were written against
+EXPECTED_ABI = 9  # td_abi_version() of the library these signatures were written against
 _LIB_PATH = os.environ.get("TD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtubedetr_hip.so")  # (TD_HIP_LIB: an A/B build of the same ABI, tools/build_variant.sh)
 _lib = None
 
@@ -81,6 +81,7 @@ _SIGS = {
     "td_bottleneck_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "td_stem_pair_weights": [_P, _P, _I, _I, _P],
     "td_stem_pool": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "td_pw_chain2": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "td_frames_to_nhwc": [C.POINTER(FrameSource), _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P],
     "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _P, _P, _SZ, _I, _I, _P],
     "td_weight_prep_batch": [_P, _I, _I, _I, _P],

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtubedetr_hip.so")
-SOURCES = ["api.cpp", "gemm_conv.hip", "prep.hip", "elementwise.hip", "attention.hip", "resnet_exec.hip", "optim.hip", "criterion.hip", "stem.hip", "bottleneck.hip", "cross_attn.hip"]
+SOURCES = ["api.cpp", "gemm_conv.hip", "prep.hip", "elementwise.hip", "attention.hip", "resnet_exec.hip", "optim.hip", "criterion.hip", "stem.hip", "bottleneck.hip", "cross_attn.hip", "chain.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 

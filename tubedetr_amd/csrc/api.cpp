@@ -110,4 +110,4 @@ extern "C" int td_prof_dump(const char* path) {
 }
 
 extern "C" const char* td_last_error(void) { return td::g_err; }
-extern "C" int td_abi_version(void) { return 8; }  // 8 (round 5): td_pw_chain removed
+extern "C" int td_abi_version(void) { return 9; }  // 9 (round 6): td_pw_chain2

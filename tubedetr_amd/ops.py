@@ -286,6 +286,21 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, residual=
     return y
 
 
+def pw_chain2(y2: Tensor, w3: Tensor, b3: Tensor, residual: Tensor, w1: Tensor, b1: Tensor, *, out: Optional[Tensor] = None,
+              h1: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """td_pw_chain2: out [M,4P] = relu(y2 [M,P] @ w3^T + b3 + residual), h1 [M,P] = relu(out @ w1^T + b1) in one launch (bf16, P = 256):
+    conv3 + identity of one layer3 bottleneck and conv1 of the next; bit-identical to the two linear_fwd calls."""
+    M, P = y2.shape
+    assert y2.dtype == torch.bfloat16 and w3.shape == (4 * P, P) and w1.shape == (P, 4 * P) and residual.shape == (M, 4 * P)
+    assert y2.is_contiguous() and w3.is_contiguous() and w1.is_contiguous() and residual.is_contiguous()
+    assert b3.dtype == torch.float32 and b1.dtype == torch.float32 and b3.numel() == 4 * P and b1.numel() == P
+    out = out if out is not None else torch.empty((M, 4 * P), dtype=y2.dtype, device=y2.device)
+    h1 = h1 if h1 is not None else torch.empty((M, P), dtype=y2.dtype, device=y2.device)
+    check(_hip.lib().td_pw_chain2(ptr(y2), ptr(w3), ptr(b3), ptr(residual), ptr(out), ptr(w1), ptr(b1), ptr(h1), M, P, dtype_code(y2.dtype),
+                                  stream_ptr()), "td_pw_chain2")
+    return out, h1
+
+
 def _rows2d(t: Tensor):
     assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D operand expected (unit column stride)"
     return t
