@@ -7,6 +7,7 @@ evaluation of the same op on the same bf16-rounded operands:
   pw_resident2_kernel               layer3 conv3      M = 484 000, N = 1024, K = 256      + residual + ReLU
   pw_resident2_kernel               layer1 conv3      M = 7 744 000, N = 256, K = 64      + residual + ReLU
   conv_gemm_big8(n)_kernel / conv_gemm_kernel (tap-uniform)  the stride-2 layers of a stage's first block (3x3 and the 1x1 downsample)
+  pw_chain2_kernel                  layer3 conv3 + identity chained with the next conv1   M = 484 000 / 774 400, 256 -> 1024 -> 256
   conv_wgrad_wide_batch_kernel      the trunk's batched weight-gradient table at 200 slow frames (one job per layer shape)
 
 The forward-type results are compared on sampled row ranges (first / middle / last rows of the launch: tile 0, an interior
@@ -110,6 +111,38 @@ def test_pointwise_layers_at_bench_shape(shape):
         if res is not None:
             ref = ref + res[a:b].float()
         assert rel_err(y[a:b].float(), ref.relu()) < TOL, (shape[0], a)
+
+
+@pytest.mark.parametrize("frames", [FRAMES_FWD, 1600, 7], ids=["484000_rows", "774400_rows", "ragged_3388_rows"])
+def test_chained_conv3_conv1_pair_at_bench_shape(frames):
+    """td_pw_chain2 (chain.hip): conv3 + identity + ReLU of a layer3 block and conv1 + ReLU of the next in one launch, 484 000 x 256 -> 1024 -> 256.
+    (a) bit-identical to the two launches it replaces (pw_resident2_kernel, conv_gemm_big8_kernel<false>); (b) both results against fp32 torch on
+    the same bf16 operands, per element: |err| <= 2^-8 |ref| + 2e-3 max|ref| (output rounding + fp32 summation order; the second product sees the
+    bf16-rounded first result on both sides); (c) rows past M stay untouched."""
+    from tubedetr_amd import ops
+
+    P, M = 256, frames * 484
+    g = torch.Generator(device=dev()).manual_seed(11)
+    y2 = _rand((M, P), g, relu=True)
+    res = _rand((M, 4 * P), g, relu=True)
+    w3 = (torch.randn(4 * P, P, generator=g, device=dev()) / math.sqrt(P)).to(torch.bfloat16)
+    w1 = (torch.randn(P, 4 * P, generator=g, device=dev()) / math.sqrt(4 * P)).to(torch.bfloat16)
+    b3 = torch.randn(4 * P, generator=g, device=dev()) * 0.1
+    b1 = torch.randn(P, generator=g, device=dev()) * 0.1
+    guard_o = torch.full((M + 130, 4 * P), 3.0, device=dev(), dtype=torch.bfloat16)
+    guard_h = torch.full((M + 130, P), 3.0, device=dev(), dtype=torch.bfloat16)
+    out, h1 = ops.pw_chain2(y2, w3, b3, res, w1, b1, out=guard_o[:M], h1=guard_h[:M])
+    out_u = ops.linear_fwd(y2, w3, b3, residual=res, relu=True)
+    h1_u = ops.linear_fwd(out_u, w1, b1, relu=True)
+    assert torch.equal(out, out_u) and torch.equal(h1, h1_u), "the chained launch differs from the two launches it replaces"
+    assert bool((guard_o[M:] == 3.0).all()) and bool((guard_h[M:] == 3.0).all()), "rows past M were written"
+    for a, b in ((0, min(M, 4096)), (max(0, M // 2 - 1000), min(M, M // 2 + 3000)), (max(0, M - 4096), M)):
+        ref_o = (y2[a:b].float() @ w3.float().t() + b3 + res[a:b].float()).relu()
+        err = (out[a:b].float() - ref_o).abs()
+        assert bool((err <= ref_o.abs() * 2.0**-8 + 2e-3 * ref_o.abs().max()).all()), (frames, a, "out")
+        ref_h = (out[a:b].float() @ w1.float().t() + b1).relu()
+        err = (h1[a:b].float() - ref_h).abs()
+        assert bool((err <= ref_h.abs() * 2.0**-8 + 2e-3 * ref_h.abs().max()).all()), (frames, a, "h1")
 
 
 def _wgrad_ref(gy, x, R, stride, pad):

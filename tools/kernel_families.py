@@ -16,6 +16,7 @@ FAMILY_OF_PROF_ID = {
     7: "td::stem_pool_kernel + td::bottleneck_first3_kernel + td::bottleneck_resident3_kernel",
     8: "td::cross_q1_fwd_mfma_kernel + td::cross_q1_bwd_mfma_kernel + td::cross_q1_dmem_kernel",
     9: "td::conv_wgrad_kernel<unsigned short, ...>",
+    10: "td::pw_chain2_kernel",  # conv3 + identity of a layer3 block chained with the next block's conv1: HBM-bound, the block output is not read back
 }
 
 
@@ -31,6 +32,8 @@ def family(name: str):
         return f"td::conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, ...>"  # pipeline depths, pointwise / tap-uniform / two-source instances merged
     if "td::pw_resident2_kernel" in name:
         return FAMILY_OF_PROF_ID[4]
+    if "td::pw_chain2_kernel" in name:
+        return FAMILY_OF_PROF_ID[10]
     m = re.search(r"td::conv_gemm_big8n?_kernel<(true|false)", name)
     if m:
         return FAMILY_OF_PROF_ID[5 if m.group(1) == "true" else 6]

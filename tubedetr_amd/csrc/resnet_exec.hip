@@ -224,6 +224,8 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
   // variant) vs 3.72 ms.  TD_L1_FUSED: 0 = never (exact-fp32 mode and A/B: layer by layer), 1 = block 0 only, 2 (default) = every
   // frozen 64-plane block.
   static const int l1_fused = [] { const char* e = getenv("TD_L1_FUSED"); return e ? atoi(e) : 2; }();
+  static const int chain_on = [] { const char* e = getenv("TD_CHAIN"); return e ? atoi(e) : 1; }();
+  bool h1_done = false;  // this block's conv1 output was written by the previous block's chained launch
   for (size_t bi = 0; bi < P.blocks.size(); ++bi) {
     auto& b = P.blocks[bi];
     const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
@@ -238,12 +240,26 @@ extern "C" int td_resnet_fwd(const td_frame_source* srcs, int n_srcs, const floa
           return rc;
       continue;
     }
-    if ((rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream, fg))) return rc;
+    if (!h1_done && (rc = run_conv(base, b.in, b.h1, N, P.convs[c1], w_fwd[c1], bias[c1], nullptr, 1, dtype, stream, fg))) return rc;
+    h1_done = false;
     if ((rc = run_conv(base, b.h1, b.h2, N, P.convs[c2], w_fwd[c2], bias[c2], nullptr, 1, dtype, stream, fg))) return rc;
     const char* idt = base + b.in.off;
     if (cd >= 0) {
       if ((rc = run_conv(base, b.in, b.idt, N, P.convs[cd], w_fwd[cd], bias[cd], nullptr, 0, dtype, stream, fg))) return rc;
       idt = base + b.idt.off;
+    }
+    // conv3 + identity + ReLU of this block CHAINED with conv1 + ReLU of the next one (chain.hip: the block output is written - it is the
+    // next identity and, in a saved pass, a saved activation - but not read back from HBM).  Where: 256-plane blocks (layer3) with a
+    // successor in the same stage, bf16; both tensors of the pair are written exactly where the two separate launches write them, so
+    // td_resnet_bwd walks the same workspace.  TD_CHAIN=0: the two launches (A/B; bit-identical results).
+    if (chain_on && dtype == TD_BF16 && bi + 1 < P.blocks.size() && P.blocks[bi + 1].stage == b.stage && P.convs[c3].cin == 256 && P.convs[c3].cout == 1024 &&
+        P.blocks[bi + 1].stride == 1 && (double)N * b.out.H * b.out.W * 1024.0 * 2.0 < 4294967000.0) {
+      const BlockPlan& nb_ = P.blocks[bi + 1];
+      const int n1 = nb_.conv[0];
+      if ((rc = td_pw_chain2(base + b.h2.off, w_fwd[c3], bias[c3], idt, base + b.out.off, w_fwd[n1], bias[n1], base + nb_.h1.off, N * b.out.H * b.out.W, 256, dtype, stream)))
+        return rc;
+      h1_done = true;
+      continue;
     }
     if ((rc = run_conv(base, b.h2, b.out, N, P.convs[c3], w_fwd[c3], bias[c3], idt, 1, dtype, stream, fg))) return rc;
   }
