@@ -16,7 +16,7 @@ FAMILY_OF_PROF_ID = {
     7: "td::stem_pool_kernel + td::bottleneck_first3_kernel + td::bottleneck_resident3_kernel",
     8: "td::cross_q1_fwd_mfma_kernel + td::cross_q1_bwd_mfma_kernel + td::cross_q1_dmem_kernel",
     9: "td::conv_wgrad_kernel<unsigned short, ...>",
-    10: "td::pw_chain2_kernel",  # conv3 + identity of a layer3 block chained with the next block's conv1: HBM-bound, the block output is not read back
+    10: "td::pw_chain2_kernel_w4",  # conv3 + identity of a layer3 block chained with the next block's conv1: HBM-bound, the block output is not read back
 }
 
 

@@ -1,6 +1,7 @@
 """Sustained clock / power while ONE kernel shape runs back to back (the 3x3 of layer3 on 256-row tiles, or the persistent 1x1).
-usage: power_probe.py [3x3|1x1|mix|wgrad|l1] [seconds]   - prints rocm-smi power / sclk samples taken while the loop runs.
-(wgrad = the trunk's 90 batched weight-gradient jobs at 400 slow frames, l1 = the fused 256-channel layer1 bottleneck at 1 000 frames)"""
+usage: power_probe.py [3x3|1x1|mix|wgrad|l1|chain|pair] [seconds]   - prints rocm-smi power / sclk samples taken while the loop runs.
+(wgrad = the trunk's 90 batched weight-gradient jobs at 400 slow frames, l1 = the fused 256-channel layer1 bottleneck at 1 000 frames,
+chain = td_pw_chain2 on 800 layer3 frames, pair = the two launches it replaces on the same tensors; TD_HIP_LIB=<TD_CHAIN_ABL build> for ablations)"""
 import os, subprocess, sys, threading, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -45,7 +46,18 @@ def make_l1():
                                                     None, None, N, Hh, Hh, 256, _hip.TD_BF16, _hip.stream_ptr()), "td_bottleneck_fused")
 
 
-fn = {"3x3": lambda: f3, "1x1": lambda: f1, "mix": lambda: (lambda: (f3(), f1())), "wgrad": make_wgrad, "l1": make_l1}[what]()
+def make_chain(fused):
+    M = frames * 484
+    w1 = (torch.randn(256, 1024, device=dev, generator=g) * 0.02).bfloat16()
+    b1 = torch.randn(256, device=dev, generator=g)
+    y2 = torch.randn(M, 256, device=dev, generator=g).relu().bfloat16()
+    h1 = torch.empty(M, 256, device=dev, dtype=torch.bfloat16)
+    if fused:
+        return lambda: ops.pw_chain2(y2, w3, b3, r3, w1, b1, out=y3, h1=h1)
+    return lambda: (ops.linear_fwd(y2, w3, b3, residual=r3, relu=True, out=y3), ops.linear_fwd(y3, w1, b1, relu=True, out=h1))
+
+
+fn = {"chain": lambda: make_chain(True), "pair": lambda: make_chain(False), "3x3": lambda: f3, "1x1": lambda: f1, "mix": lambda: (lambda: (f3(), f1())), "wgrad": make_wgrad, "l1": make_l1}[what]()
 samples = []
 stop = False
 def sampler():
