@@ -33,6 +33,13 @@ typedef void* td_stream_t; /* hipStream_t */
 const char* td_last_error(void);
 int td_abi_version(void);
 
+/* Deterministic parity mode: 1 = every reduction that is normally split over workgroups and combined with fp32 atomics (weight gradients,
+ * LayerNorm dgamma / dbeta, bias column sums) runs as one sequential reduction per output element: two runs of a step are bit-identical.
+ * Process-wide atomic flag, seeded once from TD_DETERMINISTIC=1 in the environment, read at LAUNCH time: grid and split choices are frozen
+ * into a captured HIP graph, so a graph captured under the other setting must be re-captured. */
+int td_set_deterministic(int on);
+int td_get_deterministic(void);
+
 /* Dropout RNG: counter-based, keep(seed, element index) = hash32(element index * golden + seed) >= p * 2^32.  Every
  * dropout-capable entry point takes an optional `dropout_counter`: a DEVICE pointer to one uint32 step counter.  When
  * non-NULL the kernels re-key the seed with a hash of (seed, *dropout_counter), read at execution time - a captured HIP

@@ -13,8 +13,9 @@ evaluation of the same op on the same bf16-rounded operands:
 The forward-type results are compared on sampled row ranges (first / middle / last rows of the launch: tile 0, an interior
 tile, the ragged last tile) - the reference of a whole 484 000 x 2304 launch would be another GEMM library's result, not
 a check; weight gradients are full reductions and are compared whole, against fp32 matmuls over the same rows.
-Tolerance: operands are identical bf16 values on both sides and both accumulate in fp32, so only the output rounding
-(bf16: 2^-8 relative) and the summation order differ: max |err| <= 1.2e-2 max |ref| (the module-wide bf16 bound)."""
+Tolerance: operands are identical bf16 values on both sides and both accumulate in fp32, so only the output rounding (bf16: at most
+2^-8 of the value) and the fp32 summation order differ - PER ELEMENT |err| <= 2^-8 |ref| + 2e-3 max |ref| (round 6; it used to be one
+1.2e-2 max |ref| for the whole tensor, three times what those two effects explain)."""
 import math
 
 import pytest
@@ -23,12 +24,20 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1.2e-2
 FRAMES_FWD, FRAMES_BWD = 1000, 200  # 8 clips x (100 fast + 25 slow) frames forward, 8 x 25 slow frames backward
 
 
 def dev():
     return torch.device("cuda:0")
+
+
+def assert_bf16(got, ref, what=None):
+    """every element within the bf16 output rounding of the fp32 reference plus a summation-order allowance"""
+    got, ref = got.detach().double(), ref.detach().double()
+    err = (got - ref).abs()
+    bound = ref.abs() * 2.0**-8 + 2e-3 * ref.abs().max()
+    bad = err > bound
+    assert not bool(bad.any()), (what, int(bad.sum()), float((err / bound).max()))
 
 
 def rel_err(got, ref):
@@ -61,7 +70,7 @@ def test_layer3_conv3x3_forward_and_dgrad_at_bench_shape():
     fr = _frames_sample(N)
     xs = x[fr].float().permute(0, 3, 1, 2)
     ref = F.relu(F.conv2d(xs, w, bias, padding=1)).permute(0, 2, 3, 1)
-    assert rel_err(y[fr].float(), ref) < TOL
+    assert_bf16(y[fr].float(), ref)
     # input gradient at the backward's shape (200 frames: 379 row tiles of 256 on 256 CUs), ReLU mask of the producing layer fused
     Nb = FRAMES_BWD
     gy = _rand((Nb, H, W, C), g)
@@ -70,7 +79,7 @@ def test_layer3_conv3x3_forward_and_dgrad_at_bench_shape():
     fr = _frames_sample(Nb)
     gs = gy[fr].float().permute(0, 3, 1, 2)
     ref = F.conv_transpose2d(gs, w, padding=1).permute(0, 2, 3, 1) * (act[fr].float() > 0)
-    assert rel_err(dx[fr].float(), ref) < TOL
+    assert_bf16(dx[fr].float(), ref)
 
 
 @pytest.mark.parametrize("shape", [("layer3.0 downsample (strided 1x1 on the 256-row tiles)", 44, 512, 1024, 1), ("layer2.0 downsample (strided 1x1, short K)", 88, 256, 512, 1),
@@ -91,7 +100,7 @@ def test_stage_entry_strided_layers_at_bench_shape(shape):
     ref = F.conv2d(x[fr].float().permute(0, 3, 1, 2), w, bias, stride=2, padding=ksz // 2).permute(0, 2, 3, 1)
     if ksz == 3:
         ref = ref.relu()
-    assert rel_err(y[fr].float(), ref) < TOL, shape[0]
+    assert_bf16(y[fr].float(), ref, shape[0])
 
 
 @pytest.mark.parametrize("shape", [("layer3.conv1 (256-row tiles)", 484000, 1024, 256, False), ("layer3.conv3 (persistent)", 484000, 256, 1024, True),
@@ -110,7 +119,7 @@ def test_pointwise_layers_at_bench_shape(shape):
         ref = x[a:b].float() @ w.float().t() + bias
         if res is not None:
             ref = ref + res[a:b].float()
-        assert rel_err(y[a:b].float(), ref.relu()) < TOL, (shape[0], a)
+        assert_bf16(y[a:b].float(), ref.relu(), (shape[0], a))
 
 
 @pytest.mark.parametrize("frames", [FRAMES_FWD, 1600, 7], ids=["484000_rows", "774400_rows", "ragged_3388_rows"])
@@ -143,6 +152,27 @@ def test_chained_conv3_conv1_pair_at_bench_shape(frames):
         ref_h = (out[a:b].float() @ w1.float().t() + b1).relu()
         err = (h1[a:b].float() - ref_h).abs()
         assert bool((err <= ref_h.abs() * 2.0**-8 + 2e-3 * ref_h.abs().max()).all()), (frames, a, "h1")
+
+
+def test_persistent_256_row_kernel_equals_one_tile_per_workgroup():
+    """The persistent form of conv_gemm_big8_kernel (next tile's prologue pieces issued under this tile's epilogue, hand-counted vmcnt / lgkmcnt
+    waits) against its one-tile-per-workgroup form (TD_CONV_BIG_PERSIST=0, the documented fallback), bit for bit: plain, residual and residual +
+    ReLU-mask epilogues, row counts that end in a ragged tile.  A compiler that reschedules a scalar load into those counted sequences would
+    show up here as a changed bit."""
+    import os
+    import subprocess
+    import sys
+
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_persist_probe.py")
+    outs = []
+    for knob in ("1", "0"):
+        env = dict(os.environ, TD_CONV_BIG_PERSIST=knob)
+        r = subprocess.run([sys.executable, probe], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if len(ln.split()) >= 2 and len(ln.split()[-1]) == 64]
+        assert len(lines) == 5, r.stdout
+        outs.append(lines)
+    assert outs[0] == outs[1], "\n".join(f"{a}  |  {b}" for a, b in zip(*outs))
 
 
 def _wgrad_ref(gy, x, R, stride, pad):
@@ -206,12 +236,12 @@ def test_layer4_layers_on_the_256_row_kernel_at_bench_shape():
     y = ops.conv_fwd(x, wf, b_out, 3, 3, 1, 1, relu=True)
     fr = _frames_sample(N)
     ref = F.relu(F.conv2d(x[fr].float().permute(0, 3, 1, 2), w, bias, padding=1)).permute(0, 2, 3, 1)
-    assert rel_err(y[fr].float(), ref) < TOL
+    assert_bf16(y[fr].float(), ref)
     gy = _rand((N, H, W, C), g)
     act = _rand((N, H, W, C), g, relu=True)
     dx = ops.conv_dgrad(gy, wd, (H, W), 3, 3, 1, 1, mask_src=act)
     ref = F.conv_transpose2d(gy[fr].float().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * (act[fr].float() > 0)
-    assert rel_err(dx[fr].float(), ref) < TOL
+    assert_bf16(dx[fr].float(), ref)
     # conv3: rows x 512 -> 2048 with residual + ReLU (pointwise K >= 512: the 256-row kernel's residual instantiation)
     M = N * H * W
     h2 = _rand((M, 512), g, relu=True)
@@ -221,7 +251,7 @@ def test_layer4_layers_on_the_256_row_kernel_at_bench_shape():
     out = ops.linear_fwd(h2, w3, b3, residual=res, relu=True)
     for a, b in ((0, 4096), (M // 2 - 1000, M // 2 + 3000), (M - 4096, M)):
         ref = (h2[a:b].float() @ w3.float().t() + b3 + res[a:b].float()).relu()
-        assert rel_err(out[a:b].float(), ref) < TOL, a
+        assert_bf16(out[a:b].float(), ref, a)
     # input gradient of conv1 (2048 -> 512 forward): g [M, 512] x W [512, 2048] + residual (the identity branch's gradient), masked by the block input
     gh1 = _rand((M, 512), g)
     w1 = (torch.randn(512, 2048, generator=g, device=dev()) / math.sqrt(2048)).to(torch.bfloat16).float()
@@ -231,4 +261,4 @@ def test_layer4_layers_on_the_256_row_kernel_at_bench_shape():
     dxin = ops.conv_dgrad(gh1.view(N, H, W, 512), w1d, (H, W), 1, 1, 1, 0, residual=gres.view(N, H, W, 2048), mask_src=xin.view(N, H, W, 2048)).view(M, 2048)
     for a, b in ((0, 4096), (M // 2 - 1000, M // 2 + 3000), (M - 4096, M)):
         ref = (gh1[a:b].float() @ w1 + gres[a:b].float()) * (xin[a:b].float() > 0)
-        assert rel_err(dxin[a:b].float(), ref) < TOL, a
+        assert_bf16(dxin[a:b].float(), ref, a)

@@ -333,11 +333,22 @@ def test_bench_rehearsal_flags_reach_the_ranks_and_fail_cleanly_without_a_device
 
 
 def test_set_deterministic_switches_the_library_and_torch():
+    """The library's flag is one atomic (td_set_deterministic / td_get_deterministic: no environment access on the launch path); torch's
+    own setting is restored to what it WAS, not forced off, and importing the package touches neither."""
     import tubedetr_amd
 
+    assert not torch.are_deterministic_algorithms_enabled()  # importing the package changed nothing
     try:
         tubedetr_amd.set_deterministic(True)
-        assert os.environ["TD_DETERMINISTIC"] == "1" and torch.are_deterministic_algorithms_enabled()
+        assert tubedetr_amd.is_deterministic() and torch.are_deterministic_algorithms_enabled()
     finally:
         tubedetr_amd.set_deterministic(False)
-    assert os.environ["TD_DETERMINISTIC"] == "0" and not torch.are_deterministic_algorithms_enabled()
+    assert not tubedetr_amd.is_deterministic() and not torch.are_deterministic_algorithms_enabled()
+    # a setting the user made is given back
+    torch.use_deterministic_algorithms(True, warn_only=False)
+    try:
+        tubedetr_amd.set_deterministic(True)
+        tubedetr_amd.set_deterministic(False)
+        assert torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled()
+    finally:
+        torch.use_deterministic_algorithms(False)

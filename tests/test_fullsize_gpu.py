@@ -29,6 +29,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+TIED_ROWS_ALLOWED_FULL = {}  # (configuration, key) -> rows whose argmax may be the oracle's runner-up; empty: none has ever been observed
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOGIT_TOL = 1e-3
 FULL = {
@@ -139,7 +141,9 @@ def test_fp32_mode_matches_oracle_at_full_size(name):
                 flips += int(differ.sum())
                 gaps += [float(g_) for g_ in gap.flatten()]
         rec["argmax_rows_" + key], rec["argmax_tied_rows_" + key], rec["argmax_tied_gaps_" + key] = rows, flips, sorted(gaps)[-8:]
-        assert flips <= 0.01 * rows, (name, key, flips, rows)
+        # recorded constant: NO row of any full-size configuration has needed the runner-up rule (profiles/r0*_fullsize_report.json); one that does
+        # is to be looked at, not absorbed
+        assert flips <= TIED_ROWS_ALLOWED_FULL.get((name, key), 0), (name, key, flips, rows, gaps[-8:])
     assert sorted(ld) == sorted(ld_ref) and len(ld) == 24
     worst = 0.0
     for k_ in ld_ref:
@@ -216,13 +220,65 @@ def test_bf16_gradients_follow_fp32_mode_at_full_size(name):
     # ~60x fewer rows than cfg3, so the bf16 rounding noise of the individual terms averages out ~8x less: measured global
     # cosine 0.981 .. 0.992 / norm ratio 0.90 .. 0.94 over two runs, worst parameter (layer2.0.conv2) 0.845 / 16 % - bounded with
     # margin at those values.
-    g_cos, g_norm, p_cos, p_norm = (0.97, 0.13, 0.80, 0.22) if name == "cfg1" else (0.995, 0.03, 0.97, 0.15)
+    g_cos, g_norm, p_cos, p_norm = (0.97, 0.13, 0.82, 0.22) if name == "cfg1" else (0.995, 0.03, 0.97, 0.15)  # (cfg1's 0.82: free-running runs measured 0.845 and 0.899; the deterministic test below pins 0.8994 - 0.03)
     assert rec["global_cosine"] >= g_cos and abs(rec["global_norm_ratio"] - 1.0) <= g_norm, rec
     bad = [(s[0], s[1], s[2], s[4]) for s in stats if (s[1] < p_cos or abs(s[2]) > p_norm) and s[4] > 0.25 * med]
     # (small gradients on the absolute scale: 8 % of the median norm - the --no_fast start/end head measured 4.4 % and 5.8 % in two
     #  runs of the same code: its gradient is a difference of near-equal softmax terms, chaotic under bf16 rounding)
     bad += [(s[0], s[1], s[2], s[4]) for s in stats if s[4] <= 0.25 * med and s[3] * s[4] > 0.08 * med * (3.0 if name == "cfg1" else 1.0)]
     assert not bad, bad[:10]
+
+
+CFG1_DET_MIN_COSINE = 0.87  # worst per-parameter cosine (bf16 vs fp32) of cfg1 in deterministic mode: measured 0.8994 (layer2.0.conv2, bit-identical over two runs) - 0.03
+
+
+def test_cfg1_bf16_gradient_direction_is_reproducible_in_deterministic_mode():
+    """cfg1's worst per-parameter cosine between the bf16 and the fp32 gradient (layer2.0.conv2) measured 0.845 and 0.899 in two runs of the
+    same code.  If that wander is the arrival order of the fp32 atomics that combine the split weight-gradient /
+    LayerNorm / bias reductions, it must vanish in deterministic mode (one sequential reduction per output element): two bf16 backward
+    passes are then BIT-IDENTICAL, and the cosine against the (deterministic) fp32 gradient is one number - bounded here at that number
+    minus 0.03 instead of the free-running test's 0.80."""
+    import tubedetr_amd
+    from tubedetr_amd.harness import batch_to, forward_step
+
+    c = FULL["cfg1"]
+    cfg, sd, batch = _inputs(c)
+    dev = torch.device("cuda:0")
+    model, criterion, weight_dict, Tok = _model(cfg, sd, torch.float32)
+    model.transformer.tokenizer = Tok(batch["input_ids"], batch["attention_mask"])
+    b_dev = batch_to(batch, dev)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def grads(dt):
+        model.set_compute_dtype(dt)
+        for p in params:
+            p.grad = None
+        loss, _, _, _ = forward_step(model, criterion, weight_dict, b_dev)
+        loss.backward()
+        torch.cuda.synchronize()
+        return [None if p.grad is None else p.grad.detach().clone() for p in params]
+
+    tubedetr_amd.set_deterministic(True)
+    try:
+        g32 = grads(torch.float32)
+        g16a = grads(torch.bfloat16)
+        g16b = grads(torch.bfloat16)
+    finally:
+        tubedetr_amd.set_deterministic(False)
+    differing = [n for n, a, b in zip(names, g16a, g16b) if a is not None and not torch.equal(a, b)]
+    assert not differing, ("bf16 gradients differ between two deterministic runs", differing[:8])
+    norms = torch.stack([g.double().norm() for g in g32 if g is not None])
+    floor, med = 1e-6 * norms.max().item(), norms.median().item()
+    cos = []
+    for n, a, b in zip(names, g32, g16a):
+        if a is None or a.double().norm().item() <= max(floor, 0.25 * med):
+            continue
+        ad, bd = a.double().flatten(), b.double().flatten()
+        cos.append(((ad @ bd).item() / (ad.norm().item() * bd.norm().item() + 1e-300), n))
+    cos.sort()
+    _report("bf16_vs_fp32/cfg1_deterministic", {"worst_cosine": [(n, round(v, 5)) for v, n in cos[:6]], "checked_parameters": len(cos)})
+    assert cos[0][0] >= CFG1_DET_MIN_COSINE, cos[:6]
 
 
 # ---- (3) full-size backward against the oracle's autograd ----------------------------------------------------------
@@ -343,6 +399,51 @@ def test_bench_batch_fp32_forward_matches_oracle_per_clip():
         assert rel < 1e-3, (k_, ld[k_].item(), want)
     rec["max_rel_err_losses"] = worst
     _report(f"fp32_vs_oracle/cfg3_x{BENCH_CLIPS}_clips", rec)
+
+
+def test_bench_batch_of_16_distinct_clips_fp32_forward_matches_oracle():
+    """The benchmarked launch geometry (16 clips of cfg3 per step) fed with 16 DIFFERENT clips - the test above tiles 4 distinct clips 4 x -
+    in the exact-fp32 mode against the oracle's forward of every clip, final decoder layer: logits and attention weights within 1e-3, attention
+    argmax exact on every row the oracle itself decides by more than 4e-5, the 24 losses of the batch = the mean of the per-clip losses.
+    (Cost: 16 oracle passes of the T = 100 clip on the host cores, nothing shared between them.)"""
+    from tubedetr_amd.harness import batch_to, forward_step
+
+    c = FULL["cfg3"]
+    seeds = [CLIP_SEED + 100 + i for i in range(BENCH_CLIPS)]
+    refs = []
+    for s_ in seeds:
+        cfg, sd, batch, out_ref, ld_ref = _oracle_forward(c, s_)
+        refs.append((batch, {k_: out_ref[k_].clone() for k_ in ("pred_boxes", "pred_sted", "weights", "ca_weights")}, ld_ref))
+        _ORACLE_ENC.pop((c["T"], c["res"], c["k"], c["L"], c["fast"], s_), None)  # (the encode of a clip used once: not kept)
+    batch = _stitch([r[0] for r in refs])
+    torch.cuda.empty_cache()
+    model, criterion, weight_dict, Tok = _model(cfg, sd, torch.float32)
+    model.transformer.tokenizer = Tok(batch["input_ids"], batch["attention_mask"])
+    with torch.no_grad():
+        _, ld, out, _ = forward_step(model, criterion, weight_dict, batch_to(batch, torch.device("cuda:0")))
+    torch.cuda.synchronize()
+    rec = {"clips": BENCH_CLIPS, "distinct": True}
+    for key in ("pred_boxes", "pred_sted", "weights", "ca_weights"):
+        got = _per_clip(out[key].float().cpu(), BENCH_CLIPS)
+        err, agree = 0.0, True
+        for pos in range(BENCH_CLIPS):
+            b_ = refs[pos][1][key].reshape(got[pos].shape)
+            err = max(err, (got[pos] - b_).abs().max().item())
+            if key in ("weights", "ca_weights") and b_.shape[-1] > 1:
+                top2 = b_.topk(2, dim=-1).values
+                decided = (top2[..., 0] - top2[..., 1]) > 4e-5
+                agree = agree and bool((got[pos].argmax(-1) == b_.argmax(-1))[decided].all())
+        rec["max_err_" + key] = err
+        assert err < LOGIT_TOL, (key, err)
+        assert agree, key
+    worst = 0.0
+    for k_ in refs[0][2]:
+        want = sum(r[2][k_].item() for r in refs) / BENCH_CLIPS
+        rel = abs(ld[k_].item() - want) / max(1.0, abs(want))
+        worst = max(worst, rel)
+        assert rel < 1e-3, (k_, ld[k_].item(), want)
+    rec["max_rel_err_losses"] = worst
+    _report(f"fp32_vs_oracle/cfg3_x{BENCH_CLIPS}_distinct_clips", rec)
 
 
 @pytest.mark.parametrize("n_clips", [BENCH_CLIPS, 8])  # 16: the benchmark's batch (separate slow / fast trunk passes); 8: the largest batch whose

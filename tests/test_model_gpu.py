@@ -31,17 +31,24 @@ def _load(model, cfg, seed):
     return sd
 
 
+# Rows in which the HIP argmax may differ from the reference's because the reference itself holds its maximum more than once (to within 1e-6):
+# a RECORDED constant per fixture, not an open hatch - anything not listed is 0, and a fixture that needs more than its constant fails.
+TIED_ROWS_ALLOWED = {"v_notime_T6-5_res64_k2": 12}
+
+
 def _same_argmax(got, ref, tie=1e-6):
     """Attention indices bit-exact - except in rows whose maximum the reference itself holds more than once (to within ``tie``): there
     the index is decided by the last bit of either implementation.  It happens in exactly one fixture: without time encodings
     (--no_time_embed) all time queries of a clip are identical in the first decoder layer, its temporal self-attention is uniform
-    (1 / t in every column) and the reference's own argmax over such a row is 0, 2 or 4 depending on the row."""
+    (1 / t in every column) and the reference's own argmax over such a row is 0, 2 or 4 depending on the row.
+    Returns (every row equal or tied, number of rows that needed the tie rule)."""
     ga, ra = got.argmax(-1), ref.argmax(-1)
     ref_at_got = np.take_along_axis(ref, ga[..., None], -1)[..., 0]
-    return bool(((ga == ra) | (ref.max(-1) - ref_at_got <= tie)).all())
+    tied = (ga != ra) & (ref.max(-1) - ref_at_got <= tie)
+    return bool(((ga == ra) | tied).all()), int(tied.sum())
 
 
-def _compare_with_golden(model, criterion, weight_dict, batch, gold):
+def _compare_with_golden(model, criterion, weight_dict, batch, gold, fixture=None):
     from tubedetr_amd.harness import FixedTokenizer, batch_to, forward_step
 
     dev = torch.device("cuda:0")
@@ -68,11 +75,15 @@ def _compare_with_golden(model, criterion, weight_dict, batch, gold):
         got = np.stack([cpu(o[key]) for o in layers])
         err = np.abs(got - gold["out." + key]).max()
         assert err < LOGIT_TOL, (key, err)
+    n_tied = 0
     for key in ("weights", "ca_weights"):  # attention indices bit-exact
         if "out." + key not in gold.files:
             continue
         got = np.stack([cpu(o[key]) for o in layers])
-        assert _same_argmax(got, gold["out." + key]), key
+        ok, n = _same_argmax(got, gold["out." + key])
+        assert ok, key
+        n_tied += n
+    assert n_tied <= TIED_ROWS_ALLOWED.get(fixture, 0), (fixture, n_tied, "rows decided by the tie rule: more than the recorded constant")
 
     names = sorted(ld)
     assert names == list(gold["loss.names"])
@@ -102,7 +113,7 @@ def test_model_matches_reference_golden_fp32(name):
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     model, criterion, weight_dict = _build(cfg)
     _load(model, cfg, WEIGHT_SEED)
-    params = _compare_with_golden(model, criterion, weight_dict, synthetic_batch(**bkw), gold)
+    params = _compare_with_golden(model, criterion, weight_dict, synthetic_batch(**bkw), gold, fixture=name)
     unused = [k for k, p in params.items() if p.requires_grad and p.grad is None]
     assert all("pooler" in k for k in unused), unused
 
@@ -128,7 +139,7 @@ def test_ablation_flags_match_reference_golden_fp32(name):
     assert list(sd0.keys()) == [str(k) for k in gold["meta.state_keys"]]
     assert sorted(k for k, p in model.named_parameters() if p.requires_grad) == [str(k) for k in gold["meta.trainable"]]
     model.load_state_dict(fill_state({k: tuple(v.shape) for k, v in sd0.items()}, WEIGHT_SEED), strict=True)
-    params = _compare_with_golden(model, criterion, weight_dict, synthetic_batch(**bkw), gold)
+    params = _compare_with_golden(model, criterion, weight_dict, synthetic_batch(**bkw), gold, fixture=name)
     no_grad = sorted(k for k, p in params.items() if p.requires_grad and p.grad is None)
     assert no_grad == [str(k) for k in gold["meta.no_grad"]]  # what the variant leaves out of its graph (noslow: the slow trunk + encoder)
 
@@ -193,6 +204,42 @@ def test_model_bf16_close_to_fp32_and_trains():
     for k, p in model.named_parameters():
         if p.requires_grad and "pooler" not in k:
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+def test_dedupe_is_proven_from_the_inputs_not_flagged():
+    """TubeDETR._slow_is_strided_fast: the slow clip as an index list over the very buffer the fast frames are, with the host copy of that
+    list equal to 0, k, 2k, ... of every video (what data.ClipPipeline hands over) is a proof; anything else - another buffer, a shifted or
+    permuted list, no host copy, a duration that does not match - is not, and then both passes run."""
+    import tubedetr_amd
+    from tubedetr_amd.models import build_model
+    from tubedetr_amd.util.misc import FrameSources, NestedTensor
+
+    dev = torch.device("cuda:0")
+    model, _, _ = build_model(tubedetr_amd.default_args(stride=4, resnet_layers=(1, 1, 1, 1), enc_layers=1, dec_layers=1))
+    assert model.slow_frames_are_strided_fast is None  # the default: prove it per call
+    video = torch.zeros(14, 3, 32, 32, dtype=torch.uint8, device=dev)
+    durations = [8, 6]
+    good = (0, 4, 8, 12)
+
+    def nt(x, n):
+        return NestedTensor(x, torch.zeros(n, 32, 32, dtype=torch.bool, device=dev))
+
+    def slow(base, idx, host):
+        return nt(FrameSources([(base, torch.tensor(idx, dtype=torch.int32, device=dev))], None, [host]), len(idx))
+
+    fast = nt(video, 14)
+    assert model._slow_is_strided_fast(slow(video, good, good), fast, durations)
+    assert model._slow_is_strided_fast(slow(video, good, good), nt(FrameSources([(video, None)]), 14), durations)
+    assert not model._slow_is_strided_fast(slow(video.clone(), good, good), fast, durations)          # equal pixels, another buffer: not provable
+    assert not model._slow_is_strided_fast(slow(video, good, None), fast, durations)                   # no host copy of the list
+    assert not model._slow_is_strided_fast(slow(video, (0, 4, 9, 13), (0, 4, 9, 13)), fast, durations)  # not every 4th frame of the second video
+    assert not model._slow_is_strided_fast(slow(video, (4, 0, 8, 12), (4, 0, 8, 12)), fast, durations)  # permuted
+    assert not model._slow_is_strided_fast(slow(video, good, good), fast, [7, 7])                      # other durations: 0, 4, 7, 11 expected
+    assert not model._slow_is_strided_fast(nt(video[::4], 4), fast, durations)                         # a plain tensor: nothing to reason about
+    model.slow_frames_are_strided_fast = False
+    assert not model._slow_is_strided_fast(slow(video, good, good), fast, durations)                   # switched off: the reference's two passes
+    model.slow_frames_are_strided_fast = True
+    assert model._slow_is_strided_fast(nt(video[::4], 4), fast, durations)                             # the caller vouches
 
 
 def test_dedupe_slow_frames_is_exact(monkeypatch):

@@ -21,6 +21,23 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+# The kernels with hand-counted s_waitcnt sequences (conv_gemm_big8*, pw_resident2, pw_chain2: inline-asm loads / LDS-DMA whose completion the
+# compiler does not track) were validated - bit for bit against their uncounted forms, tests/test_bench_shapes_gpu.py - with THIS compiler.  A
+# different one may schedule its own scalar / vector loads into those sequences: the build goes on, loudly; re-run the GPU tests before trusting it.
+HIPCC_VALIDATED = "roc-7.2.0"
+
+
+def _check_compiler(hipcc: str) -> None:
+    try:
+        v = subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception as e:  # noqa: BLE001
+        v = repr(e)
+    if HIPCC_VALIDATED not in v:
+        print(f"[tubedetr_amd.build] WARNING: hipcc is not the validated {HIPCC_VALIDATED} toolchain ({v.splitlines()[0] if v else 'unknown'}): "
+              "run `pytest tests -m gpu` (test_persistent_256_row_kernel_equals_one_tile_per_workgroup, test_chained_conv3_conv1_pair_at_bench_shape) before use",
+              file=sys.stderr, flush=True)
+
+
 def _stale(out: str, deps) -> bool:
     if not os.path.exists(out):
         return True
@@ -31,6 +48,7 @@ def _stale(out: str, deps) -> bool:
 def build_lib(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
+    _check_compiler(hipcc)
     headers = [os.path.join(CSRC, "td_common.h"), os.path.join(os.path.dirname(HERE), "include", "tubedetr_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:

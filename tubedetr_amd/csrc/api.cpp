@@ -58,7 +58,27 @@ void prof_set_bytes(double bytes) {
   if (t_cur >= 0 && t_cur < (long)g_recs.size()) g_recs[t_cur].bytes = bytes;
 }
 
+// the one mode switch of the library: -1 = not yet seeded from the environment
+static std::atomic<int> g_det{-1};
+bool deterministic() {
+  int v = g_det.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("TD_DETERMINISTIC");
+    v = (e && e[0] == '1') ? 1 : 0;
+    int expected = -1;
+    g_det.compare_exchange_strong(expected, v, std::memory_order_relaxed);
+    v = g_det.load(std::memory_order_relaxed);
+  }
+  return v == 1;
+}
+
 }  // namespace td
+
+extern "C" int td_set_deterministic(int on) {
+  td::g_det.store(on ? 1 : 0, std::memory_order_relaxed);
+  return TD_OK;
+}
+extern "C" int td_get_deterministic(void) { return td::deterministic() ? 1 : 0; }
 
 extern "C" int td_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(td::g_prof_mu);
@@ -110,4 +130,4 @@ extern "C" int td_prof_dump(const char* path) {
 }
 
 extern "C" const char* td_last_error(void) { return td::g_err; }
-extern "C" int td_abi_version(void) { return 9; }  // 9 (round 6): td_pw_chain2
+extern "C" int td_abi_version(void) { return 9; }  // 9 (round 6): td_pw_chain2, td_set_deterministic / td_get_deterministic

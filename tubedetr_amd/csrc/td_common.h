@@ -40,13 +40,11 @@ __device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint32_t
   return ctr ? mix32(mix32(seed ^ 0xA511E9B3u) + ctr[0] * 0xC2B2AE3Du) : seed;
 }
 
-// TD_DETERMINISTIC=1 (read at every call: a test may switch it): reductions that are normally split over workgroups and combined
-// with fp32 atomics - weight gradients over M, LayerNorm's dgamma / dbeta, bias column sums - run as ONE sequential reduction per
-// output element, so that two runs of the same step are bit-identical (the exact-fp32 parity mode's regression anchor; slow).
-inline bool deterministic() {
-  const char* e = getenv("TD_DETERMINISTIC");
-  return e && e[0] == '1';
-}
+// Deterministic parity mode (td_set_deterministic; seeded ONCE from TD_DETERMINISTIC=1 in the environment): reductions that are normally
+// split over workgroups and combined with fp32 atomics - weight gradients over M, LayerNorm's dgamma / dbeta, bias column sums - run as
+// ONE sequential reduction per output element, so that two runs of the same step are bit-identical (the exact-fp32 parity mode's
+// regression anchor; slow).  One atomic flag in api.cpp: no getenv() on the launch path (another thread may be changing the environment).
+bool deterministic();
 
 // bench-only launch timing (api.cpp)
 bool prof_on();

@@ -86,7 +86,7 @@ class ClipPipeline:
             ev.record(self.copy_stream)
         slot[2] = ev
         return {"event": ev, "video": vid_dev, "mask": msk_dev, "slow_index": idx_dev, "valid_hw": vhw_dev, "durations": durations, "input_ids": ids_dev,
-                "attention_mask": att_dev, "target_boxes": box_dev, "inter_idx": [list(x) for x in inter_idx], "n_slow": len(slow_idx)}
+                "attention_mask": att_dev, "target_boxes": box_dev, "inter_idx": [list(x) for x in inter_idx], "n_slow": len(slow_idx), "slow_index_host": tuple(slow_idx)}
 
     def collect(self, ticket: dict) -> dict:
         """Batch dict for ``harness.forward_step``; the current stream waits for the ticket's copies (no host sync)."""
@@ -97,7 +97,7 @@ class ClipPipeline:
                 ticket[k_].record_stream(cur)  # allocated on the copy stream, consumed on the compute stream
         video, mask, idx, vhw = ticket["video"], ticket["mask"], ticket["slow_index"], ticket["valid_hw"]
         return {
-            "frames": FrameSources([(video, idx)], [vhw]),   # slow clip: an index list over the same pixels
+            "frames": FrameSources([(video, idx)], [vhw], [ticket["slow_index_host"]]),   # slow clip: an index list over the same pixels (+ its host copy: the model proves slow = fast[::k] from it)
             "frames_mask": mask[idx.long()],
             "frames_fast": FrameSources([(video, None)], [vhw]) if vhw is not None else video,  # uint8; normalised by the trunk's input kernel
             "fast_mask": mask,

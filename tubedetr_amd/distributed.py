@@ -27,7 +27,7 @@ def _all_reduce(t: torch.Tensor, op, group=None) -> None:
     """dist.all_reduce; with the `gloo` backend (CPU tests, single-GPU debugging with several ranks on one device) a
     device buffer is moved through the host, since gloo builds without device support reject CUDA tensors."""
     if t.is_cuda and dist.get_backend(group) == "gloo":
-        host = t.cpu()
+        host = t.detach().contiguous().cpu()  # (gloo rejects non-contiguous tensors; .cpu() alone keeps the strides of a view)
         dist.all_reduce(host, op=op, group=group)
         t.copy_(host)
     else:
@@ -38,7 +38,7 @@ def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> None:
     """dist.broadcast in place (what DistributedDataParallel's constructor does with rank 0's parameters and buffers, main.py:372-376);
     device tensors go through the host under `gloo`, like ``_all_reduce``."""
     if t.is_cuda and dist.get_backend(group) == "gloo":
-        host = t.cpu()
+        host = t.detach().contiguous().cpu()
         dist.broadcast(host, src, group=group)
         if dist.get_rank(group) != src:
             t.copy_(host)
@@ -58,16 +58,11 @@ def _reduce_scatter_all_gather(buf: torch.Tensor, shard: torch.Tensor, op, group
     works = []
     host = buf.is_cuda and dist.get_backend(group) == "gloo"  # (CPU tests with a device buffer: staged through the host, synchronous)
     if host:
-        hb = buf.cpu()
+        hb = buf.detach().contiguous().cpu()
         _reduce_scatter_all_gather(hb, torch.empty(max(1, m // world), dtype=hb.dtype), op, group)
         buf.copy_(hb)
         return None
-    if m and not (hasattr(dist, "reduce_scatter_tensor") and hasattr(dist, "all_gather_into_tensor")):
-        import warnings
-
-        warnings.warn("torch.distributed has no reduce_scatter_tensor / all_gather_into_tensor: the rs_ag exchange falls back to all_reduce")
-        w = dist.all_reduce(buf, op=op, group=group, async_op=async_op)
-        return [w] if async_op else None
+    assert has_rs_ag(), "reduce_scatter_tensor / all_gather_into_tensor missing (FlatGradAllReducer falls back to all_reduce at construction)"
     if m:
         sh = shard[: m // world]
         w1 = dist.reduce_scatter_tensor(sh, buf[:m], op=op, group=group, async_op=async_op)
@@ -77,6 +72,10 @@ def _reduce_scatter_all_gather(buf: torch.Tensor, shard: torch.Tensor, op, group
     if n - m:
         works.append(dist.all_reduce(buf[m:], op=op, group=group, async_op=async_op))
     return works if async_op else None
+
+
+def has_rs_ag() -> bool:
+    return hasattr(dist, "reduce_scatter_tensor") and hasattr(dist, "all_gather_into_tensor")
 
 
 class FlatGradAllReducer:
@@ -110,6 +109,12 @@ class FlatGradAllReducer:
                 self.runs.append([off, off + p.numel(), lt])
             off += p.numel()
         assert collective in ("all_reduce", "rs_ag")
+        if collective == "rs_ag" and not has_rs_ag():
+            # decided ONCE, here, so that whoever reports ``self.collective`` (bench.py's JSON line) reports what actually runs
+            import warnings
+
+            warnings.warn("torch.distributed has no reduce_scatter_tensor / all_gather_into_tensor: the gradient exchange uses all_reduce")
+            collective = "all_reduce"
         self.collective = collective  # "rs_ag": reduce-scatter + all-gather on the flat buffer instead of one all-reduce (same result)
         self._shard = None  # rs_ag scratch: ceil(numel / world) elements, allocated at first use (never on the host-staged gloo path)
         self._pending: list = []

@@ -88,10 +88,12 @@ class TubeDETR(nn.Module):
         self._sine_pos = isinstance(pe, PositionEmbeddingSine)
         if self._sine_pos:
             transformer.sine_pos = (pe.num_pos_feats, float(pe.temperature))
-        # Opt-in (bench.py / callers whose data pipeline guarantees it, like datasets/vidstg.py:250-251 does): the slow
-        # frames ARE the fast frames [::stride] of each video.  The trunk then runs once over the fast frames only
-        # (slow ones first, so backward still walks a contiguous prefix) instead of recomputing the same pixels.
-        self.slow_frames_are_strided_fast = False
+        # "The slow frames ARE the fast frames [::stride] of each video" (datasets/vidstg.py:250-251): the trunk then need not compute
+        # those pixels twice (slow ones first, so backward still walks a contiguous prefix).  None (default) = PROVEN per call from the
+        # inputs (``_slow_is_strided_fast``: the slow clip is an index list over the very buffer the fast frames are, and that list is
+        # 0, k, 2k, ... of every video) - SURVEY 8a' "dead work the build may skip"; True = the caller vouches for inputs the model
+        # cannot see through (two separate tensors with equal pixels); False = always run both passes as the reference does.
+        self.slow_frames_are_strided_fast = None
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dt: torch.dtype):
@@ -108,6 +110,31 @@ class TubeDETR(nn.Module):
         rows = feat.permute(0, 2, 3, 1).reshape(n * h * w, c)
         y = Fk.linear(rows, self.input_proj.weight.view(self.input_proj.out_channels, c), self.input_proj.bias)
         return y.view(n, h, w, -1).permute(0, 3, 1, 2)
+
+    def _slow_is_strided_fast(self, samples, samples_fast, durations) -> bool:
+        """Structural proof, no device traffic: samples.tensors is a FrameSources of ONE part (base, index) whose base IS samples_fast's
+        frame tensor (same storage pointer, shape and dtype) and whose index list - known on the host, FrameSources.index_host - is
+        exactly 0, k, 2k, ... within every video of ``durations``."""
+        flag = self.slow_frames_are_strided_fast
+        if flag is not None:
+            return bool(flag)
+        xs, xf = samples.tensors, samples_fast.tensors
+        if not isinstance(xs, FrameSources) or len(xs.parts) != 1 or xs.index_host[0] is None:
+            return False
+        if isinstance(xf, FrameSources):
+            if len(xf.parts) != 1 or xf.parts[0][1] is not None:
+                return False
+            fast = xf.parts[0][0]
+        else:
+            fast = xf
+        base = xs.parts[0][0]
+        if not (torch.is_tensor(fast) and fast.data_ptr() == base.data_ptr() and fast.shape == base.shape and fast.dtype == base.dtype and fast.stride() == base.stride()):
+            return False
+        want, off = [], 0
+        for d in durations:
+            want += list(range(off, off + d, self.stride))
+            off += d
+        return off == fast.shape[0] and tuple(want) == xs.index_host[0]
 
     def _dedupe_index(self, durations, device):
         """perm: fast-frame indices with each video's slow frames (0, k, 2k, ...) first, in the slow batch order;
@@ -172,7 +199,7 @@ class TubeDETR(nn.Module):
         # sine encoding: the transformer forms the positional operand from the (original) pad mask itself, see Joiner.forward
         want_pos = not self._sine_pos
         merged = self._joiner and self.fast and samples_fast is not None and torch.is_grad_enabled() and samples_fast.tensors.shape[1:] == samples.tensors.shape[1:]
-        dedupe = merged and self.slow_frames_are_strided_fast and sum(durations) == samples_fast.tensors.shape[0]
+        dedupe = merged and sum(durations) == samples_fast.tensors.shape[0] and self._slow_is_strided_fast(samples, samples_fast, durations)
         if merged:
             # a pass that keeps activations for backward holds at most ResNetBody.max_frames frames (32-bit tensor addressing: 1 083
             # bf16 frames at res 352); a larger batch runs the slow frames (kept for backward) and the no-grad fast frames as two

@@ -99,8 +99,15 @@ class FrameSources:
     that hold pixels when videos of different sizes were padded to a common H x W as raw uint8; the input kernel writes
     exactly 0 outside, which is what padding the already NORMALISED frames with zeros gives (util/misc.py:158-170)."""
 
-    def __init__(self, parts, valid=None):
+    def __init__(self, parts, valid=None, index_host=None):
+        """``index_host`` (optional, one entry per part): the HOST copy of a part's index list (a tuple of ints) when the producer built the
+        device index from one - it lets a consumer reason about WHICH frames a part names without a device-to-host copy (TubeDETR proves
+        "the slow clip is every k-th fast frame of the same buffer" from it and then skips recomputing those frames)."""
         self.parts = [(t, (i.to(torch.int32).contiguous() if i is not None else None)) for t, i in parts]
+        self.index_host = [None] * len(self.parts) if index_host is None else [(tuple(int(v) for v in h) if h is not None else None) for h in index_host]
+        assert len(self.index_host) == len(self.parts)
+        for (_, i), h in zip(self.parts, self.index_host):
+            assert h is None or (i is not None and len(h) == i.numel()), "index_host: the host copy of that part's index list"
         self.valid = [None] * len(self.parts) if valid is None else [(v.to(torch.int32).contiguous() if v is not None else None) for v in valid]
         assert len(self.valid) == len(self.parts)
         for (t, _), v in zip(self.parts, self.valid):
@@ -127,7 +134,7 @@ class FrameSources:
 
     def to(self, device, non_blocking: bool = False):
         return FrameSources([(t.to(device, non_blocking=non_blocking), (i.to(device, non_blocking=non_blocking) if i is not None else None)) for t, i in self.parts],
-                            [(v.to(device, non_blocking=non_blocking) if v is not None else None) for v in self.valid])
+                            [(v.to(device, non_blocking=non_blocking) if v is not None else None) for v in self.valid], self.index_host)
 
     def materialize(self) -> torch.Tensor:
         """The concatenated (N, 3, H, W) tensor the sources describe (tests / fallbacks); raw values - the zeroing of
