@@ -175,6 +175,26 @@ def test_persistent_256_row_kernel_equals_one_tile_per_workgroup():
     assert outs[0] == outs[1], "\n".join(f"{a}  |  {b}" for a, b in zip(*outs))
 
 
+def test_four_wavefront_weight_gradient_tiles_equal_the_sixteen_wavefront_ones():
+    """conv_wgrad_wide4_batch_kernel (256 x 256 tiles on four wavefronts with 128 x 128 wave tiles, hand-allocated accumulator file, counted vmcnt on a
+    four-stage ring) against conv_wgrad_wide_batch_kernel (sixteen wavefronts; TD_WGRAD_WIDE4=0) in deterministic mode - one work item per output
+    tile, the same summation order per element in both: bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_wgrad4_probe.py")
+    outs = []
+    for knob in ("1", "0"):
+        env = dict(os.environ, TD_WGRAD_WIDE4=knob)
+        r = subprocess.run([sys.executable, probe], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if len(ln.split()) >= 2 and len(ln.split()[-1]) == 64]
+        assert len(lines) == 5, r.stdout
+        outs.append(lines)
+    assert outs[0] == outs[1], "\n".join(f"{a}  |  {b}" for a, b in zip(*outs))
+
+
 def _wgrad_ref(gy, x, R, stride, pad):
     """dW [Co, Ci, R, R] = sum over output pixels of gy^T x(shifted): fp32 matmuls over the same rows (NHWC operands)."""
     N, H, W, Ci = x.shape

@@ -2033,6 +2033,240 @@ __global__ __launch_bounds__(1024, 1) void conv_wgrad_wide_batch_kernel(const Wg
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 weight-gradient tiles on FOUR wavefronts with 128 x 128 wave tiles (round 6; the 256-channel / K >= 256 jobs of the batched launch:
+// most of the trunk's weight-gradient FLOPs).  Why: both operands of dW = g^T x are reduction-major in HBM, so every MFMA fragment is a pair
+// of transposing LDS reads (ds_read_b64_tr_b16), and those sustain 85 - 119 B/clk per CU here (round 4).  A 64 x 64 wave tile (the sixteen-
+// wavefront body above) needs 16 such reads per 16 MFMAs = 128 B/clk at the full matrix rate - the kernel sat at mfma_util 0.39.  A 128 x 128
+// wave tile reads 16 fragments (32 reads) per 64 MFMAs: 64 B/clk.  Price: one wavefront per SIMD (256 accumulator AGPRs, allocated by hand as in
+// chain.hip), so the next stage's fragments are read UNDER this stage's MFMAs into a second register set - two fragments behind every eight MFMAs.
+// Stages are 32 reduction rows (one K-step; 4 sub-tiles x 8 KiB) on a ring of four: the barrier at the top of stage s publishes stage s + 1
+// (whose fragments are read during stage s) and frees the buffer of stage s - 1 for stage s + 3.  Same LDS image per sub-tile and the same
+// summation order per output element as the sixteen-wavefront body: results are bit-identical to it for unsplit jobs.
+template <bool PW>
+__device__ __forceinline__ void wgrad_wide4_body(const WgradParams& p, const int bx, const int by, const int bz, char* r0_, char* r1_, char* r2_, char* r3_) {
+  constexpr int ES = 2, MK = 32, ROWB = 256, SUB = MK * ROWB;  // one 128-column sub-tile of a stage = 8 KiB; a stage = g0 g1 x0 x1
+  constexpr uint32_t OOB = 0xFFFFFFF0u;
+  const td_conv_desc& d = p.d;
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int co0 = bx * 256, kk0 = by * 256;
+  const int mbeg = bz * p.mper;
+  const int mend = min(p.M, mbeg + p.mper);
+  if (mbeg >= mend) return;
+  const int HoWo = d.Ho * d.Wo;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  asm volatile("" ::: "a255");  // the whole accumulator file is this kernel's: acc(i, j) = a[4 (8 i + j) .. + 4], i = output-channel fragment, j = k fragment
+
+  // DMA bookkeeping: piece e (0, 1) of this wavefront fills rows (e * 4 + wave) * 4 + lane / 16 of every sub-tile, LDS chunk lane % 16
+  const int c16 = lane & 15;
+  int mcur[2], rn[2], rho[2], rwo[2], col[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int drow = (e * 4 + wave) * 4 + (lane >> 4);
+    col[e] = ((((c16 >> 1) ^ wg_swz<ES>(drow)) << 1) | (c16 & 1)) * 8;  // logical column of this lane's chunk
+    mcur[e] = mbeg + drow;
+    rn[e] = mcur[e] / HoWo;
+    rho[e] = (mcur[e] - rn[e] * HoWo) / d.Wo;
+    rwo[e] = mcur[e] - rn[e] * HoWo - rho[e] * d.Wo;
+  }
+  bool g_in[2], x_in[2];
+  int g_c0[2], x_c0[2], x_r[2], x_s[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    g_c0[s_] = co0 + s_ * 128;
+    g_in[s_] = g_c0[s_] < d.Nc;
+    const int kk = kk0 + s_ * 128;
+    x_in[s_] = kk < p.K;
+    x_r[s_] = 0; x_s[s_] = 0; x_c0[s_] = kk;
+    if (!PW && d.R * d.S > 1) {
+      const int tap = kk / d.C;
+      x_c0[s_] = kk - tap * d.C;
+      x_r[s_] = tap / d.S;
+      x_s[s_] = tap - x_r[s_] * d.S;
+    }
+  }
+  const int dN = MK / HoWo, dH = (MK - dN * HoWo) / d.Wo, dW = MK - dN * HoWo - dH * d.Wo;
+  // 8 pieces per stage, BRANCH-FREE (all-ones / all-zeros masks, no bool select the compiler could turn into divergent control flow: a piece
+  // issued once per side of a branch would break the counted waits and leave LDS slots unwritten).  Rows past the slice, columns past the
+  // matrix and out-of-image taps: out-of-range offset = zero fill, no traffic.
+  auto neg = [](int v) -> uint32_t { return (uint32_t)(v >> 31); };  // all ones if v < 0
+  uint32_t gm[2], xm[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    gm[s_] = g_in[s_] ? 0xFFFFFFFFu : 0u;
+    xm[s_] = x_in[s_] ? 0xFFFFFFFFu : 0u;
+  }
+  auto issue_stage = [&](char* st) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int m = mcur[e];
+      const uint32_t okm = neg(m - mend);  // m < mend
+      const uint32_t grow = ((uint32_t)m * (uint32_t)p.ldg + (uint32_t)col[e]) * ES;
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const uint32_t k_ = okm & gm[s_];
+        const uint32_t og = ((grow + (uint32_t)g_c0[s_] * ES) & k_) | (OOB & ~k_);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(st + s_ * SUB + (e * 4 + wave) * 1024), 16, og, 0, 0, 0);
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        uint32_t ox, k_;
+        if constexpr (PW) {
+          k_ = okm & xm[s_];
+          ox = ((uint32_t)m * (uint32_t)d.C + (uint32_t)(x_c0[s_] + col[e])) * ES;
+        } else {
+          const int hs = rho[e] * d.stride - d.pad + x_r[s_], ws = rwo[e] * d.stride - d.pad + x_s[s_];
+          k_ = okm & xm[s_] & ~neg(hs | (d.Hs - 1 - hs) | ws | (d.Ws - 1 - ws));  // 0 <= hs < Hs and 0 <= ws < Ws
+          ox = ((uint32_t)((rn[e] * d.Hs + hs) * d.Ws + ws) * (uint32_t)d.C + (uint32_t)(x_c0[s_] + col[e])) * ES;
+        }
+        ox = (ox & k_) | (OOB & ~k_);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st + (2 + s_) * SUB + (e * 4 + wave) * 1024), 16, ox, 0, 0, 0);
+      }
+      if constexpr (!PW) {
+        rwo[e] += dW;
+        const int c1 = (int)(~neg(rwo[e] - d.Wo) & 1u);  // rwo >= Wo
+        rwo[e] -= c1 * d.Wo;
+        rho[e] += dH + c1;
+        const int c2 = (int)(~neg(rho[e] - d.Ho) & 1u);
+        rho[e] -= c2 * d.Ho;
+        rn[e] += dN + c2;
+      }
+      mcur[e] += MK;
+    }
+  };
+
+  const int wyc = wave >> 1, wxk = wave & 1;  // this wavefront's 128 output channels / 128 k columns = sub-tile wyc of g, sub-tile wxk of x
+  const int lr = lane & 15, lg = lane >> 4;
+  const int jrow = lr >> 2, q = lr & 3;
+  const int f = jrow | ((lg & 1) << 2);  // = wg_swz(r0) = wg_swz(r0 + 4)
+  const int rowoff = (8 * lg + jrow) * ROWB + q * 8;
+  // fragment F (0..7 = g blocks, 8..15 = x blocks) of the stage in buffer `st`: two transposing reads (rows r0, r0 + 4)
+  auto frag = [&](const char* st, int F) -> u32x4 {
+    const char* sub = st + (F < 8 ? wyc : 2 + wxk) * SUB;
+    const int cb = (((F & 7) ^ f) << 5);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sub + rowoff + cb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sub + rowoff + 4 * ROWB + cb));
+    const uint2 l2 = *(uint2*)&lo, h2 = *(uint2*)&hi;
+    return u32x4{l2.x, l2.y, h2.x, h2.y};
+  };
+  u32x4 fa[16], fb[16];  // the two fragment sets: [0..7] g (output channels), [8..15] x (k columns)
+
+  // one stage: 64 MFMAs on set `cur`; the next stage's 16 fragments are read into set `nxt` two at a time behind every eight MFMAs
+#define TD_W4_MFMA(I, Jx, cur) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], %2, %3, a[%c0:%c1]" ::"n"(4 * (8 * (I) + (Jx))), "n"(4 * (8 * (I) + (Jx)) + 3), "v"(cur[I]), "v"(cur[8 + (Jx)]));
+#define TD_W4_ROWM(I, cur) TD_W4_MFMA(I, 0, cur) TD_W4_MFMA(I, 1, cur) TD_W4_MFMA(I, 2, cur) TD_W4_MFMA(I, 3, cur) TD_W4_MFMA(I, 4, cur) TD_W4_MFMA(I, 5, cur) TD_W4_MFMA(I, 6, cur) TD_W4_MFMA(I, 7, cur)
+// (the x fragments - needed by EVERY row of the next stage - are read first, under rows 0..3; g fragment I, needed by row I, under rows 4..7;
+//  the pieces of stage s + 3 are issued behind row 3: the top of a stage is a wait and a barrier only)
+#define TD_W4_STAGE(cur, nxt, nbuf, buf_sp3)                                                            \
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                      \
+  __builtin_amdgcn_s_barrier();                                                                         \
+  TD_W4_ROWM(0, cur) nxt[8] = frag(nbuf, 8);   nxt[9] = frag(nbuf, 9);   __builtin_amdgcn_sched_barrier(0); \
+  TD_W4_ROWM(1, cur) nxt[10] = frag(nbuf, 10); nxt[11] = frag(nbuf, 11); __builtin_amdgcn_sched_barrier(0); \
+  TD_W4_ROWM(2, cur) nxt[12] = frag(nbuf, 12); nxt[13] = frag(nbuf, 13); __builtin_amdgcn_sched_barrier(0); \
+  TD_W4_ROWM(3, cur) nxt[14] = frag(nbuf, 14); nxt[15] = frag(nbuf, 15); __builtin_amdgcn_sched_barrier(0); \
+  issue_stage(buf_sp3);                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  TD_W4_ROWM(4, cur) nxt[0] = frag(nbuf, 0);  nxt[1] = frag(nbuf, 1);   __builtin_amdgcn_sched_barrier(0); \
+  TD_W4_ROWM(5, cur) nxt[2] = frag(nbuf, 2);  nxt[3] = frag(nbuf, 3);   __builtin_amdgcn_sched_barrier(0); \
+  TD_W4_ROWM(6, cur) nxt[4] = frag(nbuf, 4);  nxt[5] = frag(nbuf, 5);   __builtin_amdgcn_sched_barrier(0); \
+  TD_W4_ROWM(7, cur) nxt[6] = frag(nbuf, 6);  nxt[7] = frag(nbuf, 7);   __builtin_amdgcn_sched_barrier(0);
+  // top of stage s: this wavefront's pieces of stage s + 1 have landed (behind them: the 8 pieces of stage s + 2), then everybody's; the
+  // buffer of stage s - 1 (read during stage s - 2, consumed in stage s - 1) takes stage s + 3 from the middle of the stage on
+
+  // zero the accumulator file (64 fragments): C = 0 forms would need a first-stage copy of the whole stage macro
+#define TD_W4_Z(N) asm volatile("v_accvgpr_write_b32 a%c0, 0\n\tv_accvgpr_write_b32 a%c1, 0\n\tv_accvgpr_write_b32 a%c2, 0\n\tv_accvgpr_write_b32 a%c3, 0" ::"n"(4 * (N)), "n"(4 * (N) + 1), "n"(4 * (N) + 2), "n"(4 * (N) + 3));
+#define TD_W4_Z8(B) TD_W4_Z(B) TD_W4_Z(B + 1) TD_W4_Z(B + 2) TD_W4_Z(B + 3) TD_W4_Z(B + 4) TD_W4_Z(B + 5) TD_W4_Z(B + 6) TD_W4_Z(B + 7)
+  TD_W4_Z8(0) TD_W4_Z8(8) TD_W4_Z8(16) TD_W4_Z8(24) TD_W4_Z8(32) TD_W4_Z8(40) TD_W4_Z8(48) TD_W4_Z8(56)
+#undef TD_W4_Z8
+#undef TD_W4_Z
+
+  const int nst = (mend - mbeg + MK - 1) / MK;
+  const int nquad = (nst + 3) / 4;  // ONE loop over stage quadruples and nothing else (extra stages: zero fill without traffic)
+  issue_stage(r0_);
+  issue_stage(r1_);
+  issue_stage(r2_);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage 0 has landed
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int F = 0; F < 16; ++F) fa[F] = frag(r0_, F);
+#pragma unroll 1
+  for (int it = 0; it < nquad; ++it) {
+    TD_W4_STAGE(fa, fb, r1_, r3_)
+    TD_W4_STAGE(fb, fa, r2_, r0_)
+    TD_W4_STAGE(fa, fb, r3_, r1_)
+    TD_W4_STAGE(fb, fa, r0_, r2_)
+  }
+#undef TD_W4_STAGE
+#undef TD_W4_ROWM
+#undef TD_W4_MFMA
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // trailing zero-fill DMAs / fragment reads must not outlive the workgroup's LDS
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the asm MFMAs' results are read below
+  // D[i = co][j = kk]: lane holds co = base + 4 lg + rr, kk = base + lr
+  const int RS = d.R * d.S;
+  // (a wide job has Nc % 256 == 0 - host-checked - so every output channel of the tile exists; k columns past K and padded input channels do not)
+  float sc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) sc[i][rr] = p.scale ? p.scale[co0 + wyc * 128 + i * 16 + 4 * lg + rr] : 1.f;
+  const bool plain = p.out_mode == 2;  // (uniform) a single split: this workgroup owns the tile
+#define TD_W4_OUT(I, Jx)                                                                                                                     \
+  if (jok[Jx]) {                                                                                                                            \
+    float v_[4];                                                                                                                            \
+    asm volatile("v_accvgpr_read_b32 %0, a%c4\n\tv_accvgpr_read_b32 %1, a%c5\n\tv_accvgpr_read_b32 %2, a%c6\n\tv_accvgpr_read_b32 %3, a%c7"     \
+                 : "=v"(v_[0]), "=v"(v_[1]), "=v"(v_[2]), "=v"(v_[3])                                                                        \
+                 : "n"(4 * (8 * (I) + (Jx))), "n"(4 * (8 * (I) + (Jx)) + 1), "n"(4 * (8 * (I) + (Jx)) + 2), "n"(4 * (8 * (I) + (Jx)) + 3));      \
+    float* dst = jdst[Jx] + (size_t)((I) * 16) * cstride;                                                                                   \
+    _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                                                      \
+      const float v = v_[rr] * sc[I][rr];                                                                                                   \
+      if (plain) dst[(size_t)rr * cstride] = v;                                                                                             \
+      else atomicAdd(dst + (size_t)rr * cstride, v);                                                                                        \
+    }                                                                                                                                       \
+  }
+  const size_t cstride = (size_t)p.ci_real * RS;  // elements between consecutive output channels of dW [Nc][ci_real][R][S]
+  bool jok[8];
+  float* jdst[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kko = kk0 + wxk * 128 + j * 16 + lr;
+    int tap = 0, ci = kko;
+    if (!PW && RS > 1) {
+      tap = kko / d.C;
+      ci = kko - tap * d.C;
+    }
+    jok[j] = kko < p.K && ci < p.ci_real;
+    jdst[j] = p.dw + ((size_t)(co0 + wyc * 128 + 4 * lg) * p.ci_real + ci) * RS + tap;
+  }
+#define TD_W4_OUTROW(I) TD_W4_OUT(I, 0) TD_W4_OUT(I, 1) TD_W4_OUT(I, 2) TD_W4_OUT(I, 3) TD_W4_OUT(I, 4) TD_W4_OUT(I, 5) TD_W4_OUT(I, 6) TD_W4_OUT(I, 7)
+  TD_W4_OUTROW(0) TD_W4_OUTROW(1) TD_W4_OUTROW(2) TD_W4_OUTROW(3) TD_W4_OUTROW(4) TD_W4_OUTROW(5) TD_W4_OUTROW(6) TD_W4_OUTROW(7)
+#undef TD_W4_OUTROW
+#undef TD_W4_OUT
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad_wide4_batch_kernel(const WgradParams* __restrict__ jobs, WgradXcdIndex xi) {
+  // four 32-KiB stage buffers as four LDS objects: disjoint alias scopes, so the fragment reads of one stage do not wait for the LDS-DMA filling another
+  __shared__ __attribute__((aligned(1024))) char w4s0[32768];
+  __shared__ __attribute__((aligned(1024))) char w4s1[32768];
+  __shared__ __attribute__((aligned(1024))) char w4s2[32768];
+  __shared__ __attribute__((aligned(1024))) char w4s3[32768];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  if (slot >= xi.slots[xcd]) return;
+  int lo = xi.start[xcd], hi = xi.start[xcd + 1] - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first <= slot) lo = mid;
+    else hi = mid - 1;
+  }
+  const WgradParams p = jobs[lo];
+  int local = slot - p.first;
+  const int bx = local % p.tn;
+  local /= p.tn;
+  const int by = local % p.tk, bz = local / p.tk;
+  if (p.cls & 4) wgrad_wide4_body<true>(p, bx, by, bz, w4s0, w4s1, w4s2, w4s3);
+  else wgrad_wide4_body<false>(p, bx, by, bz, w4s0, w4s1, w4s2, w4s3);
+}
+
 static int validate(const td_conv_desc* d, int dtype, const char* who) {
   const int vec = dtype == TD_BF16 ? 8 : 4;
   TD_REQUIRE(dtype == TD_F32 || dtype == TD_BF16, "%s: bad dtype %d", who, dtype);
@@ -2491,7 +2725,7 @@ extern "C" int td_conv_wgrad_bias(const void* g, const void* src, float* dw, flo
 // The job table of a launch lives in caller-provided memory: the library writes it into `table_host` (page-locked),
 // enqueues ONE hipMemcpyAsync into `table_dev` on the caller's stream and launches; no allocation, no synchronisation.
 static size_t wg_table_half(int n_jobs) { return (((size_t)n_jobs * sizeof(WgradParams)) + 255) & ~(size_t)255; }
-extern "C" size_t td_conv_wgrad_batch_table_bytes(int n_jobs) { return n_jobs > 0 ? 6 * wg_table_half(n_jobs) : 0; }  // (general / pointwise / wide-tile tables) x (overwriting / accumulating jobs)
+extern "C" size_t td_conv_wgrad_batch_table_bytes(int n_jobs) { return n_jobs > 0 ? 8 * wg_table_half(n_jobs) : 0; }  // (general / pointwise / wide-tile / four-wavefront wide-tile tables) x (overwriting / accumulating jobs)
 
 static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev, size_t half, bool accumulate, td_stream_t stream);
 
@@ -2507,14 +2741,15 @@ extern "C" int td_conv_wgrad_batch(const td_wgrad_job* jobs, int n_jobs, int dty
   int rc = TD_OK;
   if (!first.empty()) rc = wgrad_batch_phase(first.data(), (int)first.size(), dtype, table_host, table_dev, half, false, stream);
   if (rc == TD_OK && !second.empty())
-    rc = wgrad_batch_phase(second.data(), (int)second.size(), dtype, (char*)table_host + 3 * half, (char*)table_dev + 3 * half, half, true, stream);
+    rc = wgrad_batch_phase(second.data(), (int)second.size(), dtype, (char*)table_host + 4 * half, (char*)table_dev + 4 * half, half, true, stream);
   return rc;
 }
 
 static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, void* table_host, void* table_dev, size_t half, bool accumulate,
                              td_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
-  std::vector<WgradParams> tab[3];  // [0] general geometry, [1] pointwise, [2] wide tiles (conv_wgrad_wide_batch_kernel)
+  std::vector<WgradParams> tab[4];  // [0] general geometry, [1] pointwise, [2] wide tiles (conv_wgrad_wide_batch_kernel), [3] 256 x 256 tiles on four wavefronts (conv_wgrad_wide4_batch_kernel)
+  static const int wide4_on = [] { const char* e = getenv("TD_WGRAD_WIDE4"); return e ? atoi(e) : 0; }();  // (measured 11 % SLOWER than the sixteen-wavefront tiles on the trunk's table, profiles/r06_wgrad_wide4.log: off by default, kept for the A/B and its bit-identity test)
   double flops = 0, abytes = 0;
   static const int wide_on = [] { const char* e = getenv("TD_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
   static const int wide_min_m = [] { const char* e = getenv("TD_WGRAD_WIDE_MIN_M"); return e ? atoi(e) : 4096; }();
@@ -2566,7 +2801,7 @@ static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, vo
       p.tn = j.d.Nc / (gs * 128);
       p.tk = cdiv(p.K, xs * 128);
     }
-    tab[wide ? 2 : (pw ? 1 : 0)].push_back(p);
+    tab[wide ? ((wide4_on && (p.cls & 3) == 3) ? 3 : 2) : (pw ? 1 : 0)].push_back(p);
     flops += 2.0 * p.M * j.d.Nc * p.K;
     abytes += ((double)p.M * j.ldg + (double)j.d.N * j.d.Hs * j.d.Ws * j.d.C) * (dtype == TD_BF16 ? 2.0 : 4.0) + (double)j.d.Nc * j.ci_real * j.d.R * j.d.S * 4.0;
   }
@@ -2576,7 +2811,7 @@ static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, vo
     prof_set_bytes(abytes);
   }
   const int nstg = wgrad_stages();
-  for (int pw = 0; pw < 3; ++pw) {
+  for (int pw = 0; pw < 4; ++pw) {
     std::vector<WgradParams>& t = tab[pw];
     if (t.empty()) continue;
     // one XCD per job, longest job first onto the least loaded XCD; inside an XCD the long work items come first so
@@ -2587,7 +2822,7 @@ static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, vo
     for (int i = 0; i < nj; ++i) {
       order[i] = i;
       cost[i] = (double)t[i].tn * t[i].tk * t[i].first /*splits*/ * (double)t[i].mper * ((pw == 1 || (t[i].cls & 4)) ? 1.0 : 1.5) *
-                (pw == 2 && (t[i].cls & 3) != 3 ? 0.6 : 1.0);  // half-size wide tiles: half the MFMAs, same DMA count
+                (pw >= 2 && (t[i].cls & 3) != 3 ? 0.6 : 1.0);  // half-size wide tiles: half the MFMAs, same DMA count
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2640,7 +2875,9 @@ static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, vo
     if (pw) conv_wgrad_batch_kernel<TT, NS, true><<<grid, 256, 0, st>>>(dev, xi);            \
     else conv_wgrad_batch_kernel<TT, NS, false><<<grid, 256, 0, st>>>(dev, xi);              \
   } while (0)
-    if (pw == 2) {
+    if (pw == 3) {
+      conv_wgrad_wide4_batch_kernel<<<grid, 256, 0, st>>>(dev, xi);
+    } else if (pw == 2) {
       conv_wgrad_wide_batch_kernel<<<grid, 1024, 0, st>>>(dev, xi);
     } else if (nstg == 4) {
       if (dtype == TD_BF16) TD_WGB_LAUNCH(u16, 4);
