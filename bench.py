@@ -67,8 +67,8 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 # algorithmic TFLOP per clip fwd+bwd
 ALGO_TFLOP_PER_CLIP = {"cfg3": 6.847, "cfg2": 2.538, "cfg1": 0.233}
 DEFAULT_CLIPS_PER_GPU = 16
-PMC_TRAFFIC = "r05_pmc_traffic.json"
-PMC_MFMA = "r05_pmc_mfma.json"
+PMC_TRAFFIC = "r06_pmc_traffic.json"
+PMC_MFMA = "r06_pmc_mfma.json"
 
 
 def make_batch(T, res, k, L, seed, device, clips=1, frames="u8"):
@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--force-ddp", action="store_true", help="diagnostic: run the N>1 code path (process group + gradient exchange) with one rank")
     ap.add_argument("--ddp", action="store_true", help="N>1: use torch DistributedDataParallel like main.py:372-376 instead of the flat exchange")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one flat all-reduce after the whole backward instead of the staged, overlapped exchange")
+    ap.add_argument("--trunk-pieces", type=int, default=1, choices=[1, 3],
+                    help="N>1, staged exchange: 3 = the trunk's backward is issued stage by stage (layer4 | layer3 | layer2), each stage's weight gradients in a launch "
+                         "of their own, and leave in three pieces under the remaining backward instead of one piece behind it (3 or 4 HIP graphs instead of 2)")
     ap.add_argument("--grad-wire-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the wire")
     ap.add_argument("--grad-collective", default="all_reduce", choices=["all_reduce", "rs_ag"],
                     help="N>1: how the flat gradient buffer is averaged: one all-reduce per stage, or reduce-scatter + all-gather on the flat buffer (same result)")
@@ -338,7 +341,7 @@ def main():
     net = model
     distributed = world > 1 or a.force_ddp
     staged = distributed and not a.ddp and not a.no_overlap
-    reducer = None
+    reducer, pieces = None, 1
     if distributed and a.ddp:
         set_wgrad_deferral(False)  # DDP's reducer hooks read every gradient the moment autograd produces it
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True)  # main.py:372-376
@@ -350,7 +353,14 @@ def main():
         for t_ in list(model.parameters()) + list(model.buffers()):
             broadcast_(t_.data, 0)
         late = [p_ for n_, p_ in model.named_parameters() if n_.startswith("backbone.") and p_.requires_grad] if staged else None
-        reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32, late=late, collective=a.grad_collective)
+        pieces = a.trunk_pieces if staged else 1
+        if pieces > 1:
+            from tubedetr_amd.harness import trunk_stage_groups
+
+            reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32, late_groups=trunk_stage_groups(model), collective=a.grad_collective)
+            assert reducer.n_late_stages == 3 and sum(reducer.is_late) == len(late)
+        else:
+            reducer = FlatGradAllReducer(model.parameters(), torch.bfloat16 if a.grad_wire_dtype == "bf16" else torch.float32, late=late, collective=a.grad_collective)
         criterion.external_num_boxes = torch.ones(1, dtype=torch.float32, device=dev)
         reducer.always_communicate = a.force_ddp  # exercise the RCCL call in the 1-rank diagnostic
         set_split_backward(model, staged)
@@ -369,7 +379,10 @@ def main():
         if reducer is not None:
             sync_num_boxes(b["target_boxes"].shape[0], criterion.external_num_boxes)
         loss, _, _, _ = forward_step(net, criterion, weight_dict, b)
-        if staged:
+        if staged and pieces > 1:
+            backward_in_stages(model, loss, after_first_stage=lambda: reducer.launch(early=True), after_trunk_stage=lambda k_, ws_: reducer.launch(stage=k_))
+            reducer.finish(attach=True)
+        elif staged:
             backward_in_stages(model, loss, after_first_stage=lambda: reducer.launch(early=True))  # exchange overlaps the trunk backward
             reducer.launch(early=False)
             reducer.finish(attach=True)
@@ -414,6 +427,11 @@ def main():
                 model.backbone[0].body.backward_trunk()
                 reducer.gather_stage(early=False)
 
+            def body2_pieces():  # generator: one trunk stage + the gather of its gradients per next()
+                for st_, _ in model.backbone[0].body.backward_trunk_iter():
+                    reducer.gather_stage(stage=4 - st_)
+                    yield 4 - st_
+
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -421,7 +439,10 @@ def main():
                     for p_ in params:
                         p_.grad = None
                     body1()
-                    if staged:
+                    if staged and pieces > 1:
+                        for _ in body2_pieces():
+                            pass
+                    elif staged:
                         body2()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
@@ -434,8 +455,17 @@ def main():
             ops_.reset_capture_arena()
             with torch.cuda.graph(graph, capture_error_mode=cap_mode):
                 static_loss = body1()
-            graph2 = None
-            if staged:
+            graph2, graphs2 = None, []
+            if staged and pieces > 1:
+                it2 = body2_pieces()
+                for _ in range(reducer.n_late_stages):
+                    g2 = torch.cuda.CUDAGraph()
+                    ops_.reset_capture_arena()
+                    with torch.cuda.graph(g2, pool=graph.pool(), capture_error_mode=cap_mode):
+                        k2 = next(it2)
+                    graphs2.append((g2, k2))
+                assert next(it2, None) is None
+            elif staged:
                 graph2 = torch.cuda.CUDAGraph()
                 ops_.reset_capture_arena()
                 with torch.cuda.graph(graph2, pool=graph.pool(), capture_error_mode=cap_mode):
@@ -454,7 +484,13 @@ def main():
                 if reducer is not None:
                     sync_num_boxes(b_["target_boxes"].shape[0], criterion.external_num_boxes)
                 graph.replay()
-                if staged:
+                if staged and graphs2:
+                    reducer.exchange_stage(early=True)
+                    for g2_, k2_ in graphs2:                # layer4 | layer3 | layer2: each stage's gradients leave while the next stage runs
+                        g2_.replay()
+                        reducer.exchange_stage(stage=k2_)
+                    reducer.finish(attach=None)
+                elif staged:
                     reducer.exchange_stage(early=True)   # 0.57 GB, overlaps the second graph (trunk backward)
                     graph2.replay()
                     reducer.exchange_stage(early=False)  # the trunk's 0.17 GB
@@ -464,7 +500,7 @@ def main():
                 return static_loss
 
             execution = ("hip_graph (text encoder on a forked branch)" if a.text_stream else "hip_graph (linear)") if not staged else \
-                ("2 hip_graphs (cut at the trunk boundary, exchange overlapped" + ("; text encoder on a forked branch of the first)" if a.text_stream else ")"))
+                (f"{1 + max(1, len(graphs2))} hip_graphs (cut at the trunk boundary" + (" and between the trunk's stages" if graphs2 else "") + ", exchange overlapped" + ("; text encoder on a forked branch of the first)" if a.text_stream else ")"))
         except Exception as exc:  # capture not possible: measure the eager path
             ops_.set_dropout_counter(None)
             torch.cuda.synchronize()

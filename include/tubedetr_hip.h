@@ -249,7 +249,11 @@ size_t td_resnet_bwd_table_bytes(const int* nblocks, int first_train_stage);
 /* dW_prezeroed = 1: every dW[i] was zero-filled by the caller (one fill over the flat buffer they are views of): no per-job fills. */
 int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, const int* nblocks, int first_train_stage,
                   const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws, void* ws,
-                  size_t ws_bytes, void* table_host, void* table_dev, size_t table_bytes, int dW_prezeroed, int dtype, td_stream_t stream);
+                  size_t ws_bytes, void* table_host, void* table_dev, size_t table_bytes, int dW_prezeroed, int dtype, int only_stage, td_stream_t stream);
+/* only_stage = -1: the whole pass (one batched weight-gradient launch at its end).  only_stage = s: only the launches of stage s (3 = layer4 ..
+ * first_train_stage), its weight gradients in a batched launch of their own; the caller issues s = 3, 2, .. on one stream with the same
+ * workspace.  A data-parallel caller can then start the exchange of layer4's gradients while layer3 / layer2 are still computed
+ * (DistributedDataParallel's bucketed reducer does that for the reference, main.py:372-376). */
 
 /* Fold FrozenBatchNorm2d (models/backbone.py:60-70) into a conv: w_fwd[co][r][s][ci] = W[co][ci][r][s]*scale[co]
  * (ci zero-padded to Cpad), w_dgrad[ci][r][s][co] likewise (may be NULL), bias_out[co] = b - rm*scale,

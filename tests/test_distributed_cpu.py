@@ -199,6 +199,51 @@ def _flat_staged_overlap(rank, world):
         assert m.never.weight.grad is None
 
 
+def _flat_trunk_in_three_pieces(rank, world):
+    """late_groups: the trunk's gradients leaving stage by stage (launch(stage=1), (2), (3) as ResNetBody.backward_trunk(after_stage=...) hands
+    them over) give BIT FOR BIT the averaged buffer of the one late exchange (launch(early=False)) - both collectives, fp32 and bf16 wire - and
+    the pieces can be started before the later stages have a gradient at all."""
+    from tubedetr_amd.distributed import FlatGradAllReducer
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.head = torch.nn.Linear(5, 3)
+            self.l4, self.l3, self.l2 = torch.nn.Linear(7, 5), torch.nn.Linear(6, 7), torch.nn.Linear(4, 6)  # odd sizes: runs that do not divide by the world
+
+    def grads(m):
+        g = torch.Generator().manual_seed(100 + rank)
+        for p in m.parameters():
+            p.grad = torch.randn(p.shape, generator=g)
+
+    for wire in (torch.float32, torch.bfloat16):
+        for coll in ("all_reduce", "rs_ag"):
+            m1, m2 = M(), M()
+            grads(m1)
+            one = FlatGradAllReducer(m1.parameters(), wire, late=list(m1.l4.parameters()) + list(m1.l3.parameters()) + list(m1.l2.parameters()), collective=coll)
+            one.launch(early=True)
+            one.launch(early=False)
+            one.finish(attach=True)
+            three = FlatGradAllReducer(m2.parameters(), wire, late_groups=[list(m2.l4.parameters()), list(m2.l3.parameters()), list(m2.l2.parameters())], collective=coll)
+            assert three.n_late_stages == 3 and [r[2] for r in three.runs] == [0, 1, 2, 3]
+            g = torch.Generator().manual_seed(100 + rank)
+            vals = [torch.randn(p.shape, generator=g) for p in m2.parameters()]
+            by = dict(zip([id(p) for p in m2.parameters()], vals))
+            for p in m2.head.parameters():
+                p.grad = by[id(p)]
+            three.launch(early=True)
+            for k_, mod in enumerate((m2.l4, m2.l3, m2.l2)):
+                assert all(p.grad is None for later in (m2.l4, m2.l3, m2.l2)[k_:] for p in later.parameters())  # not yet computed
+                for p in mod.parameters():
+                    p.grad = by[id(p)]
+                three.launch(stage=k_ + 1)
+            three.finish(attach=True)
+            assert torch.equal(one.flat, three.flat), (wire, coll)
+            for a, b in zip(m1.parameters(), m2.parameters()):
+                assert torch.equal(a.grad, b.grad)
+
+
 def _eval_collectives(rank, world):
     """util/dist.py:34-122 of the reference: all_gather of picklable per-rank results of DIFFERENT sizes (the evaluators'
     prediction dicts) and reduce_dict of the loss dict (sum / average, one collective, key order independent of the rank)."""
@@ -263,7 +308,7 @@ def _flat_rs_ag(rank, world):
         assert torch.equal(res["rs_ag"][0], res["rs_ag"][1])  # staged == plain
 
 
-@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce, _flat_rank_dependent_usage, _flat_staged_overlap,
+@pytest.mark.parametrize("fn", [_ddp_two_calls, _criterion_num_boxes, _timing_max, _flat_grad_allreduce, _flat_rank_dependent_usage, _flat_staged_overlap, _flat_trunk_in_three_pieces,
                                 _flat_rs_ag, _eval_collectives])
 def test_world_size_2_gloo(fn):
     _run(fn)

@@ -272,6 +272,57 @@ def test_split_backward_two_graphs_with_overlapped_exchange_equals_plain_step(te
             reducer2.finish(attach=True)
         torch.cuda.synchronize()
         check("two graphs")
+        # the trunk itself stage by stage (td_resnet_bwd only_stage: layer4 | layer3 | layer2, each stage's weight gradients in a launch of their
+        # own): its gradients leave in three pieces while the remaining stages are still computed - eagerly, then as 1 + 3 graphs
+        from tubedetr_amd.harness import trunk_stage_groups
+
+        groups = trunk_stage_groups(model)
+        assert len(groups) == 3 and sum(len(g_) for g_ in groups) == len(late)
+        reducer3 = FlatGradAllReducer(params, late_groups=groups)
+        reducer3.always_communicate = True
+        assert [r[2] for r in reducer3.runs if r[2]] == [3, 2, 1]  # parameter order layer2, layer3, layer4 = late stages 3, 2, 1
+        for p in params:
+            p.grad = None
+        invalidate_prepared()
+        loss, _, _, _ = forward_step(model, criterion, weight_dict, batch)
+        seen = []
+        backward_in_stages(model, loss, after_first_stage=lambda: reducer3.launch(early=True),
+                           after_trunk_stage=lambda k_, ws_: (seen.append((k_, len(ws_))), reducer3.launch(stage=k_)))
+        reducer3.finish(attach=True)
+        torch.cuda.synchronize()
+        assert [k_ for k_, _ in seen] == [1, 2, 3] and [n_ for _, n_ in seen] == [len(g_) for g_ in groups]
+        check("trunk in three pieces, eager")
+        for p in params:
+            p.grad = None
+        reducer4 = FlatGradAllReducer(params, late_groups=groups)
+        reducer4.always_communicate = True
+        body = model.backbone[0].body
+        g1 = torch.cuda.CUDAGraph()
+        _ops.reset_capture_arena()
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+            invalidate_prepared()
+            l_, _, _, _ = forward_step(model, criterion, weight_dict, batch)
+            l_.backward()
+            reducer4.gather_stage(early=True)
+        it = body.backward_trunk_iter()
+        gs = []
+        for _ in range(3):
+            g_ = torch.cuda.CUDAGraph()
+            _ops.reset_capture_arena()
+            with torch.cuda.graph(g_, pool=g1.pool(), capture_error_mode="thread_local"):
+                st_, _w = next(it)
+                reducer4.gather_stage(stage=4 - st_)
+            gs.append((g_, 4 - st_))
+        assert next(it, None) is None
+        for _ in range(3):
+            g1.replay()
+            reducer4.exchange_stage(early=True)
+            for g_, k_ in gs:
+                g_.replay()
+                reducer4.exchange_stage(stage=k_)
+            reducer4.finish(attach=True)
+        torch.cuda.synchronize()
+        check("four graphs")
     except BaseException:
         import traceback
 

@@ -206,6 +206,46 @@ def test_model_bf16_close_to_fp32_and_trains():
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
+def test_trunk_backward_stage_by_stage_is_bit_identical_in_deterministic_mode():
+    """td_resnet_bwd(only_stage = 3, 2, 1) - the trunk's backward issued stage by stage, one batched weight-gradient launch per stage, for a
+    gradient exchange that leaves in pieces - against the single pass: the same kernels on the same operands in the same order, so in
+    deterministic mode (one work item per weight-gradient tile) every gradient is identical bit for bit, fp32 and bf16."""
+    import tubedetr_amd
+    from oracle.tubedetr_oracle import OracleConfig
+    from oracle.weights import fill_state, state_spec, synthetic_batch
+    from tubedetr_amd.harness import FixedTokenizer, backward_in_stages, batch_to, forward_step, set_split_backward
+
+    cfg = OracleConfig(stride=2)
+    batch = synthetic_batch(T=4, res=64, k=2, L=5, seed=43)
+    sd = fill_state(state_spec(cfg), 17)
+    dev = torch.device("cuda:0")
+    tubedetr_amd.set_deterministic(True)
+    try:
+        for dt in (torch.float32, torch.bfloat16):
+            res = {}
+            for mode in ("single", "stages"):
+                model, criterion, weight_dict = _build(cfg)
+                model.load_state_dict(sd, strict=True)
+                model.to(dev).eval()
+                model.set_compute_dtype(dt)
+                model.transformer.tokenizer = FixedTokenizer(batch["input_ids"], batch["attention_mask"])
+                set_split_backward(model, mode == "stages")
+                loss, _, _, _ = forward_step(model, criterion, weight_dict, batch_to(batch, dev))
+                seen = []
+                if mode == "stages":
+                    backward_in_stages(model, loss, after_trunk_stage=lambda k_, ws_: seen.append((k_, len(ws_))))
+                    assert [k_ for k_, _ in seen] == [1, 2, 3] and all(n_ > 0 for _, n_ in seen)
+                else:
+                    loss.backward()
+                torch.cuda.synchronize()
+                res[mode] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            assert res["single"].keys() == res["stages"].keys()
+            bad = [n for n in res["single"] if not torch.equal(res["single"][n], res["stages"][n])]
+            assert not bad, (dt, bad[:8])
+    finally:
+        tubedetr_amd.set_deterministic(False)
+
+
 def test_dedupe_is_proven_from_the_inputs_not_flagged():
     """TubeDETR._slow_is_strided_fast: the slow clip as an index list over the very buffer the fast frames are, with the host copy of that
     list equal to 0, k, 2k, ... of every video (what data.ClipPipeline hands over) is a proof; anything else - another buffer, a shifted or

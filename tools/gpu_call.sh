@@ -9,7 +9,7 @@ for what in "$@"; do
     sel) timeout 1500 python -m pytest $TD_PYTEST_SEL -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/${tag}_sel.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${tag}_sel.log ;;
     bench) timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?" >> gpurun_out/${tag}_bench.err ;;
     benchfast) timeout 600 python bench.py --cpu-frames 0 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?" >> gpurun_out/${tag}_bench.err ;;
-    stats) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_stats -- python $GRAFT_REPO_ROOT/bench.py --no-graph --steps 3 --warmup 2 --cpu-frames 0 --roofline-steps 1 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_stats.log 2>&1) ;;
+    stats) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_stats -- python $GRAFT_REPO_ROOT/bench.py --no-graph --steps 3 --warmup 2 --cpu-frames 0 --roofline-steps 1 --dedupe-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_stats.log 2>&1) ;;
     *) echo "unknown step $what" ;;
   esac
 done

@@ -33,7 +33,7 @@ def main():
     F, W = load(fetch), load(write)
     res = {"_doc": "bytes per launch = counter sum (KiB) * 1024 / dispatches; fetch doubled (gfx950 16-B/lane streaming-read correction); "
                    "Infinity-Cache hits are counted by these memory-side counters",
-           "_command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --no-graph --steps 1 --warmup 1 --cpu-frames 0 --roofline-steps 0",
+           "_command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --no-graph --steps 1 --warmup 1 --cpu-frames 0 --roofline-steps 0 --dedupe-steps 0",
            "_steps": 2}  # warm-up + timed step: `dispatches` / _steps = launches per step
     for f in sorted(set(F) | set(W)):
         nf, sf = F.get(f, [0, 0.0])

@@ -85,7 +85,7 @@ _SIGS = {
     "td_set_deterministic": [_I],
     "td_get_deterministic": [],
     "td_frames_to_nhwc": [C.POINTER(FrameSource), _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P],
-    "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _P, _P, _SZ, _I, _I, _P],
+    "td_resnet_bwd": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _SZ, _P, _P, _SZ, _I, _I, _I, _P],
     "td_weight_prep_batch": [_P, _I, _I, _I, _P],
     "td_weight_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "td_wgrad_finalize": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -5,6 +5,7 @@
 // its autograd backward.  Conv order everywhere: stem, then per block conv1, conv2, conv3[, downsample].
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "td_common.h"
@@ -325,19 +326,36 @@ extern "C" size_t td_resnet_bwd_ws_bytes(int N, int H, int W, const int* nblocks
   return dwk_bytes(P, first_train_stage, nullptr) + 6 * grad_slot_bytes(P, N, first_train_stage);
 }
 
+// jobs of one stage: three convs per bottleneck + the stage's downsample
+static int stage_jobs(const int* nblocks, int st) { return nblocks[st] > 0 ? 3 * nblocks[st] + 1 : 0; }
+// The table is laid out per stage (stage 3 first): a pass that is issued stage by stage (only_stage >= 0) launches one batch per call, and a
+// batch's staging memory must stay untouched until the stream has passed its launch - every stage owns its part.
+static size_t stage_table_offset(const int* nblocks, int first_train_stage, int st) {
+  size_t off = 0;
+  for (int s = 3; s > st; --s)
+    if (s >= first_train_stage) off += td_conv_wgrad_batch_table_bytes(stage_jobs(nblocks, s));
+  return off;
+}
 extern "C" size_t td_resnet_bwd_table_bytes(const int* nblocks, int first_train_stage) {
   int n = 0;
   for (int st = 0; st < 4; ++st)
-    if (st >= first_train_stage) n += 3 * nblocks[st] + 1;  // three convs per bottleneck + the stage's downsample
-  return td_conv_wgrad_batch_table_bytes(n);
+    if (st >= first_train_stage) n += stage_jobs(nblocks, st);
+  // (one batch over all jobs, or one per stage: the larger of the two layouts)
+  return std::max(td_conv_wgrad_batch_table_bytes(n), stage_table_offset(nblocks, first_train_stage, first_train_stage - 1));
 }
 
 extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, const int* nblocks, int first_train_stage,
                              const void* const* w_dgrad, const float* const* scale, float* const* dW, const void* fwd_ws,
                              void* ws, size_t ws_bytes, void* table_host, void* table_dev, size_t table_bytes, int dW_prezeroed, int dtype,
-                             td_stream_t stream) {
+                             int only_stage, td_stream_t stream) {
   TD_REQUIRE(dfeat && nblocks && w_dgrad && scale && dW && fwd_ws && ws, "td_resnet_bwd: null pointer");
   TD_REQUIRE(N >= 1 && N <= N_fwd, "td_resnet_bwd: N=%d must be in 1..N_fwd=%d", N, N_fwd);
+  // only_stage = -1: the whole pass.  only_stage = s (first_train_stage..3): ONLY the launches of stage s - the walk below is the same
+  // (the gradient activations are bump-allocated in walk order, so the gradient a stage receives sits where the previous call left it);
+  // calls must come in the order 3, 2, .., first_train_stage on one stream with the same workspace.  That is how the trunk's weight
+  // gradients leave in pieces (one batched launch per stage) for a data-parallel exchange that overlaps the remaining backward.
+  TD_REQUIRE(only_stage == -1 || (only_stage >= first_train_stage && only_stage <= 3), "td_resnet_bwd: only_stage=%d out of range", only_stage);
+  TD_REQUIRE(only_stage == -1 || wgrad_batched(), "td_resnet_bwd: a stage-by-stage pass needs the batched weight gradients");
   // activation offsets are those of the forward pass over N_fwd frames; the first N frames of every tensor (a
   // contiguous prefix, frames are the leading dimension) are the ones that carry gradient
   Plan P = make_plan(N_fwd, H, W, nblocks, dtype, 1);
@@ -367,7 +385,9 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     return TD_ERR_LAUNCH;
   }
   int rc;
+  bool live = true;  // the block being walked belongs to the requested stage
   auto wgrad = [&](const void* g, const Tens& gt, const Tens& xin, int ci) -> int {
+    if (!live) return TD_OK;
     const ConvSpec& c = P.convs[ci];
     td_conv_desc d = {N, xin.H, xin.W, xin.C, gt.H, gt.W, c.k, c.k, c.stride, c.pad, 0, c.cout, c.cout, 1, 0, 0};
     if (batched) {
@@ -391,6 +411,7 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
     return td_wgrad_finalize(dwk, scale[ci], dW[ci], c.cout, c.cin, c.k, c.k, c.cin, 0, stream);
   };
   auto dgrad = [&](const void* g, const Tens& gt, const Tens& xin, int ci, const void* residual, const void* mask, void* out) -> int {
+    if (!live) return TD_OK;
     const ConvSpec& c = P.convs[ci];
     td_conv_desc d = {N, gt.H, gt.W, gt.C, xin.H, xin.W, c.k, c.k, c.stride, c.pad, 1, c.cin, c.cin, 1, 0, 0};
     td_epilogue e;
@@ -405,9 +426,12 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
   if (first > last) return TD_OK;
   const Tens& fo = P.blocks[last].out;
   char* g_out = galloc(fo);
-  if ((rc = td_relu_bwd(dfeat, acts + fo.off, g_out, (size_t)N * fo.H * fo.W * fo.C, 1.f, dtype, stream))) return rc;
+  if ((only_stage == -1 || only_stage == P.blocks[last].stage) &&
+      (rc = td_relu_bwd(dfeat, acts + fo.off, g_out, (size_t)N * fo.H * fo.W * fo.C, 1.f, dtype, stream)))
+    return rc;
   for (int bi = last; bi >= first; --bi) {
     const BlockPlan& b = P.blocks[bi];
+    live = only_stage == -1 || b.stage == only_stage;
     const int c1 = b.conv[0], c2 = b.conv[1], c3 = b.conv[2], cd = b.conv[3];
     if ((rc = wgrad(g_out, b.out, b.h2, c3))) return rc;
     char* g_h2 = galloc(b.h2);
@@ -431,14 +455,17 @@ extern "C" int td_resnet_bwd(const void* dfeat, int N, int N_fwd, int H, int W, 
         memset(&e, 0, sizeof(e));
         e.residual = dx;
         e.mask_src = xin;
-        if ((rc = td_conv_gemm(g_out, w_dgrad[cd], dx, &d, &e, dtype, stream))) return rc;
+        if (live && (rc = td_conv_gemm(g_out, w_dgrad[cd], dx, &d, &e, dtype, stream))) return rc;
       }
     } else {
       if ((rc = dgrad(g_h1, b.h1, b.in, c1, g_out, xin, dx))) return rc;
     }
     g_out = dx;
   }
-  if (batched && !jobs.empty())
-    return td_conv_wgrad_batch(jobs.data(), (int)jobs.size(), dtype, table_host, table_dev, table_bytes, stream);
+  if (batched && !jobs.empty()) {
+    const size_t toff = only_stage == -1 ? 0 : stage_table_offset(nblocks, first_train_stage, only_stage);
+    TD_REQUIRE(table_bytes >= toff + td_conv_wgrad_batch_table_bytes((int)jobs.size()), "td_resnet_bwd: job-table workspace too small");
+    return td_conv_wgrad_batch(jobs.data(), (int)jobs.size(), dtype, (char*)table_host + toff, (char*)table_dev + toff, table_bytes - toff, stream);
+  }
   return TD_OK;
 }

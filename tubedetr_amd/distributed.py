@@ -80,14 +80,24 @@ def has_rs_ag() -> bool:
 
 class FlatGradAllReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], wire_dtype: torch.dtype = torch.float32, group=None, late=None,
-                 collective: str = "all_reduce"):
+                 collective: str = "all_reduce", late_groups=None):
         """``late``: optional set of parameters (or ids) whose gradient only becomes final in the LAST backward stage (the
         ResNet trunk when the step is split at the trunk boundary, harness.backward_in_stages): everything else is
         exchanged by ``launch(early=True)`` while that stage still runs - the overlap DDP's bucketed reducer gives the
-        reference (main.py:372-376), with two collectives instead of ~30 buckets."""
+        reference (main.py:372-376), with two collectives instead of ~30 buckets.
+        ``late_groups`` (instead of ``late``): SEVERAL late stages, in the order their gradients become final (the trunk issued stage by
+        stage, ResNetBody.backward_trunk(after_stage=...): layer4's parameters, layer3's, layer2's) - stage k of them is exchanged by
+        ``launch(stage=k)``, 1-based, while the later ones are still computed; ``launch(early=False)`` still means "everything late"."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        late_ids = {id(p) if torch.is_tensor(p) else p for p in (late or [])}
-        self.is_late = [id(p) in late_ids for p in self.params]
+        assert late is None or late_groups is None, "late or late_groups, not both"
+        groups = [list(late)] if late is not None else [list(g_) for g_ in (late_groups or [])]
+        stage_by_id = {}
+        for k_, g_ in enumerate(groups):
+            for p in g_:
+                stage_by_id[id(p) if torch.is_tensor(p) else p] = k_ + 1
+        self.stage_of = [stage_by_id.get(id(p), 0) for p in self.params]  # 0 = final when the first backward stage ends
+        self.n_late_stages = len(groups)
+        self.is_late = [s_ > 0 for s_ in self.stage_of]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         dev = self.params[0].device
@@ -100,9 +110,9 @@ class FlatGradAllReducer:
             self.views.append(self.flat[off : off + p.numel()].view_as(p))
             off += p.numel()
         self.numel = n
-        # maximal runs of consecutive parameters of the same stage: (first element, end element, late?)
+        # maximal runs of consecutive parameters of the same stage: (first element, end element, stage)
         self.runs, off = [], 0
-        for p, lt in zip(self.params, self.is_late):
+        for p, lt in zip(self.params, self.stage_of):
             if self.runs and self.runs[-1][2] == lt:
                 self.runs[-1][1] = off + p.numel()
             else:
@@ -194,10 +204,17 @@ class FlatGradAllReducer:
         return self._shard
 
     # ---- staged form: exchange what is final while the rest of backward still runs ----
-    def gather_stage(self, early: bool) -> None:
+    @staticmethod
+    def _wanted(st: int, early, stage) -> bool:
+        """Does a parameter / run of stage ``st`` belong to the selection?  stage = k: exactly late stage k; else early: stage 0 / every late stage."""
+        if stage is not None:
+            return st == stage
+        return (st == 0) if early else (st > 0)
+
+    def gather_stage(self, early: Optional[bool] = None, stage: Optional[int] = None) -> None:
         """Fused multi-tensor copy of one stage's gradients into the flat buffer (no collective: may be captured in the
         HIP graph of that stage)."""
-        sel = [i for i, lt in enumerate(self.is_late) if lt != early]
+        sel = [i for i, st in enumerate(self.stage_of) if self._wanted(st, early, stage)]
         grads = [self.params[i].grad for i in sel]
         have = [(self.views[i], g) for i, g in zip(sel, grads) if g is not None and g.data_ptr() != self.views[i].data_ptr()]
         missing = [self.views[i] for i, g in zip(sel, grads) if g is None]
@@ -207,15 +224,15 @@ class FlatGradAllReducer:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         self._note_usage(sel, grads)  # (same invalidation rule as gather(): the staged / graph path must not keep a stale usage map)
 
-    def exchange_stage(self, early: bool) -> None:
+    def exchange_stage(self, early: Optional[bool] = None, stage: Optional[int] = None) -> None:
         """Start the all-reduce of one stage's runs WITHOUT waiting for it (async_op: the collective is ordered after the
         work enqueued on the current stream so far and runs on the backend's own stream); ``finish()`` joins."""
         if not (self.world > 1 or self.always_communicate):
             return
         avg = dist.get_backend(self.group) == "nccl"
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        for a, b, lt in self.runs:
-            if lt == early:
+        for a, b, st in self.runs:
+            if not self._wanted(st, early, stage):
                 continue
             buf = self.flat[a:b]
             if self.wire is not self.flat:
@@ -236,11 +253,11 @@ class FlatGradAllReducer:
                 work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
             self._pending.append((work, a, b, avg))
 
-    def launch(self, early: bool) -> None:
-        """gather_stage + exchange_stage: exchange what is final (early: everything but the ``late`` parameters) while the
-        rest of backward still runs."""
-        self.gather_stage(early)
-        self.exchange_stage(early)
+    def launch(self, early: Optional[bool] = None, stage: Optional[int] = None) -> None:
+        """gather_stage + exchange_stage: exchange what is final (early: everything but the ``late`` parameters; stage = k: late
+        stage k) while the rest of backward still runs."""
+        self.gather_stage(early, stage)
+        self.exchange_stage(early, stage)
 
     def finish(self, attach: Optional[bool] = True) -> None:
         """Wait (on the current stream) for the collectives started by ``launch`` and hand the averaged gradients over

@@ -87,16 +87,35 @@ def set_split_backward(model, on: bool) -> None:
     core.backbone[0].body.split_backward = bool(on)
 
 
-def backward_in_stages(model, loss, after_first_stage=None) -> None:
+def backward_in_stages(model, loss, after_first_stage=None, after_trunk_stage=None) -> None:
     """loss.backward() in two stages split at the trunk boundary (set_split_backward(model, True) before the forward):
     stage 1 = heads, decoder, encoder, text encoder, input_proj - 0.57 GB of the 0.74 GB of gradients are final when it
     ends; ``after_first_stage()`` runs there (the data-parallel reducer starts their all-reduce); stage 2 = the trunk's
-    backward, which the collective overlaps.  Numerically identical to a single loss.backward()."""
+    backward, which the collective overlaps.  Numerically identical to a single loss.backward().
+    ``after_trunk_stage(k, weights)`` (optional): the trunk itself is issued stage by stage (layer4, layer3, layer2: k = 1, 2, 3 in the
+    reducer's ``late_groups`` numbering), each stage's weight gradients in a launch of their own, and the callback runs behind each -
+    the trunk's own 0.17 GB then leave in three pieces under the remaining backward instead of behind it."""
     loss.backward()
     if after_first_stage is not None:
         after_first_stage()
     core = getattr(model, "module", model)
-    core.backbone[0].body.backward_trunk()
+    body = core.backbone[0].body
+    if after_trunk_stage is None:
+        body.backward_trunk()
+    else:
+        body.backward_trunk(after_stage=lambda stage, ws_: after_trunk_stage(4 - stage, ws_))
+
+
+def trunk_stage_groups(model):
+    """The trunk's trainable weights grouped by stage in backward order (layer4, layer3, layer2): ``late_groups`` of FlatGradAllReducer."""
+    core = getattr(model, "module", model)
+    body = core.backbone[0].body
+    groups = {}
+    for name, blk in body.blocks():
+        for p in blk.parameters():
+            if p.requires_grad:
+                groups.setdefault(int(name[5]), []).append(p)
+    return [groups[k] for k in sorted(groups, reverse=True)]
 
 
 def train_step(model, criterion, weight_dict, batch, optimizer: Optional[torch.optim.Optimizer] = None, max_norm: float = 0.0):

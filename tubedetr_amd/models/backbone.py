@@ -136,16 +136,52 @@ class ResNetBody(nn.Module):
             return leaf, rest
         return feat, rest
 
-    def backward_trunk(self) -> bool:
-        """Second backward stage of a split step; returns False when there is nothing to do."""
+    def backward_trunk(self, after_stage=None) -> bool:
+        """Second backward stage of a split step; returns False when there is nothing to do.  ``after_stage(stage, weights)`` (optional): the
+        pass is issued STAGE BY STAGE (layer4, layer3, layer2 - td_resnet_bwd's ``only_stage``), each stage's weight gradients leave in a
+        batched launch of their own, are accumulated into ``.grad`` and handed to the callback - which may start their data-parallel exchange
+        while the remaining stages are still computed (what DDP's bucketed reducer does for the reference, main.py:372-376)."""
         if self._split is None:
             return False
         feat, leaf = self._split
         self._split = None
         if leaf.grad is None:
             return False
-        feat.backward(leaf.grad)
+        if after_stage is None:
+            feat.backward(leaf.grad)
+            return True
+        self._split = (feat, leaf)
+        for stage, ws_ in self.backward_trunk_iter():
+            after_stage(stage, ws_)
         return True
+
+    def backward_trunk_iter(self):
+        """Generator form of ``backward_trunk(after_stage=...)``: every ``next()`` enqueues ONE stage (3 = layer4, 2, ..) and yields
+        (stage, that stage's weights with ``.grad`` set) - a caller that replays the step from HIP graphs captures each stage in a graph of
+        its own and launches the stage's exchange between the replays."""
+        if self._split is None:
+            return
+        feat, leaf = self._split
+        self._split = None
+        if leaf.grad is None:
+            return
+        ctx = feat.grad_fn  # the autograd node of ResNetTrunkFn IS its ctx
+        assert ctx is not None and hasattr(ctx, "dims"), "backward_trunk_iter: the trunk pass kept nothing for backward"
+        first = None
+        for name, blk in self.blocks():
+            if blk.conv1.weight.requires_grad:
+                first = int(name[5]) - 1
+                break
+        by_w = {id(p): p for p in self.trainable_weights()}
+        for stage in range(3, (4 if first is None else first) - 1, -1):
+            with torch.no_grad():
+                got = ResNetTrunkFn._enqueue(ctx, leaf.grad, stage)
+                ws_ = []
+                for wid, g in got.items():
+                    p = by_w[wid]
+                    p.grad = g if p.grad is None else p.grad.add_(g)
+                    ws_.append(p)
+            yield stage, ws_
 
 
 def _prep(conv: ConvWeight, bn: FrozenBatchNorm2d, dt, need_dgrad, cpad=None):
@@ -277,10 +313,13 @@ class ResNetTrunkFn(Function):
         return a, b
 
     @staticmethod
-    def backward(ctx, dfeat, _drest=None):
+    def _enqueue(ctx, dfeat, only_stage=-1):
+        """Enqueue the trunk's backward (td_resnet_bwd) - the whole pass, or the launches of ONE stage (3 = layer4 .. first trainable stage;
+        the caller walks them in that order).  Returns {id(weight): dW} of the convs whose gradient this call produced; the dW tensors of a
+        pass are views of ONE zero-filled flat buffer kept on ctx."""
         import ctypes as C
 
-        from .. import _hip
+        from .. import _hip, ops
 
         body, dt, ws, preps = ctx.body, ctx.dt, ctx.ws, ctx.preps
         N, N_fwd, H, W = ctx.dims
@@ -293,27 +332,43 @@ class ResNetTrunkFn(Function):
                 first_stage = int(name[5]) - 1
                 break
         nb = (C.c_int * 4)(*body.layers)
-        # every trainable conv's dW is a view of ONE zero-filled flat buffer: jobs that the batched launch splits along M accumulate
-        # with atomics into zeros, and one fill replaces ~85 per-job fills per step (td_resnet_bwd: dW_prezeroed)
-        sizes = [c.weight.numel() if c.weight.requires_grad else 0 for c, _ in convs]
-        offs_ = [0]
-        for n_ in sizes:
-            offs_.append(offs_[-1] + (n_ + 63) // 64 * 64)
-        flat = torch.zeros(offs_[-1], dtype=torch.float32, device=dfeat.device)
-        dWs = [flat[o : o + n_].view_as(c.weight) if n_ else None for (c, _), n_, o in zip(convs, sizes, offs_)]
-        nbytes = L.td_resnet_bwd_ws_bytes(N, H, W, nb, first_stage, code)
-        bws = torch.empty(nbytes, dtype=torch.uint8, device=dfeat.device)
-        from .. import ops
+        st = getattr(ctx, "bwd_state", None)
+        if st is None:
+            # every trainable conv's dW is a view of ONE zero-filled flat buffer: jobs that the batched launch splits along M accumulate
+            # with atomics into zeros, and one fill replaces ~85 per-job fills per step (td_resnet_bwd: dW_prezeroed)
+            sizes = [c.weight.numel() if c.weight.requires_grad else 0 for c, _ in convs]
+            offs_ = [0]
+            for n_ in sizes:
+                offs_.append(offs_[-1] + (n_ + 63) // 64 * 64)
+            flat = torch.zeros(offs_[-1], dtype=torch.float32, device=dfeat.device)
+            dWs = [flat[o : o + n_].view_as(c.weight) if n_ else None for (c, _), n_, o in zip(convs, sizes, offs_)]
+            nbytes = L.td_resnet_bwd_ws_bytes(N, H, W, nb, first_stage, code)
+            bws = torch.empty(nbytes, dtype=torch.uint8, device=dfeat.device)
+            tbytes = L.td_resnet_bwd_table_bytes(nb, first_stage)
+            th, td_, done = ops.job_tables.take(tbytes, dfeat.device)  # weight-gradient job table: caller-owned staging
+            st = ctx.bwd_state = dict(dWs=dWs, bws=bws, nbytes=nbytes, th=th, td=td_, tbytes=tbytes, done=done, dfeat=dfeat.contiguous(), first_stage=first_stage)
+        _hip.check(L.td_resnet_bwd(st["dfeat"].data_ptr(), N, N_fwd, H, W, nb, first_stage, _ptr_array([p[1] for p in preps]),
+                                   _ptr_array([p[3] for p in preps]), _ptr_array(st["dWs"]), ws.data_ptr(), st["bws"].data_ptr(), st["nbytes"],
+                                   st["th"].data_ptr(), st["td"].data_ptr(), st["tbytes"], 1, code, int(only_stage), _hip.stream_ptr()), "td_resnet_bwd")
+        # which convs belong to the stage(s) just issued: conv list order = stem, then per block conv1, conv2, conv3[, downsample]
+        out, k = {}, 1
+        for name, blk in body.blocks():
+            n_c = 4 if blk.downsample is not None else 3
+            stage = int(name[5]) - 1
+            if stage >= first_stage and (only_stage == -1 or stage == only_stage):
+                for (c, _), g in zip(convs[k : k + n_c], st["dWs"][k : k + n_c]):
+                    if g is not None:
+                        out[id(c.weight)] = g
+            k += n_c
+        if only_stage == -1 or only_stage == first_stage:  # the pass is complete
+            st["done"]()
+            ctx.ws = ctx.preps = None
+        return out
 
-        tbytes = L.td_resnet_bwd_table_bytes(nb, first_stage)
-        th, td_, done = ops.job_tables.take(tbytes, dfeat.device)  # weight-gradient job table: caller-owned staging
-        _hip.check(L.td_resnet_bwd(dfeat.contiguous().data_ptr(), N, N_fwd, H, W, nb, first_stage, _ptr_array([p[1] for p in preps]),
-                                   _ptr_array([p[3] for p in preps]), _ptr_array(dWs), ws.data_ptr(), bws.data_ptr(), nbytes,
-                                   th.data_ptr(), td_.data_ptr(), tbytes, 1, code, _hip.stream_ptr()), "td_resnet_bwd")
-        done()
-        ctx.ws = ctx.preps = None
-        by_id = {id(c.weight): g for (c, _), g in zip(convs, dWs)}
-        return (None, None, None, None) + tuple(by_id.get(id(p)) for p in body.trainable_weights())
+    @staticmethod
+    def backward(ctx, dfeat, _drest=None):
+        by_id = ResNetTrunkFn._enqueue(ctx, dfeat, -1)
+        return (None, None, None, None) + tuple(by_id.get(id(p)) for p in ctx.body.trainable_weights())
 
 
 class BackboneBase(nn.Module):
