@@ -222,7 +222,7 @@ def main():
     ap.add_argument("--dedupe", action="store_true",
                     help="do not recompute the slow frames inside the fast pass (exact, slow = video[::k]); off by default so the timed step "
                          "executes the same work as the reference's")
-    ap.add_argument("--dedupe-steps", type=int, default=4, help="N=1: eager steps timed with the dead work skipped, reported as value_dedupe beside the headline (0 = skip)")
+    ap.add_argument("--dedupe-steps", type=int, default=5, help="N=1: eager steps timed with the dead work skipped, reported as value_dedupe beside the headline (0 = skip)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True, help="capture the step in HIP graph(s)")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--force-ddp", action="store_true", help="diagnostic: run the N>1 code path (process group + gradient exchange) with one rank")
@@ -561,17 +561,18 @@ def main():
         ops_.set_dropout_counter(None)
         model.slow_frames_are_strided_fast = None
         try:
-            for i in range(2):
+            for i in range(3):  # (the mode allocates differently shaped trunk workspaces: let the allocator settle)
                 eager_step(a.warmup + a.steps + i)
             torch.cuda.synchronize()
-            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            d0.record()
+            dm = [torch.cuda.Event(enable_timing=True) for _ in range(a.dedupe_steps + 1)]
+            dm[0].record()
             for i in range(a.dedupe_steps):
-                eager_step(a.warmup + a.steps + 2 + i)
-            d1.record()
+                eager_step(a.warmup + a.steps + 3 + i)
+                dm[i + 1].record()
             torch.cuda.synchronize()
-            d_ms = d0.elapsed_time(d1) / a.dedupe_steps
-            dedupe_rec = {"value_dedupe": round(B * 1e3 / d_ms, 3), "ms_per_step_dedupe": round(d_ms, 2), "steps": a.dedupe_steps, "execution": "eager",
+            d_all = sorted(dm[i].elapsed_time(dm[i + 1]) for i in range(a.dedupe_steps))
+            d_ms = d_all[len(d_all) // 2]  # median step: one allocator stall must not stand for the mode
+            dedupe_rec = {"value_dedupe": round(B * 1e3 / d_ms, 3), "ms_per_step_dedupe": round(d_ms, 2), "ms_per_step_dedupe_min_max": [round(d_all[0], 2), round(d_all[-1], 2)], "steps": a.dedupe_steps, "execution": "eager (median step)",
                           "trunk_forward_frames_per_clip": {"reference": T + math.ceil(T / k), "executed": T},
                           "note": "slow frames proven to be fast[::k] of the same buffer (FrameSources aliasing + host index list) and not recomputed; "
                                   "not the headline: `value` executes every frame of the reference algorithm"}
