@@ -33,6 +33,23 @@ __device__ __forceinline__ uint32_t bn_cvt_pk(float lo, float hi) {
   bn_bf16x2 v = {(__bf16)lo, (__bf16)hi};
   return *(uint32_t*)&v;
 }
+// ReLU of two packed bf16: as 16-bit integers, max(x, 0) (v_pk_max_i16) - a negative value (sign bit set, -0.0 included) becomes +0.0,
+// a non-negative one is unchanged.  ONE operation per two values behind the conversion; fmaxf(x, 0.f) before it is two per value
+// (the compiler quiets a possible signalling NaN with a v_max x, x first).
+// (As asm: written with vector types the compiler splits the conversion in front of it into two half conversions and a v_perm.  The
+// CONVERSION must stay the compiler's own instruction: it is the first reader of an MFMA result, and the wait states an MFMA -> VALU
+// read needs are inserted by the compiler's hazard pass, which does not look into asm operands - a v_cvt_pk_bf16_f32 written as
+// asm read accumulators the matrix pipe had not written yet.)
+__device__ __forceinline__ uint32_t bn_relu_pk(uint32_t v) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint2 bn_relu_pack4(const f32x4& a) { return make_uint2(bn_relu_pk(bn_cvt_pk(a[0], a[1])), bn_relu_pk(bn_cvt_pk(a[2], a[3]))); }
+// The walk over tiles (tile += gridDim.x) without a division per tile: (image, tile row, tile column) advanced with carries.
+struct BnTile {
+  int img, ty, tx;
+};
 typedef unsigned int bn_u32x2 __attribute__((ext_vector_type(2)));
 // 8-byte output store through a buffer descriptor: a lane whose pixel lies outside the image passes an out-of-range offset and the
 // hardware drops the store.  No branch around the stores: behind a branch the compiler cannot count them in its vmcnt bookkeeping
@@ -52,6 +69,20 @@ __device__ __forceinline__ void bn_lds_store8(char* p, uint2 v) {
   const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)p;
   asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
+// LDS banks (round 6).  ds_read_b128 is served in four groups of 16 lanes - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -
+// and a group takes one cycle only if its 16 addresses fall on 16 different 16-byte slots of the 256-byte bank row.  With the MFMA operand
+// layout (lane = 16 * k-chunk + row) that is two k-chunks x 8 + 8 rows per group:
+//   * 128-byte rows with chunk ^ (row & 7) (the input tiles): conflict-free for 16 CONSECUTIVE rows, and for any 16 rows whose (row & 7)
+//     take every value once per k-chunk of a group;
+//   * padded rows without a swizzle (h1 / h2, so that a tap is "lane base + immediate"): consecutive rows need a pitch of 160 bytes
+//     (10 slots: rows r and r + 8 land 80 = 5 x 16 slots apart, i.e. on the other half of the bank row); the 144 bytes of rounds 4 - 5
+//     were two-way for consecutive rows and THREE-way for the 2 x 8-pixel row blocks of the 256-channel kernel (pixels 0 and 14 of a
+//     block share a slot for every pitch).  rocprofv3 had it in plain sight: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50 / 0.44
+//     (profiles/r06_pmc_LDS_per_kernel.csv), the sum of exactly these patterns;
+//   * the 256-channel kernel's row blocks are therefore 8 rows x 2 COLUMNS of the tile: halo rows 10 apart x 2 adjacent - with the 160-byte
+//     pitch every tap's fragment read, h2's reads and the identity reads from the swizzled input tile are all one cycle per group.
+// The 8-byte result stores pay for it (pitch 160: four rows per 128-byte window, 16 instead of 8 cycles), 6 per wavefront and tile
+// against 48 fragment reads.  tools/lds_bank_model.py is the model these statements were checked with.
 #define TD_BN_OOB 0xFFFFFFF0u
 #ifndef TD_BN_ABL
 #define TD_BN_ABL 0  // timing ablations of the bottleneck_resident kernels (tools/build_variant.sh; wrong results): 1 no input loads, 2 no output stores
@@ -98,7 +129,13 @@ struct BneckParams {
 //     cg = w & 3 (16 / 16 / 64 channels in the three phases) x row-block half w >> 2;
 //   * biases seed the accumulators, and the identity is one more MFMA per fragment against a unit-matrix block;
 //   * tiles whose halo lies inside the image (81 of 121 per frame at res 352) take a path without any validity arithmetic.
-// What is left (ablations of this kernel): 1.83 ms with no memory operation at all, +0.1 for the stores, +0.5 for the loads -
+// Round 6 (2.63 -> 2.35 ms per 1 000 frames, block 0: 1.61 -> 1.37; tools/fused_l1_time.py, old and new library in one call): the
+// kernel issues instructions, it does not wait for memory - ~960 per wavefront and tile around 92 MFMAs.  (1) h1 / h2 at a 160-byte
+// pitch and row blocks of 8 rows x 2 columns: every fragment read is one LDS cycle per lane group (see "LDS banks" above; -5 %);
+// (2) the tile walk carries (image, row, column) instead of dividing, and an interior tile's seven DMA pieces take a per-launch
+// register + a scalar offset (310 -> ~60 instructions in front of the first barrier); (3) ReLU on the packed pair behind the
+// conversion (10 -> 4 VALU operations per accumulator fragment).  ~640 instructions per wavefront and tile now.
+// What was left in round 4 (ablations of that form): 1.83 ms with no memory operation at all, +0.1 for the stores, +0.5 for the loads -
 // a tile's compute (3.9 us) does not cover the landing time of the next tile's 51 KiB under load, and there is no LDS for a
 // third tile.  Measured and dropped: touching tile t + 2's lines a tile earlier to pull them into L2 (2.98 instead of 2.69 ms:
 // the extra requests cost more than the latency they hide); the same restructuring with two 4-wavefront workgroups per CU and a
@@ -108,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
   constexpr int TH = 8, TW = 8, HW = TW + 2;
   constexpr int HROWS = 112;   // 100 halo pixels -> 7 blocks of 16 rows
   constexpr int NP = 7;        // DMA pieces per wavefront and tile: row groups half*7 .. half*7 + 6 of channel chunk cg
-  constexpr int HP = 144;      // row pitch of h1 / h2: 128 bytes + 16 (bank spread without a swizzle)
+  constexpr int HP = 160;      // row pitch of h1 / h2: 128 bytes + 32 (see "LDS banks" above: conflict-free ds_read_b128 without a swizzle)
   constexpr int XBUF = NC * HROWS * 128;
   // two distinct LDS objects: the compiler's wait-count pass then knows that a fragment read of one buffer cannot alias the DMA that
   // is filling the other (one array would put a vmcnt(0) in front of the first read of every phase)
@@ -149,58 +186,90 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
 #pragma unroll
     for (int i = 0; i < 4; ++i) b3v[i][q] = p.b3[64 * cg + 16 * i + 4 * lg + q];
   }
-  auto tile_px_of = [&](int tile, int& y0, int& x0) -> uint32_t {
-    const int img = tile / tiles_per_img;
-    const int trem = tile - img * tiles_per_img;
-    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-    y0 = ty * TH;
-    x0 = tx * TW;
-    return (uint32_t)((img * p.H + y0) * p.W + x0);
+  // ---- the tile walk: tile += gridDim.x as (image, tile row, tile column) with carries (one division per launch, none per tile) ----
+  const int g_img = (int)gridDim.x / tiles_per_img, g_rem = (int)gridDim.x - g_img * tiles_per_img;
+  const int g_ty = g_rem / p.tiles_x, g_tx = g_rem - g_ty * p.tiles_x;
+  auto advance = [&](BnTile c) {
+    c.tx += g_tx;
+    const int kx = c.tx >= p.tiles_x ? 1 : 0;
+    c.tx -= kx ? p.tiles_x : 0;
+    c.ty += g_ty + kx;
+    const int ky = c.ty >= p.tiles_y ? 1 : 0;
+    c.ty -= ky ? p.tiles_y : 0;
+    c.img += g_img + ky;
+    return c;
   };
-  // the 7 pieces of `tile` (tiles past the end: out-of-range offsets, zero fill) into buffer `buf`
-  auto issue_tile = [&](int tile, char* xbuf) {
-    int y0, x0;
-    const uint32_t px = tile_px_of(tile, y0, x0);
-    const bool exists = tile < p.n_tiles;
-    const bool interior = exists && y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;  // wave-uniform: the whole halo lies inside the image
-    char* dst = xbuf + cg * (HROWS * 128) + half * NP * 1024;
-    // DMA piece k of this wavefront: halo rows (half*7 + k)*8 .. +7 of channel chunk cg; the lane's source 16 bytes are chunk
-    // (lane & 7) ^ lrow of its row (the swizzle of the LDS image, applied on the source side: the DMA destination is lane-linear)
-    int ln = lane0;
-    asm volatile("" : "+v"(ln));
-    const int lrow = ln >> 3;
-    const uint32_t lane_part = (uint32_t)(cg * 128 + (((ln & 7) ^ lrow) << 4));
+  // DMA piece k of this wavefront: halo rows (half*7 + k)*8 .. +7 of channel chunk cg; the lane's source 16 bytes are chunk
+  // (lane & 7) ^ lrow of its row (the swizzle of the LDS image, applied on the source side: the DMA destination is lane-linear).
+  // The lane's byte offset RELATIVE TO THE HALO'S FIRST PIXEL does not depend on the tile: seven registers for the whole launch, and a
+  // tile whose halo lies inside the image (81 of 121 per frame at res 352) issues its pieces with that register as the vector offset
+  // and the halo origin as the instruction's SCALAR offset - no vector arithmetic at all.  (Rounds 4 - 5 recomputed row / 10, the
+  // offset and a validity select per piece and tile: ~25 instructions per piece, a third of the instructions a wavefront issued per
+  // tile.)  Rows 100 .. 111 of the last pieces are padding: out-of-range offset, zero fill.
+  uint32_t voff[NP];
+  {
+    const int lrow = lane0 >> 3;
+    const uint32_t lane_part = (uint32_t)(cg * 128 + (((lane0 & 7) ^ lrow) << 4));
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const int row = (half * NP + k) * 8 + lrow;
       const int hy = (row * 205) >> 11, hx = row - hy * HW;  // row / 10 for row < 1029
-      // source relative to the tile's first centre pixel (modulo 2^32: the halo is "negative")
-      uint32_t off = (px + (uint32_t)((hy - 1) * p.W + (hx - 1))) * (CIN * 2) + lane_part;
-      bool ok = row < 100;  // rows 100 .. 111 are padding (compile-time true for all but the last two pieces of the second half)
-      if (!interior) ok = ok && exists && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
-      off = ok ? off : TD_BN_OOB;
+      voff[k] = row < 100 ? (uint32_t)(hy * p.W + hx) * (CIN * 2) + lane_part : TD_BN_OOB;
+    }
+  }
+  // the 7 pieces of tile c (past the end: out-of-range offsets, zero fill) into buffer `xbuf`
+  auto issue_tile = [&](BnTile c, char* xbuf) {
+    const int y0 = c.ty * TH, x0 = c.tx * TW;
+    const bool exists = c.img < p.N;
+    const bool interior = exists && y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;  // wave-uniform: the whole halo lies inside the image
+    const uint32_t px = (uint32_t)((c.img * p.H + y0) * p.W + x0);
+    char* dst = xbuf + cg * (HROWS * 128) + half * NP * 1024;
+    if (interior) {
+      // the halo's first pixel (>= 0 for an interior tile); readfirstlane: the compiler does not prove the walk uniform and would wrap every piece in a loop
+      const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)((px - (uint32_t)(p.W + 1)) * (CIN * 2)));
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
 #if TD_BN_ABL & 1
-      asm volatile("" ::"v"(off));
+        asm volatile("" ::"v"(voff[k]), "s"(soff));
 #else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_p)(dst + k * 1024), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_p)(dst + k * 1024), 16, voff[k], soff, 0, 0);
 #endif
+      }
+    } else {
+      int ln = lane0;
+      asm volatile("" : "+v"(ln));
+      const int lrow = ln >> 3;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int row = (half * NP + k) * 8 + lrow;
+        const int hy = (row * 205) >> 11, hx = row - hy * HW;
+        // (modulo 2^32: where the halo lies before the buffer's first byte the piece is masked anyway)
+        uint32_t off = (px - (uint32_t)(p.W + 1)) * (CIN * 2) + voff[k];
+        const bool ok = row < 100 && exists && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+        off = ok ? off : TD_BN_OOB;
+#if TD_BN_ABL & 1
+        asm volatile("" ::"v"(off));
+#else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_p)(dst + k * 1024), 16, off, 0, 0, 0);
+#endif
+      }
     }
   };
 
   // one tile, input in buffer B (compile-time: the two buffers are different LDS objects)
-  auto process = [&](int tile, auto B_) {
+  auto process = [&](BnTile tc, BnTile tnext, auto B_) {
     constexpr int B = decltype(B_)::value;
     char* const xb_w = B ? xall1 : xall0;
     char* const xo_w = B ? xall0 : xall1;
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int lr = lane & 15, lg = lane >> 4;
-    const int cyl = lr >> 3, cxl = lr & 7;  // centre pixel of row block mb, lane lr: (2 * mb + cyl, cxl)
-    int y0, x0;
-    const uint32_t tile_px = tile_px_of(tile, y0, x0);
+    const int cyl = lr >> 1, cxl = lr & 1;  // centre pixel of row block mb, lane lr: (cyl, 2 * mb + cxl) - a block is two tile COLUMNS
+    const int y0 = tc.ty * TH, x0 = tc.tx * TW;
+    const uint32_t tile_px = (uint32_t)((tc.img * p.H + y0) * p.W + x0);
     const bool interior = y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;
     // the other buffer was last read in phase 3 of the previous tile, behind that tile's closing barrier
-    issue_tile(tile + gridDim.x, xo_w);
+    issue_tile(tnext, xo_w);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");  // this tile's pieces (issued a tile ago) have landed; the next tile's stay in flight
     TD_BN_BARRIER();
     const char* const xb = xb_w;
@@ -230,25 +299,27 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
         __builtin_amdgcn_sched_barrier(0);
       }
       char* const hw = h1 + (half * 64 + lr) * HP + (16 * cg + 4 * lg) * 2;
+      uint2 o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint2 o;
-        o.x = bn_cvt_pk(fmaxf(acc[j][0], 0.f), fmaxf(acc[j][1], 0.f));
-        o.y = bn_cvt_pk(fmaxf(acc[j][2], 0.f), fmaxf(acc[j][3], 0.f));
-        if (!interior) {  // outside the image: conv2's zero padding (an interior tile has no such pixel; rows >= 100 are never read)
+      for (int j = 0; j < 4; ++j) o[j] = bn_relu_pack4(acc[j]);
+      if (!interior) {  // outside the image: conv2's zero padding (an interior tile has no such pixel; rows >= 100 are never read)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
           const int row = (half * 4 + j) * 16 + lr;
           const int hy = (row * 205) >> 11, hx = row - hy * HW;
           const bool inside = (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
-          o.x = inside ? o.x : 0u;
-          o.y = inside ? o.y : 0u;
+          o[j].x = inside ? o[j].x : 0u;
+          o[j].y = inside ? o[j].y : 0u;
         }
-        if (half * 4 + j < 7) bn_lds_store8(hw + j * 16 * HP, o);  // (wave-uniform; the 8th block does not exist)
       }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) bn_lds_store8(hw + j * 16 * HP, o[j]);
+      if (half == 0) bn_lds_store8(hw + 3 * 16 * HP, o[3]);  // (wave-uniform; the 8th block does not exist)
     }
     TD_BN_BARRIER();  // h1 complete
     // ================= phase 2: conv2 3x3: channels 16*cg .. +15, centre row blocks 2*half, 2*half + 1 =================
     {
-      const char* const hr2 = h1 + ((4 * half + cyl) * HW + cxl) * HP + lg * 16;  // + ((2j + r) * HW + s) * HP + parity * 64
+      const char* const hr2 = h1 + (cyl * HW + 4 * half + cxl) * HP + lg * 16;  // + (r * HW + 2j + s) * HP + parity * 64
       f32x4 acc[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[j] = f32x4{b2v[0], b2v[1], b2v[2], b2v[3]};
@@ -259,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) dst[h * 2 + j] = *(const uint4*)(hr2 + ((2 * j + r) * HW + s_) * HP + h * 64);
+          for (int j = 0; j < 2; ++j) dst[h * 2 + j] = *(const uint4*)(hr2 + (r * HW + 2 * j + s_) * HP + h * 64);
       };
       load_t(0, fr[0]);
 #pragma unroll
@@ -276,12 +347,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
       TD_BN_BARRIER();  // every wavefront has read its last h1 fragment: h2 overwrites it
       char* const hw = h1 + (half * 32 + lr) * HP + (16 * cg + 4 * lg) * 2;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        uint2 o;
-        o.x = bn_cvt_pk(fmaxf(acc[j][0], 0.f), fmaxf(acc[j][1], 0.f));
-        o.y = bn_cvt_pk(fmaxf(acc[j][2], 0.f), fmaxf(acc[j][3], 0.f));
-        bn_lds_store8(hw + j * 16 * HP, o);
-      }
+      for (int j = 0; j < 2; ++j) bn_lds_store8(hw + j * 16 * HP, bn_relu_pack4(acc[j]));
     }
     TD_BN_BARRIER();  // h2 complete
     // ================= phase 3: conv3 + identity + ReLU: channels 64*cg .. +63, centre row blocks 2*half, 2*half + 1 =================
@@ -296,14 +362,17 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
         const int d2 = (lr & 7) >> 1;
         eye.x = d2 == 0 ? one : 0u; eye.y = d2 == 1 ? one : 0u; eye.z = d2 == 2 ? one : 0u; eye.w = d2 == 3 ? one : 0u;
       }
-      const int hp0 = (4 * half + cyl + 1) * HW + cxl + 1;                       // halo row of the lane's centre pixel in its first row block (+ 20 for the second)
+      const int hp0 = (cyl + 1) * HW + 4 * half + cxl + 1;                       // halo row of the lane's centre pixel in its first row block (+ 2 for the second)
       const char* const idb = xb + cg * (HROWS * 128) + hp0 * 128;
-      const uint32_t idk = (uint32_t)(((lg & 1) ^ (hp0 & 7)) << 4);              // 16-byte chunk (2i | lg & 1) ^ (row & 7) = 32i ^ idk ^ (second block: 64)
+      const uint32_t idk0 = (uint32_t)(((lg & 1) ^ (hp0 & 7)) << 4);             // 16-byte chunk (2i | lg & 1) ^ (row & 7) = 32i ^ idk
+      const uint32_t idk1 = (uint32_t)(((lg & 1) ^ ((hp0 + 2) & 7)) << 4);
       const char* const hr3 = h1 + (half * 32 + lr) * HP + lg * 16;              // + j * 16 * HP + ks * 64
       char* const stw = ostage[wave] + lr * 128 + (lg & 1) * 8;
       const uint32_t stk = (uint32_t)(((lg >> 1) ^ (lr & 7)) << 4);
       const char* const strd = ostage[wave] + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + ps * 1024
-      const uint32_t st_lane = (uint32_t)((lane >> 3) * 512 + cg * 128 + (lane & 7) * 16);
+      // staging row = pixel lr of the block = (tile row lr >> 1, column 2 * mb + (lr & 1)); a store instruction takes rows 8ps .. 8ps + 7
+      const int st_y = lane >> 4, st_x = (lane >> 3) & 1;  // + 4 * ps rows, + 2 * mb columns
+      const uint32_t st_lane = (uint32_t)((st_y * p.W + st_x) * 512 + cg * 128 + (lane & 7) * 16);
       const bool full = y0 + TH <= p.H && x0 + TW <= p.W;  // wave-uniform
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -319,22 +388,17 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const uint4 xi = *(const uint4*)(idb + j * (2 * HW * 128) + (idk ^ (uint32_t)(32 * i) ^ (uint32_t)(j * 64)));
+          const uint4 xi = *(const uint4*)(idb + j * (2 * 128) + ((j ? idk1 : idk0) ^ (uint32_t)(32 * i)));
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&eye, *(const bf16x8*)&xi, acc[i], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          uint2 o;
-          o.x = bn_cvt_pk(fmaxf(acc[i][0], 0.f), fmaxf(acc[i][1], 0.f));
-          o.y = bn_cvt_pk(fmaxf(acc[i][2], 0.f), fmaxf(acc[i][3], 0.f));
-          bn_lds_store8(stw + (stk ^ (uint32_t)(32 * i)), o);
-        }
+        for (int i = 0; i < 4; ++i) bn_lds_store8(stw + (stk ^ (uint32_t)(32 * i)), bn_relu_pack4(acc[i]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {  // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
           const uint4 o16 = *(const uint4*)(strd + ps * 1024);
-          uint32_t off = (tile_px + (uint32_t)((2 * mb + ps) * p.W)) * 512u + st_lane;
-          if (!full) off = (y0 + 2 * mb + ps < p.H && x0 + (lane >> 3) < p.W) ? off : TD_BN_OOB;
+          uint32_t off = (tile_px + (uint32_t)(4 * ps * p.W + 2 * mb)) * 512u + st_lane;
+          if (!full) off = (y0 + 4 * ps + st_y < p.H && x0 + 2 * mb + st_x < p.W) ? off : TD_BN_OOB;
 #if TD_BN_ABL & 2
           asm volatile("" ::"v"(off), "v"(o16.x), "v"(o16.y), "v"(o16.z), "v"(o16.w));
 #else
@@ -346,11 +410,24 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
     }
     TD_BN_BARRIER();  // every wavefront is done with the tile: h1 and this input buffer may be overwritten
   };
-  issue_tile(blockIdx.x, xall0);
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += 2 * gridDim.x) {
-    process(tile, std::integral_constant<int, 0>{});
-    if (tile + (int)gridDim.x >= p.n_tiles) break;
-    process(tile + gridDim.x, std::integral_constant<int, 1>{});
+  BnTile cur;  // (host: gridDim.x <= n_tiles)
+  cur.img = (int)blockIdx.x / tiles_per_img;
+  {
+    const int trem = (int)blockIdx.x - cur.img * tiles_per_img;
+    cur.ty = trem / p.tiles_x;
+    cur.tx = trem - cur.ty * p.tiles_x;
+  }
+  BnTile nxt = advance(cur);
+  issue_tile(cur, xall0);
+  for (;;) {
+    process(cur, nxt, std::integral_constant<int, 0>{});
+    cur = nxt;
+    nxt = advance(cur);
+    if (cur.img >= p.N) break;
+    process(cur, nxt, std::integral_constant<int, 1>{});
+    cur = nxt;
+    nxt = advance(cur);
+    if (cur.img >= p.N) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (out-of-range) pieces must not outlive the workgroup's LDS
 }
@@ -368,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
   constexpr int TH = 8, TW = 16, HW = TW + 2;          // halo 10 x 18 = 180 pixels
   constexpr int NHALO = (TH + 2) * HW, HROWS = 192;     // -> 12 blocks of 16 rows
   constexpr int NP = 3;                                 // DMA pieces per wavefront and tile: row groups 3w .. 3w + 2 (8 rows x 128 B each)
-  constexpr int HP = 144;                               // row pitch of h1 / h2
+  constexpr int HP = 160;                               // row pitch of h1 / h2 (conflict-free ds_read_b128 of 16 consecutive rows; 144 is two-way)
   constexpr int XBUF = HROWS * 128;
   __shared__ __attribute__((aligned(16))) char x0buf[XBUF];  // (two LDS objects: see bottleneck_resident3_kernel)
   __shared__ __attribute__((aligned(16))) char x1buf[XBUF];
@@ -410,46 +487,66 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
     }
   }
 
-  auto tile_px_of = [&](int tile, int& y0, int& x0) -> uint32_t {
-    const int img = tile / tiles_per_img;
-    const int trem = tile - img * tiles_per_img;
-    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-    y0 = ty * TH;
-    x0 = tx * TW;
-    return (uint32_t)((img * p.H + y0) * p.W + x0);
+  // the tile walk and the per-launch piece offsets: see bottleneck_resident3_kernel
+  const int g_img = (int)gridDim.x / tiles_per_img, g_rem = (int)gridDim.x - g_img * tiles_per_img;
+  const int g_ty = g_rem / p.tiles_x, g_tx = g_rem - g_ty * p.tiles_x;
+  auto advance = [&](BnTile c) {
+    c.tx += g_tx;
+    const int kx = c.tx >= p.tiles_x ? 1 : 0;
+    c.tx -= kx ? p.tiles_x : 0;
+    c.ty += g_ty + kx;
+    const int ky = c.ty >= p.tiles_y ? 1 : 0;
+    c.ty -= ky ? p.tiles_y : 0;
+    c.img += g_img + ky;
+    return c;
   };
-  auto issue_tile = [&](int tile, char* xbuf) {
-    int y0, x0;
-    const uint32_t px = tile_px_of(tile, y0, x0);
-    const bool exists = tile < p.n_tiles;
-    const bool interior = exists && y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;
-    int ln = lane0;
-    asm volatile("" : "+v"(ln));
-    const int lrow = ln >> 3;
-    const uint32_t lane_part = (uint32_t)(((ln & 7) ^ lrow) << 4);
+  uint32_t voff[NP];
+  {
+    const int lrow = lane0 >> 3;
+    const uint32_t lane_part = (uint32_t)(((lane0 & 7) ^ lrow) << 4);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const int row = (wave * NP + k) * 8 + lrow;
       const int hy = (row * 57) >> 10, hx = row - hy * HW;  // row / 18 for row < 1024
-      uint32_t off = (px + (uint32_t)((hy - 1) * p.W + (hx - 1))) * (CIN * 2) + lane_part;
-      bool ok = row < NHALO;
-      if (!interior) ok = ok && exists && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
-      off = ok ? off : TD_BN_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_p)(xbuf + (wave * NP + k) * 1024), 16, off, 0, 0, 0);
+      voff[k] = row < NHALO ? (uint32_t)(hy * p.W + hx) * (CIN * 2) + lane_part : TD_BN_OOB;
+    }
+  }
+  auto issue_tile = [&](BnTile c, char* xbuf) {
+    const int y0 = c.ty * TH, x0 = c.tx * TW;
+    const bool exists = c.img < p.N;
+    const bool interior = exists && y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;
+    const uint32_t px = (uint32_t)((c.img * p.H + y0) * p.W + x0);
+    if (interior) {
+      const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)((px - (uint32_t)(p.W + 1)) * (CIN * 2)));
+#pragma unroll
+      for (int k = 0; k < NP; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_p)(xbuf + (wave * NP + k) * 1024), 16, voff[k], soff, 0, 0);
+    } else {
+      int ln = lane0;
+      asm volatile("" : "+v"(ln));
+      const int lrow = ln >> 3;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int row = (wave * NP + k) * 8 + lrow;
+        const int hy = (row * 57) >> 10, hx = row - hy * HW;
+        uint32_t off = (px - (uint32_t)(p.W + 1)) * (CIN * 2) + voff[k];
+        const bool ok = row < NHALO && exists && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+        off = ok ? off : TD_BN_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_p)(xbuf + (wave * NP + k) * 1024), 16, off, 0, 0, 0);
+      }
     }
   };
 
-  auto process = [&](int tile, auto B_) {
+  auto process = [&](BnTile tc, BnTile tnext, auto B_) {
     constexpr int B = decltype(B_)::value;
     char* const xb_w = B ? x1buf : x0buf;
     char* const xo_w = B ? x0buf : x1buf;
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int lr = lane & 15, lg = lane >> 4;
-    int y0, x0;
-    const uint32_t tile_px = tile_px_of(tile, y0, x0);
+    const int y0 = tc.ty * TH, x0 = tc.tx * TW;
+    const uint32_t tile_px = (uint32_t)((tc.img * p.H + y0) * p.W + x0);
     const bool interior = y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W;
-    issue_tile(tile + gridDim.x, xo_w);  // (that buffer was last read in phase 3 of the previous tile, behind its closing barrier)
+    issue_tile(tnext, xo_w);  // (that buffer was last read in phase 3 of the previous tile, behind its closing barrier)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");  // this tile's pieces have landed; the next tile's stay in flight
     TD_BN_BARRIER();
     const char* const xb = xb_w;
@@ -472,20 +569,21 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
         for (int j = 0; j < 6; ++j)
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w1r[ks], *(const bf16x8*)&fr[ks][j], acc[j], 0, 0, 0);
       char* const hw = h1 + (half * 96 + lr) * HP + (16 * cg + 4 * lg) * 2;
+      uint2 o[6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        uint2 o;
-        o.x = bn_cvt_pk(fmaxf(acc[j][0], 0.f), fmaxf(acc[j][1], 0.f));
-        o.y = bn_cvt_pk(fmaxf(acc[j][2], 0.f), fmaxf(acc[j][3], 0.f));
-        if (!interior) {  // outside the image: conv2's zero padding (rows >= 180 are never read)
+      for (int j = 0; j < 6; ++j) o[j] = bn_relu_pack4(acc[j]);
+      if (!interior) {  // outside the image: conv2's zero padding (rows >= 180 are never read)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
           const int row = (half * 6 + j) * 16 + lr;
           const int hy = (row * 57) >> 10, hx = row - hy * HW;
           const bool inside = (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
-          o.x = inside ? o.x : 0u;
-          o.y = inside ? o.y : 0u;
+          o[j].x = inside ? o[j].x : 0u;
+          o[j].y = inside ? o[j].y : 0u;
         }
-        bn_lds_store8(hw + j * 16 * HP, o);
       }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) bn_lds_store8(hw + j * 16 * HP, o[j]);
     }
     TD_BN_BARRIER();  // h1 complete
     // ================= phase 2: conv2 3x3: channels 16*cg .. +15, tile rows 4*half .. + 3 (row block = one tile row of 16 pixels) =================
@@ -513,12 +611,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
       TD_BN_BARRIER();  // every wavefront has read its last h1 fragment: h2 overwrites it
       char* const hw = h1 + (half * 64 + lr) * HP + (16 * cg + 4 * lg) * 2;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint2 o;
-        o.x = bn_cvt_pk(fmaxf(acc[j][0], 0.f), fmaxf(acc[j][1], 0.f));
-        o.y = bn_cvt_pk(fmaxf(acc[j][2], 0.f), fmaxf(acc[j][3], 0.f));
-        bn_lds_store8(hw + j * 16 * HP, o);
-      }
+      for (int j = 0; j < 4; ++j) bn_lds_store8(hw + j * 16 * HP, bn_relu_pack4(acc[j]));
     }
     TD_BN_BARRIER();  // h2 complete
     // ================= phase 3: conv3 + downsample(x) + ReLU: channels 64*cg .. +63, tile rows 4*half .. + 3 =================
@@ -547,12 +640,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
           }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          uint2 o;
-          o.x = bn_cvt_pk(fmaxf(acc[i][0], 0.f), fmaxf(acc[i][1], 0.f));
-          o.y = bn_cvt_pk(fmaxf(acc[i][2], 0.f), fmaxf(acc[i][3], 0.f));
-          bn_lds_store8(stw + (stk ^ (uint32_t)(32 * i)), o);
-        }
+        for (int i = 0; i < 4; ++i) bn_lds_store8(stw + (stk ^ (uint32_t)(32 * i)), bn_relu_pack4(acc[i]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {  // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
@@ -566,11 +654,24 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
     }
     TD_BN_BARRIER();  // every wavefront is done with the tile: h1 and this input buffer may be overwritten
   };
-  issue_tile(blockIdx.x, x0buf);
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += 2 * gridDim.x) {
-    process(tile, std::integral_constant<int, 0>{});
-    if (tile + (int)gridDim.x >= p.n_tiles) break;
-    process(tile + gridDim.x, std::integral_constant<int, 1>{});
+  BnTile cur;  // (host: gridDim.x <= n_tiles)
+  cur.img = (int)blockIdx.x / tiles_per_img;
+  {
+    const int trem = (int)blockIdx.x - cur.img * tiles_per_img;
+    cur.ty = trem / p.tiles_x;
+    cur.tx = trem - cur.ty * p.tiles_x;
+  }
+  BnTile nxt = advance(cur);
+  issue_tile(cur, x0buf);
+  for (;;) {
+    process(cur, nxt, std::integral_constant<int, 0>{});
+    cur = nxt;
+    nxt = advance(cur);
+    if (cur.img >= p.N) break;
+    process(cur, nxt, std::integral_constant<int, 1>{});
+    cur = nxt;
+    nxt = advance(cur);
+    if (cur.img >= p.N) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (out-of-range) pieces must not outlive the workgroup's LDS
 }
