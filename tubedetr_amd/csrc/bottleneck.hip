@@ -61,6 +61,10 @@ typedef unsigned int bn_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void bn_store16(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(bn_u32x4{v.x, v.y, v.z, v.w}, rs, (int)off, 0, 0);
 }
+// the same with a per-launch lane offset and a SCALAR offset for everything that changes (tile, row block): no vector arithmetic per store
+__device__ __forceinline__ void bn_store16s(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, uint4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(bn_u32x4{v.x, v.y, v.z, v.w}, rs, (int)voff, (int)soff, 0);
+}
 // 8-byte LDS store as inline asm.  A DS WRITE the compiler can see is preceded by s_waitcnt vmcnt(0) whenever an LDS-DMA may be in
 // flight (its wait-count pass applies alias information to DS reads only) - in the double-buffered kernel that would wait for the
 // NEXT tile's pieces at the first result written.  Ordering is what the surrounding code provides anyway: DS operations of a wavefront
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
   __shared__ __attribute__((aligned(16))) char xall0[XBUF];
   __shared__ __attribute__((aligned(16))) char xall1[XBUF];
   __shared__ __attribute__((aligned(16))) char h1[HROWS * HP];
+  __shared__ __attribute__((aligned(16))) char h2[TH * TW * HP];  // (its own 10 KiB: no barrier between the last h1 fragment read and the h2 stores)
   __shared__ __attribute__((aligned(16))) char ostage[8][TD_BN_STAGE_BYTES];
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -217,6 +222,15 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
       voff[k] = row < 100 ? (uint32_t)(hy * p.W + hx) * (CIN * 2) + lane_part : TD_BN_OOB;
     }
   }
+  // also per launch: the unit-matrix block of phase 3's identity MFMA (row (channel) lr, columns 8*lg .. + 7: 1.0 = 0x3F80 at column lr)
+  // and the lane's part of an output store's offset (staging row lane >> 3 = pixel (tile row (lane >> 4) [+ 4 ps], column (lane >> 3) & 1 [+ 2 mb]))
+  uint4 eye = make_uint4(0u, 0u, 0u, 0u);
+  if ((lr >> 3) == lg) {
+    const uint32_t one = 0x3F80u << (16 * (lr & 1));
+    const int d2 = (lr & 7) >> 1;
+    eye.x = d2 == 0 ? one : 0u; eye.y = d2 == 1 ? one : 0u; eye.z = d2 == 2 ? one : 0u; eye.w = d2 == 3 ? one : 0u;
+  }
+  const uint32_t st_lane = (uint32_t)(((lane0 >> 4) * p.W + ((lane0 >> 3) & 1)) * 512 + cg * 128 + (lane0 & 7) * 16);
   // the 7 pieces of tile c (past the end: out-of-range offsets, zero fill) into buffer `xbuf`
   auto issue_tile = [&](BnTile c, char* xbuf) {
     const int y0 = c.ty * TH, x0 = c.tx * TW;
@@ -344,8 +358,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w2r[tap * 2 + h], *(const bf16x8*)&fr[tap & 1][h * 2 + j], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      TD_BN_BARRIER();  // every wavefront has read its last h1 fragment: h2 overwrites it
-      char* const hw = h1 + (half * 32 + lr) * HP + (16 * cg + 4 * lg) * 2;
+      char* const hw = h2 + (half * 32 + lr) * HP + (16 * cg + 4 * lg) * 2;  // (last read in phase 3 of the previous tile, three barriers back)
 #pragma unroll
       for (int j = 0; j < 2; ++j) bn_lds_store8(hw + j * 16 * HP, bn_relu_pack4(acc[j]));
     }
@@ -356,24 +369,29 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
       // matrix in its first 16 columns - the activation operand is the pixel's 16 channels 64*cg + 16i .. of the input tile still
       // in LDS (lane group lg < 2 reads channels 16i + 8lg .. + 7, groups 2, 3 read the same bytes against zero weights).
       // bf16 x 1.0 accumulated in fp32 is exact, and it replaces an 8-byte LDS read + 10 VALU operations (unpack, add) per fragment.
-      uint4 eye = make_uint4(0u, 0u, 0u, 0u);  // row (channel) lr, columns 8*lg .. + 7: 1.0 (0x3F80) at column lr
-      if ((lr >> 3) == lg) {
-        const uint32_t one = 0x3F80u << (16 * (lr & 1));
-        const int d2 = (lr & 7) >> 1;
-        eye.x = d2 == 0 ? one : 0u; eye.y = d2 == 1 ? one : 0u; eye.z = d2 == 2 ? one : 0u; eye.w = d2 == 3 ? one : 0u;
-      }
       const int hp0 = (cyl + 1) * HW + 4 * half + cxl + 1;                       // halo row of the lane's centre pixel in its first row block (+ 2 for the second)
       const char* const idb = xb + cg * (HROWS * 128) + hp0 * 128;
       const uint32_t idk0 = (uint32_t)(((lg & 1) ^ (hp0 & 7)) << 4);             // 16-byte chunk (2i | lg & 1) ^ (row & 7) = 32i ^ idk
       const uint32_t idk1 = (uint32_t)(((lg & 1) ^ ((hp0 + 2) & 7)) << 4);
-      const char* const hr3 = h1 + (half * 32 + lr) * HP + lg * 16;              // + j * 16 * HP + ks * 64
+      const char* const hr3 = h2 + (half * 32 + lr) * HP + lg * 16;              // + j * 16 * HP + ks * 64
       char* const stw = ostage[wave] + lr * 128 + (lg & 1) * 8;
       const uint32_t stk = (uint32_t)(((lg >> 1) ^ (lr & 7)) << 4);
       const char* const strd = ostage[wave] + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + ps * 1024
-      // staging row = pixel lr of the block = (tile row lr >> 1, column 2 * mb + (lr & 1)); a store instruction takes rows 8ps .. 8ps + 7
-      const int st_y = lane >> 4, st_x = (lane >> 3) & 1;  // + 4 * ps rows, + 2 * mb columns
-      const uint32_t st_lane = (uint32_t)((st_y * p.W + st_x) * 512 + cg * 128 + (lane & 7) * 16);
-      const bool full = y0 + TH <= p.H && x0 + TW <= p.W;  // wave-uniform
+      const bool full = y0 + TH <= p.H && x0 + TW <= p.W;  // wave-uniform; ONE branch per tile selects the phase's code (no branch per store)
+      auto phase3 = [&](auto FULL_) {
+      constexpr bool FULL = decltype(FULL_)::value;
+      // all twelve fragment reads of the phase first (the 24 MFMAs then wait by count, not for a round trip each)
+      uint4 a[2][2], xi[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a[j][ks] = *(const uint4*)(hr3 + j * 16 * HP + ks * 64);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xi[j][i] = *(const uint4*)(idb + j * (2 * 128) + ((j ? idk1 : idk0) ^ (uint32_t)(32 * i)));
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int mb = 2 * half + j;
@@ -382,31 +400,38 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{b3v[i][0], b3v[i][1], b3v[i][2], b3v[i][3]};  // the bias seeds the accumulator
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const uint4 a = *(const uint4*)(hr3 + j * 16 * HP + ks * 64);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w3r[i][ks], *(const bf16x8*)&a, acc[i], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w3r[i][ks], *(const bf16x8*)&a[j][ks], acc[i], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint4 xi = *(const uint4*)(idb + j * (2 * 128) + ((j ? idk1 : idk0) ^ (uint32_t)(32 * i)));
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&eye, *(const bf16x8*)&xi, acc[i], 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&eye, *(const bf16x8*)&xi[j][i], acc[i], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) bn_lds_store8(stw + (stk ^ (uint32_t)(32 * i)), bn_relu_pack4(acc[i]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {  // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
-          const uint4 o16 = *(const uint4*)(strd + ps * 1024);
-          uint32_t off = (tile_px + (uint32_t)(4 * ps * p.W + 2 * mb)) * 512u + st_lane;
-          if (!full) off = (y0 + 4 * ps + st_y < p.H && x0 + 2 * mb + st_x < p.W) ? off : TD_BN_OOB;
+        // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
+        const uint4 o16a = *(const uint4*)(strd), o16b = *(const uint4*)(strd + 1024);
 #if TD_BN_ABL & 2
-          asm volatile("" ::"v"(off), "v"(o16.x), "v"(o16.y), "v"(o16.z), "v"(o16.w));
+        asm volatile("" ::"v"(o16a.x), "v"(o16a.y), "v"(o16a.z), "v"(o16a.w), "v"(o16b.x), "v"(o16b.y), "v"(o16b.z), "v"(o16b.w));
 #else
-          bn_store16(rs_out, off, o16);
-#endif
+        if constexpr (FULL) {  // the lane's offset is per launch, tile and row block are the scalar offset
+          const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)((tile_px + (uint32_t)(2 * mb)) * 512u));
+          bn_store16s(rs_out, st_lane, so, o16a);
+          bn_store16s(rs_out, st_lane, so + (uint32_t)(4 * p.W) * 512u, o16b);
+        } else {
+          const int st_y = lane >> 4, st_x = (lane >> 3) & 1;
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            uint32_t off = (tile_px + (uint32_t)(4 * ps * p.W + 2 * mb)) * 512u + st_lane;
+            off = (y0 + 4 * ps + st_y < p.H && x0 + 2 * mb + st_x < p.W) ? off : TD_BN_OOB;
+            bn_store16(rs_out, off, ps ? o16b : o16a);
+          }
         }
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next row block overwrites the region
       }
+      };
+      if (full) phase3(std::true_type{});
+      else phase3(std::false_type{});
     }
     TD_BN_BARRIER();  // every wavefront is done with the tile: h1 and this input buffer may be overwritten
   };
@@ -450,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
   __shared__ __attribute__((aligned(16))) char x0buf[XBUF];  // (two LDS objects: see bottleneck_resident3_kernel)
   __shared__ __attribute__((aligned(16))) char x1buf[XBUF];
   __shared__ __attribute__((aligned(16))) char h1[HROWS * HP];
+  __shared__ __attribute__((aligned(16))) char h2[TH * TW * HP];  // (its own 20 KiB: no barrier between the last h1 fragment read and the h2 stores)
   __shared__ __attribute__((aligned(16))) char ostage[8][TD_BN_STAGE_BYTES];
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -511,6 +537,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
       voff[k] = row < NHALO ? (uint32_t)(hy * p.W + hx) * (CIN * 2) + lane_part : TD_BN_OOB;
     }
   }
+  const uint32_t st_lane = (uint32_t)((lane0 >> 3) * 512 + cg * 128 + (lane0 & 7) * 16);  // the lane's part of an output store's offset
   auto issue_tile = [&](BnTile c, char* xbuf) {
     const int y0 = c.ty * TH, x0 = c.tx * TW;
     const bool exists = c.img < p.N;
@@ -608,49 +635,67 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w2r[ks], *(const bf16x8*)&fr[ks & 1][j], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      TD_BN_BARRIER();  // every wavefront has read its last h1 fragment: h2 overwrites it
-      char* const hw = h1 + (half * 64 + lr) * HP + (16 * cg + 4 * lg) * 2;
+      char* const hw = h2 + (half * 64 + lr) * HP + (16 * cg + 4 * lg) * 2;  // (last read in phase 3 of the previous tile, three barriers back)
 #pragma unroll
       for (int j = 0; j < 4; ++j) bn_lds_store8(hw + j * 16 * HP, bn_relu_pack4(acc[j]));
     }
     TD_BN_BARRIER();  // h2 complete
     // ================= phase 3: conv3 + downsample(x) + ReLU: channels 64*cg .. +63, tile rows 4*half .. + 3 =================
     {
-      const char* const hr3 = h1 + (half * 64 + lr) * HP + lg * 16;  // + j * 16 * HP + ks * 64
+      const char* const hr3 = h2 + (half * 64 + lr) * HP + lg * 16;  // + j * 16 * HP + ks * 64
       char* const stw = ostage[wave] + lr * 128 + (lg & 1) * 8;
       const uint32_t stk = (uint32_t)(((lg >> 1) ^ (lr & 7)) << 4);
       const char* const strd = ostage[wave] + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);  // + ps * 1024
-      const uint32_t st_lane = (uint32_t)((lane >> 3) * 512 + cg * 128 + (lane & 7) * 16);
-      const bool full = y0 + TH <= p.H && x0 + TW <= p.W;  // wave-uniform
+      const bool full = y0 + TH <= p.H && x0 + TW <= p.W;  // wave-uniform; ONE branch per tile selects the phase's code (no branch per store)
+      auto phase3 = [&](auto FULL_) {
+      constexpr bool FULL = decltype(FULL_)::value;
+      // the four fragment reads of a tile row in front of its 16 MFMAs (a row ahead they cost 16 more registers than the kernel has)
+      uint4 fa[1][2], fx[1][2];
+      auto load_row = [&](int j, uint4 (&a)[2], uint4 (&xd)[2]) {
+        const int hp = (4 * half + j + 1) * HW + lr + 1;  // this pixel in the input halo tile (the downsample branch reads it)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          a[ks] = *(const uint4*)(hr3 + j * 16 * HP + ks * 64);
+          xd[ks] = *(const uint4*)(xb + hp * 128 + (((ks * 4 + lg) ^ (hp & 7)) << 4));
+        }
+      };
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int mb = 4 * half + j;  // tile row
+        load_row(j, fa[0], fx[0]);
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{b3v[i][0], b3v[i][1], b3v[i][2], b3v[i][3]};  // b3 + bd seed the accumulator
-        const int hp = (mb + 1) * HW + lr + 1;  // this pixel in the input halo tile (the downsample branch reads it)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const uint4 a = *(const uint4*)(hr3 + j * 16 * HP + ks * 64);
-          const uint4 xd = *(const uint4*)(xb + hp * 128 + (((ks * 4 + lg) ^ (hp & 7)) << 4));
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w3r[i][ks], *(const bf16x8*)&a, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&wdr[i][ks], *(const bf16x8*)&xd, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&w3r[i][ks], *(const bf16x8*)&fa[0][ks], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&wdr[i][ks], *(const bf16x8*)&fx[0][ks], acc[i], 0, 0, 0);
           }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) bn_lds_store8(stw + (stk ^ (uint32_t)(32 * i)), bn_relu_pack4(acc[i]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
+        const uint4 o16a = *(const uint4*)(strd), o16b = *(const uint4*)(strd + 1024);
+        if constexpr (FULL) {  // the lane's offset is per launch, tile and tile row are the scalar offset
+          const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)((tile_px + (uint32_t)(mb * p.W)) * 512u));
+          bn_store16s(rs_out, st_lane, so, o16a);
+          bn_store16s(rs_out, st_lane, so + 8u * 512u, o16b);
+        } else {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {  // 8 pixels x 128 bytes per store instruction: lane = (pixel, 16-byte chunk)
-          const uint4 o16 = *(const uint4*)(strd + ps * 1024);
-          uint32_t off = (tile_px + (uint32_t)(mb * p.W + ps * 8)) * 512u + st_lane;
-          if (!full) off = (y0 + mb < p.H && x0 + ps * 8 + (lane >> 3) < p.W) ? off : TD_BN_OOB;
-          bn_store16(rs_out, off, o16);
+          for (int ps = 0; ps < 2; ++ps) {
+            uint32_t off = (tile_px + (uint32_t)(mb * p.W + ps * 8)) * 512u + st_lane;
+            off = (y0 + mb < p.H && x0 + ps * 8 + (lane >> 3) < p.W) ? off : TD_BN_OOB;
+            bn_store16(rs_out, off, ps ? o16b : o16a);
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads retired before the next row overwrites the region
       }
+      };
+      if (full) phase3(std::true_type{});
+      else phase3(std::false_type{});
     }
     TD_BN_BARRIER();  // every wavefront is done with the tile: h1 and this input buffer may be overwritten
   };

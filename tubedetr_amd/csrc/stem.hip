@@ -29,6 +29,15 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   bf16x2_v v = {(__bf16)lo, (__bf16)hi};
   return *(uint32_t*)&v;
 }
+// ReLU of two packed bf16: max(x, 0) on the 16-bit integers (v_pk_max_i16): negative values, -0.0 included, become +0.0 - one operation
+// per pair behind the conversion (fmaxf(x, 0.f) in front of it is two per value).  As asm because the compiler splits the conversion
+// when it sees the vector form; the conversion itself must stay the compiler's instruction (it is the first reader of the MFMA result,
+// and the wait states that read needs are inserted by the compiler's hazard pass, which does not look into asm operands).
+__device__ __forceinline__ uint32_t relu_pk_bf16(uint32_t v) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(v));
+  return r;
+}
 // element-wise maximum of two packed pairs of NON-NEGATIVE bf16 values: their bit patterns order like unsigned integers (v_pk_max_u16)
 __device__ __forceinline__ uint32_t max_pk_nonneg_bf16(uint32_t a, uint32_t b) {
   const u16x2_v r = __builtin_elementwise_max(*(const u16x2_v*)&a, *(const u16x2_v*)&b);
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
       const char* a0 = patch + ((2 * cyl) * PC + cxl + lg) * 16;  // tap (r = 0, t = lg) of this lane's output pixel
       f32x4 acc[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) acc[i] = f32x4{bias4[i][0], bias4[i][1], bias4[i][2], bias4[i][3]};  // the bias seeds the accumulator
       uint4 af[7];
 #pragma unroll
       for (int r = 0; r < 7; ++r) af[r] = *(const uint4*)(a0 + r * (PC * 16));
@@ -139,14 +148,12 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
       // D[n = i*16 + 4*lg + q][m = lr]: this lane holds 4 consecutive channels of output pixel m
       const int cy = cy0 + cyl, cx = cx0 + cxl;
       const bool inside = m < MROWS && (unsigned)cy < (unsigned)p.CH && (unsigned)cx < (unsigned)p.CW;
+      const uint32_t keep = inside ? 0xffffffffu : 0u;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = inside ? fmaxf(acc[i][q] + bias4[i][q], 0.f) : 0.f;
-        uint2 o;  // (sign bits cleared: a -0.0 out of the ReLU would not order as an unsigned pattern in the pooling below)
-        o.x = cvt_pk_bf16(v[0], v[1]) & 0x7fff7fffu;
-        o.y = cvt_pk_bf16(v[2], v[3]) & 0x7fff7fffu;
+        uint2 o;  // (the integer ReLU leaves no -0.0, which would not order as an unsigned pattern in the pooling below)
+        o.x = relu_pk_bf16(cvt_pk_bf16(acc[i][0], acc[i][1])) & keep;
+        o.y = relu_pk_bf16(cvt_pk_bf16(acc[i][2], acc[i][3])) & keep;
         *(uint2*)(ctile + m * CPITCH + (i * 16 + 4 * lg) * 2) = o;
       }
     }
@@ -156,8 +163,17 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
     //  behind a branch cannot be counted by the compiler, and the wait for the prefetched patch below would then also wait for them)
 #pragma unroll
     for (int it = 0; it < (TY * TX * 8 + 255) / 256; ++it) {
+      // A wavefront pools 8 consecutive pooled pixels x 8 chunks of 16 bytes; WHICH lane takes which (pixel, chunk) is chosen for the LDS
+      // banks: ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32), and with the 144-byte pitch
+      // pooled pixel q starts 2q sixteen-byte slots into the 256-byte bank row - lane = 8 * pixel + chunk put pixels 1, 2, 3 of a group
+      // on top of each other (12 cycles per read instead of 4, tools/lds_bank_model.py; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.47).
+      // With quad k = (lane >> 2) & 7: chunk half = bit 1 of k, pixel = (k0 ^ k1 ^ k2) + 4 k2 + 2 (lane >> 5) a group reads both halves of
+      // pixels q and q + 4 (8 slots apart): one cycle per group, except where the 8 pixels wrap around the end of a tile row.
       const int e = t + it * 256;
-      const int c8 = e & 7, px_ = (e >> 3) % TX, py_ = min((e >> 3) / TX, TY - 1);
+      const int kq = (e >> 2) & 7;
+      const int c8 = ((kq & 2) << 1) + (e & 3);
+      const int qe = ((e >> 6) << 3) + (((kq ^ (kq >> 1) ^ (kq >> 2)) & 1) + (kq & 4) + ((e >> 4) & 2));  // pooled pixel of the tile, row-major
+      const int px_ = qe % TX, py_ = min(qe / TX, TY - 1);
       const int py = py0 + py_, px = px0 + px_;
       uint4 o = make_uint4(0, 0, 0, 0);  // non-negative bf16 values order like their bit patterns: packed unsigned maxima, two channels per operation
 #pragma unroll
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemParams p) {
           o.z = max_pk_nonneg_bf16(o.z, v.z);
           o.w = max_pk_nonneg_bf16(o.w, v.w);
         }
-      const bool live = e < TY * TX * 8 && py < p.PH && px < p.PW;
+      const bool live = qe < TY * TX && py < p.PH && px < p.PW;
       const uint32_t off = live ? (uint32_t)((((size_t)img * p.PH + py) * p.PW + px) * 128 + c8 * 16) : 0xFFFFFFF0u;
       __builtin_amdgcn_raw_buffer_store_b128(st_u32x4{o.x, o.y, o.z, o.w}, rs_y, (int)off, 0, 0);
     }
