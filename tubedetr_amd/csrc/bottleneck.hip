@@ -82,7 +82,7 @@ __device__ __forceinline__ void bn_lds_store8(char* p, uint2 v) {
 //     (10 slots: rows r and r + 8 land 80 = 5 x 16 slots apart, i.e. on the other half of the bank row); the 144 bytes of rounds 4 - 5
 //     were two-way for consecutive rows and THREE-way for the 2 x 8-pixel row blocks of the 256-channel kernel (pixels 0 and 14 of a
 //     block share a slot for every pitch).  rocprofv3 had it in plain sight: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50 / 0.44
-//     (profiles/r06_pmc_LDS_per_kernel.csv), the sum of exactly these patterns;
+//     (profiles/r06_pmc_LDS_per_kernel_before_layer1_rework.csv), the sum of exactly these patterns;
 //   * the 256-channel kernel's row blocks are therefore 8 rows x 2 COLUMNS of the tile: halo rows 10 apart x 2 adjacent - with the 160-byte
 //     pitch every tap's fragment read, h2's reads and the identity reads from the swizzled input tile are all one cycle per group.
 // The 8-byte result stores pay for it (pitch 160: four rows per 128-byte window, 16 instead of 8 cycles), 6 per wavefront and tile
