@@ -21,6 +21,9 @@
 #include <algorithm>
 #include <vector>
 
+#ifndef TD_BIG_XCD_CONTIG
+#define TD_BIG_XCD_CONTIG 1  // conv_gemm_big8_kernel: an XCD walks a contiguous range of row tiles (0: row tile = 8 * seq + XCD; A/B builds)
+#endif
 namespace td {
 
 struct GemmParams {
@@ -705,9 +708,19 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8_kernel(GemmParams p) {
   };
   // tile (rows m0.., columns n0..) of virtual block vb; the blocks past the last row tile (grid rounded up to 8) can only be a
   // workgroup's LAST ones
+#if TD_BIG_XCD_CONTIG
+  // XCD x (= vb & 7: workgroups go to XCDs round-robin, the grid is a multiple of 8) walks a CONTIGUOUS range of row tiles: neighbouring
+  // row tiles of a 3x3 layer share their halo rows (2 x (W + 1) of 256 rows at W = 22: 18 %), and with row tile = 8 * seq + x every
+  // one of them was fetched into two L2s (traffic 1.19x of the algorithmic bytes); now the 32 tiles an XCD has in flight are neighbours.
+  const int mtx = (cdiv(p.M, BM) + 7) / 8;
+  auto tile_m0 = [&](int vb) { const int seq = vb >> 3; return ((vb & 7) * mtx + seq / NT) * BM; };
+  auto tile_n0 = [&](int vb) { const int seq = vb >> 3; return (seq - (seq / NT) * NT) * BN; };
+  auto tile_ok = [&](int vb) { return vb < nvb && (vb >> 3) / NT < mtx && tile_m0(vb) < p.M; };
+#else
   auto tile_m0 = [&](int vb) { const int seq = vb >> 3; return ((seq / NT) * 8 + (vb & 7)) * BM; };
   auto tile_n0 = [&](int vb) { const int seq = vb >> 3; return (seq - (seq / NT) * NT) * BN; };
   auto tile_ok = [&](int vb) { return vb < nvb && tile_m0(vb) < p.M; };
+#endif
 
   // DMA piece q (0..3) of this wavefront on the activation side: tile rows xrow(q) .. + 8 = the part of QUARTER q (the rows the
   // readers consume in phase q: M fragments 2q, 2q + 1 of both row groups) that this wavefront stages
@@ -1022,7 +1035,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_big8n_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int NT = d.Nc / BN;
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+#if TD_BIG_XCD_CONTIG
+  const int mtx = (cdiv(p.M, BM) + 7) / 8;  // an XCD takes a contiguous range of row tiles (halo rows shared in ITS L2: see conv_gemm_big8_kernel)
+  const int mt = xcd * mtx + seq / NT, nt = seq - (seq / NT) * NT;
+#else
   const int mt = (seq / NT) * 8 + xcd, nt = seq - (seq / NT) * NT;
+#endif
   const int m0 = mt * BM, n0 = nt * BN;
   if (m0 >= p.M) return;
   const int lrow = lane >> 3;
