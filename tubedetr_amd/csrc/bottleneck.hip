@@ -46,10 +46,37 @@ __device__ __forceinline__ uint32_t bn_relu_pk(uint32_t v) {
   return r;
 }
 __device__ __forceinline__ uint2 bn_relu_pack4(const f32x4& a) { return make_uint2(bn_relu_pk(bn_cvt_pk(a[0], a[1])), bn_relu_pk(bn_cvt_pk(a[2], a[3]))); }
+#ifndef TD_BN_XCD_CONTIG
+#define TD_BN_XCD_CONTIG 1  // an XCD's workgroups walk a contiguous range of tiles (0: tile = blockIdx + k * gridDim; A/B builds)
+#endif
 // The walk over tiles (tile += gridDim.x) without a division per tile: (image, tile row, tile column) advanced with carries.
 struct BnTile {
   int img, ty, tx;
 };
+// Which tiles a workgroup takes.  Workgroups go to the 8 XCDs round-robin (XCD = blockIdx & 7), each XCD has its own L2, and neighbouring
+// tiles share their halo (an 8 x 8 tile reads 10 x 10 pixels): with tile = blockIdx + k * gridDim no two neighbours ever met in one L2
+// and every halo pixel was fetched from beyond it once per tile that needs it (traffic 1.22x of the algorithmic bytes).  Now XCD x takes the
+// contiguous range [x * ceil(n / 8), ...) and its 32 workgroups walk it 32 tiles at a time: at res 352 that window is three tile rows of
+// one frame.  (Grids that are not a multiple of 8 - fewer tiles than CUs - keep the old order.)
+struct BnWalk {
+  int start, stride, count;
+};
+__device__ __forceinline__ BnWalk bn_walk(int n_tiles) {
+  const int b = (int)blockIdx.x, g = (int)gridDim.x;
+  BnWalk w;
+  if ((g & 7) == 0 && TD_BN_XCD_CONTIG) {
+    const int x = b & 7, l = b >> 3, per = (n_tiles + 7) >> 3;
+    const int lim = min(per, n_tiles - x * per);
+    w.stride = g >> 3;
+    w.start = x * per + l;
+    w.count = lim > l ? (lim - l + w.stride - 1) / w.stride : 0;
+  } else {
+    w.stride = g;
+    w.start = b;
+    w.count = b < n_tiles ? (n_tiles - b + g - 1) / g : 0;
+  }
+  return w;
+}
 typedef unsigned int bn_u32x2 __attribute__((ext_vector_type(2)));
 // 8-byte output store through a buffer descriptor: a lane whose pixel lies outside the image passes an out-of-range offset and the
 // hardware drops the store.  No branch around the stores: behind a branch the compiler cannot count them in its vmcnt bookkeeping
@@ -192,7 +219,9 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
     for (int i = 0; i < 4; ++i) b3v[i][q] = p.b3[64 * cg + 16 * i + 4 * lg + q];
   }
   // ---- the tile walk: tile += gridDim.x as (image, tile row, tile column) with carries (one division per launch, none per tile) ----
-  const int g_img = (int)gridDim.x / tiles_per_img, g_rem = (int)gridDim.x - g_img * tiles_per_img;
+  const BnWalk walk = bn_walk(p.n_tiles);
+  if (walk.count <= 0) return;  // (uniform, before any barrier)
+  const int g_img = walk.stride / tiles_per_img, g_rem = walk.stride - g_img * tiles_per_img;
   const int g_ty = g_rem / p.tiles_x, g_tx = g_rem - g_ty * p.tiles_x;
   auto advance = [&](BnTile c) {
     c.tx += g_tx;
@@ -435,23 +464,31 @@ __global__ __launch_bounds__(512, 2) void bottleneck_resident3_kernel(BneckParam
     }
     TD_BN_BARRIER();  // every wavefront is done with the tile: h1 and this input buffer may be overwritten
   };
-  BnTile cur;  // (host: gridDim.x <= n_tiles)
-  cur.img = (int)blockIdx.x / tiles_per_img;
+  BnTile cur;
+  cur.img = walk.start / tiles_per_img;
   {
-    const int trem = (int)blockIdx.x - cur.img * tiles_per_img;
+    const int trem = walk.start - cur.img * tiles_per_img;
     cur.ty = trem / p.tiles_x;
     cur.tx = trem - cur.ty * p.tiles_x;
   }
-  BnTile nxt = advance(cur);
+  int left = walk.count;  // tiles of this workgroup from `cur` on; a tile past the last one is marked by img = N ("does not exist": zero-fill pieces)
+  auto after = [&](BnTile c) {
+    BnTile n = advance(c);
+    if (left <= 1) n.img = p.N;
+    return n;
+  };
+  BnTile nxt = after(cur);
   issue_tile(cur, xall0);
   for (;;) {
     process(cur, nxt, std::integral_constant<int, 0>{});
     cur = nxt;
-    nxt = advance(cur);
+    --left;
+    nxt = after(cur);
     if (cur.img >= p.N) break;
     process(cur, nxt, std::integral_constant<int, 1>{});
     cur = nxt;
-    nxt = advance(cur);
+    --left;
+    nxt = after(cur);
     if (cur.img >= p.N) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (out-of-range) pieces must not outlive the workgroup's LDS
@@ -514,7 +551,9 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
   }
 
   // the tile walk and the per-launch piece offsets: see bottleneck_resident3_kernel
-  const int g_img = (int)gridDim.x / tiles_per_img, g_rem = (int)gridDim.x - g_img * tiles_per_img;
+  const BnWalk walk = bn_walk(p.n_tiles);
+  if (walk.count <= 0) return;  // (uniform, before any barrier)
+  const int g_img = walk.stride / tiles_per_img, g_rem = walk.stride - g_img * tiles_per_img;
   const int g_ty = g_rem / p.tiles_x, g_tx = g_rem - g_ty * p.tiles_x;
   auto advance = [&](BnTile c) {
     c.tx += g_tx;
@@ -699,23 +738,31 @@ __global__ __launch_bounds__(512, 2) void bottleneck_first3_kernel(BneckParams p
     }
     TD_BN_BARRIER();  // every wavefront is done with the tile: h1 and this input buffer may be overwritten
   };
-  BnTile cur;  // (host: gridDim.x <= n_tiles)
-  cur.img = (int)blockIdx.x / tiles_per_img;
+  BnTile cur;
+  cur.img = walk.start / tiles_per_img;
   {
-    const int trem = (int)blockIdx.x - cur.img * tiles_per_img;
+    const int trem = walk.start - cur.img * tiles_per_img;
     cur.ty = trem / p.tiles_x;
     cur.tx = trem - cur.ty * p.tiles_x;
   }
-  BnTile nxt = advance(cur);
+  int left = walk.count;  // tiles of this workgroup from `cur` on; a tile past the last one is marked by img = N ("does not exist": zero-fill pieces)
+  auto after = [&](BnTile c) {
+    BnTile n = advance(c);
+    if (left <= 1) n.img = p.N;
+    return n;
+  };
+  BnTile nxt = after(cur);
   issue_tile(cur, x0buf);
   for (;;) {
     process(cur, nxt, std::integral_constant<int, 0>{});
     cur = nxt;
-    nxt = advance(cur);
+    --left;
+    nxt = after(cur);
     if (cur.img >= p.N) break;
     process(cur, nxt, std::integral_constant<int, 1>{});
     cur = nxt;
-    nxt = advance(cur);
+    --left;
+    nxt = after(cur);
     if (cur.img >= p.N) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (out-of-range) pieces must not outlive the workgroup's LDS
