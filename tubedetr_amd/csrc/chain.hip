@@ -300,11 +300,14 @@ __device__ __forceinline__ void pw_chain2_body(const ChainParams& p, const int M
         asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_accvgpr_read_b32 %1, a%c3" : "=v"(a0_), "=v"(a1_) : "n"(A3 + 4 * (J * (2 * S + H) + JJ) + R0), "n"(A3 + 4 * (J * (2 * S + H) + JJ) + R0 + 1));
         float x0 = a0_ + b3r[S][H][R0];
         float x1 = a1_ + b3r[S][H][R0 + 1];
-        x0 = fmaxf(x0 + __uint_as_float(wd << 16), 0.f);
-        x1 = fmaxf(x1 + __uint_as_float(wd & 0xffff0000u), 0.f);
+        x0 += __uint_as_float(wd << 16);
+        x1 += __uint_as_float(wd & 0xffff0000u);
         typedef __bf16 b2 __attribute__((ext_vector_type(2)));
         const b2 pk = {(__bf16)x0, (__bf16)x1};
-        oc[JJ][S][PP] = *(const uint32_t*)&pk;
+        // ReLU BEHIND the rounding, on the packed pair (v_pk_max_i16 against 0: a negative bf16, -0.0 included, becomes +0.0): one operation
+        // per pair - fmaxf(x, 0.f) in front of the conversion is two per VALUE (the compiler quiets a possible signalling NaN first).  Same
+        // values as the two-launch form, which clamps first: rounding is monotonic and keeps the sign.
+        asm("v_pk_max_i16 %0, %1, 0" : "=v"(oc[JJ][S][PP]) : "v"(*(const uint32_t*)&pk));
       }
     }
     if constexpr (Q == 5) {
@@ -455,10 +458,11 @@ __device__ __forceinline__ void pw_chain2_body(const ChainParams& p, const int M
       float v[8];                                                                                                                          \
       if (j == 0) { TD_ACC1_READ(G, 0) } else { TD_ACC1_READ(G, 1) }                                                                       \
       _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                                        \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) v[4 * h + r] = fmaxf(v[4 * h + r] + __uint_as_float(bb[(G) & 1][h][r]), 0.f);        \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) v[4 * h + r] = v[4 * h + r] + __uint_as_float(bb[(G) & 1][h][r]);                    \
       typedef __bf16 b2 __attribute__((ext_vector_type(2)));                                                                               \
       b2 a0 = {(__bf16)v[0], (__bf16)v[1]}, a1 = {(__bf16)v[2], (__bf16)v[3]}, a2 = {(__bf16)v[4], (__bf16)v[5]}, a3 = {(__bf16)v[6], (__bf16)v[7]}; \
-      const cu32x4 o = {*(uint32_t*)&a0, *(uint32_t*)&a1, *(uint32_t*)&a2, *(uint32_t*)&a3};                                              \
+      cu32x4 o = {*(uint32_t*)&a0, *(uint32_t*)&a1, *(uint32_t*)&a2, *(uint32_t*)&a3};                                                    \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) asm("v_pk_max_i16 %0, %1, 0" : "=v"(o[r]) : "v"(o[r])); /* ReLU on the rounded pairs */ \
       const uint32_t off = m < p.M ? ((uint32_t)m * (uint32_t)P + (uint32_t)(32 * (G) + 8 * lg)) * ES : OOB;                               \
       __builtin_amdgcn_raw_buffer_store_b128(o, rs_h1, (int)off, 0, 0);                                                                    \
     }                                                                                                                                      \
