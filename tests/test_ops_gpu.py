@@ -222,7 +222,8 @@ def test_fused_stem_equals_conv_relu_maxpool(size):
     assert (y.float() - two.float()).abs().gt(0).float().mean().item() < 0.05
 
 
-@pytest.mark.parametrize("cfg", [(2, 24, 32, 256), (3, 19, 27, 256), (2, 24, 32, 64), (1, 9, 50, 64), (2, 88, 88, 256), (1, 5, 3, 64)])
+@pytest.mark.parametrize("cfg", [(2, 24, 32, 256), (3, 19, 27, 256), (2, 24, 32, 64), (1, 9, 50, 64), (2, 88, 88, 256), (1, 5, 3, 64),
+                                 (4, 72, 70, 256), (8, 60, 90, 64)])  # (the last two: more tiles than CUs - the XCD-contiguous tile walk, uneven ranges, cut tiles)
 def test_fused_frozen_bottleneck_equals_the_three_convolutions(cfg):
     """td_bottleneck_fused (a whole frozen layer1 block in one launch: conv1 -> conv2 3x3 -> conv3 (+ downsample) + identity + ReLU,
     the 64-channel tensors kept in LDS) against the block in fp32 torch on the same bf16 weights, and against the layer-by-layer
