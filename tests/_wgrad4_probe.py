@@ -1,6 +1,6 @@
-"""Helper of test_bench_shapes_gpu.py::test_four_wavefront_weight_gradient_tiles_equal_the_sixteen_wavefront_ones: a few wide weight-gradient
+"""Helper of test_bench_shapes_gpu.py::test_four_and_eight_wavefront_weight_gradient_tiles_equal_the_sixteen_wavefront_ones: a few wide weight-gradient
 jobs (3x3 and pointwise, a k tile that ends inside the matrix, ragged row counts) in deterministic mode (one work item per output tile: a
-fixed summation order), one SHA-256 per result.  The test runs it with TD_WGRAD_WIDE4=1 and =0 (the knob is read once per process)."""
+fixed summation order), one SHA-256 per result.  The test runs it with TD_WGRAD_WIDE4=1, TD_WGRAD_WIDE8=1 and neither (the knobs are read once per process)."""
 import hashlib
 import os
 import sys

@@ -175,24 +175,27 @@ def test_persistent_256_row_kernel_equals_one_tile_per_workgroup():
     assert outs[0] == outs[1], "\n".join(f"{a}  |  {b}" for a, b in zip(*outs))
 
 
-def test_four_wavefront_weight_gradient_tiles_equal_the_sixteen_wavefront_ones():
+def test_four_and_eight_wavefront_weight_gradient_tiles_equal_the_sixteen_wavefront_ones():
     """conv_wgrad_wide4_batch_kernel (256 x 256 tiles on four wavefronts with 128 x 128 wave tiles, hand-allocated accumulator file, counted vmcnt on a
-    four-stage ring) against conv_wgrad_wide_batch_kernel (sixteen wavefronts; TD_WGRAD_WIDE4=0) in deterministic mode - one work item per output
-    tile, the same summation order per element in both: bit for bit."""
+    four-stage ring; TD_WGRAD_WIDE4=1) and conv_wgrad_wide8_batch_kernel (eight wavefronts, 128 x 64 wave tiles; TD_WGRAD_WIDE8=1) against
+    conv_wgrad_wide_batch_kernel (sixteen wavefronts, the default) in deterministic mode - one work item per output tile, the same summation order
+    per element in all three: bit for bit."""
     import os
     import subprocess
     import sys
 
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_wgrad4_probe.py")
     outs = []
-    for knob in ("1", "0"):
-        env = dict(os.environ, TD_WGRAD_WIDE4=knob)
+    for knobs in ({"TD_WGRAD_WIDE4": "1"}, {"TD_WGRAD_WIDE8": "1"}, {}):
+        env = dict(os.environ, TD_WGRAD_WIDE4="0", TD_WGRAD_WIDE8="0")
+        env.update(knobs)
         r = subprocess.run([sys.executable, probe], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if len(ln.split()) >= 2 and len(ln.split()[-1]) == 64]
         assert len(lines) == 5, r.stdout
         outs.append(lines)
-    assert outs[0] == outs[1], "\n".join(f"{a}  |  {b}" for a, b in zip(*outs))
+    assert outs[0] == outs[2], "\n".join(f"{a}  |  {b}" for a, b in zip(outs[0], outs[2]))
+    assert outs[1] == outs[2], "\n".join(f"{a}  |  {b}" for a, b in zip(outs[1], outs[2]))
 
 
 def _wgrad_ref(gy, x, R, stride, pad):

@@ -1848,10 +1848,13 @@ __global__ __launch_bounds__(256, NSTG == 2 ? 2 : 1) void conv_wgrad_batch_kerne
 // filter tap - validity, tap and channel base are wave-uniform scalars, the lane only adds its column.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int GS, int XS, bool PW>
+// NW = 8 (round 6, TD_WGRAD_WIDE8): the same tile on EIGHT wavefronts, two per SIMD - wave tiles of 128 x 64 (256-channel layers) instead
+// of 64 x 64: 12 instead of 16 transposing fragment reads per 32 MFMAs, two DMA instructions per wavefront, sub-tile and stage.
+template <int GS, int XS, bool PW, int NW = 16>
 __device__ __forceinline__ void wgrad_wide_body(const WgradParams& p, const int bx, const int by, const int bz, char* st0, char* st1) {
   constexpr int ES = 2, MK = 64, ROWB = 256, SUB = MK * ROWB;  // one 128-column sub-tile = 16 KiB
-  constexpr int NW = 16;
+  static_assert(NW == 16 || NW == 8, "four or two wavefronts per SIMD");
+  constexpr int RPW = 16 / NW;                 // DMA instructions (4 rows each) per wavefront, sub-tile and stage
   constexpr int WVK = XS * 2, WVC = NW / WVK;  // wavefronts along k / along the output channels
   constexpr int WCO = GS * 128 / WVC;
   constexpr int FI = WCO / 16, FJ = 4;
@@ -1868,14 +1871,20 @@ __device__ __forceinline__ void wgrad_wide_body(const WgradParams& p, const int 
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
 
-  // DMA bookkeeping: this wavefront's instruction fills rows wave*4 + lane/16 of every sub-tile, LDS chunk lane%16
-  const int drow = wave * 4 + (lane >> 4);
+  // DMA bookkeeping: this wavefront's instruction h fills rows (wave * RPW + h) * 4 + lane/16 of every sub-tile, LDS chunk lane%16
+  // (the swizzle of a row depends on its bits 0, 1 and 3: the same for both instructions of a wavefront)
+  const int drow = wave * (4 * RPW) + (lane >> 4);
   const int c16 = lane & 15;
   const int col = ((((c16 >> 1) ^ wg_swz<ES>(drow)) << 1) | (c16 & 1)) * 8;  // logical column of this lane's chunk
   int mcur = mbeg + drow;
-  int rn = mcur / HoWo;
-  int rho = (mcur - rn * HoWo) / d.Wo;
-  int rwo = mcur - rn * HoWo - rho * d.Wo;
+  int rn[RPW], rho[RPW], rwo[RPW];
+#pragma unroll
+  for (int h = 0; h < RPW; ++h) {
+    const int m_ = mcur + 4 * h;
+    rn[h] = m_ / HoWo;
+    rho[h] = (m_ - rn[h] * HoWo) / d.Wo;
+    rwo[h] = m_ - rn[h] * HoWo - rho[h] * d.Wo;
+  }
   bool g_in[GS], x_in[XS];
   int g_c0[GS], x_c0[XS], x_r[XS], x_s[XS];
 #pragma unroll
@@ -1897,34 +1906,37 @@ __device__ __forceinline__ void wgrad_wide_body(const WgradParams& p, const int 
   }
   const int dN = MK / HoWo, dH = (MK - dN * HoWo) / d.Wo, dW = MK - dN * HoWo - dH * d.Wo;
   auto issue_stage = [&](char* st) {
-    const int m = mcur;
-    const bool ok = m < mend;
-    const uint32_t grow = ((uint32_t)m * (uint32_t)p.ldg + (uint32_t)col) * ES;
 #pragma unroll
-    for (int s_ = 0; s_ < GS; ++s_) {
-      const uint32_t og = (ok && g_in[s_]) ? grow + (uint32_t)g_c0[s_] * ES : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(st + s_ * SUB + wave * 1024), 16, og, 0, 0, 0);
-    }
+    for (int h = 0; h < RPW; ++h) {
+      const int m = mcur + 4 * h;
+      const bool ok = m < mend;
+      const uint32_t grow = ((uint32_t)m * (uint32_t)p.ldg + (uint32_t)col) * ES;
 #pragma unroll
-    for (int s_ = 0; s_ < XS; ++s_) {
-      uint32_t ox;
-      if constexpr (PW) {
-        ox = (ok && x_in[s_]) ? ((uint32_t)m * (uint32_t)d.C + (uint32_t)(x_c0[s_] + col)) * ES : OOB;
-      } else {
-        const int hs = rho * d.stride - d.pad + x_r[s_], ws = rwo * d.stride - d.pad + x_s[s_];
-        const bool in = ok && x_in[s_] && (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
-        ox = in ? ((uint32_t)((rn * d.Hs + hs) * d.Ws + ws) * (uint32_t)d.C + (uint32_t)(x_c0[s_] + col)) * ES : OOB;
+      for (int s_ = 0; s_ < GS; ++s_) {
+        const uint32_t og = (ok && g_in[s_]) ? grow + (uint32_t)g_c0[s_] * ES : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(st + s_ * SUB + (wave * RPW + h) * 1024), 16, og, 0, 0, 0);
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st + (GS + s_) * SUB + wave * 1024), 16, ox, 0, 0, 0);
-    }
-    if constexpr (!PW) {
-      rwo += dW;
-      const int c1 = rwo >= d.Wo;
-      rwo -= c1 ? d.Wo : 0;
-      rho += dH + c1;
-      const int c2 = rho >= d.Ho;
-      rho -= c2 ? d.Ho : 0;
-      rn += dN + c2;
+#pragma unroll
+      for (int s_ = 0; s_ < XS; ++s_) {
+        uint32_t ox;
+        if constexpr (PW) {
+          ox = (ok && x_in[s_]) ? ((uint32_t)m * (uint32_t)d.C + (uint32_t)(x_c0[s_] + col)) * ES : OOB;
+        } else {
+          const int hs = rho[h] * d.stride - d.pad + x_r[s_], ws = rwo[h] * d.stride - d.pad + x_s[s_];
+          const bool in = ok && x_in[s_] && (unsigned)hs < (unsigned)d.Hs && (unsigned)ws < (unsigned)d.Ws;
+          ox = in ? ((uint32_t)((rn[h] * d.Hs + hs) * d.Ws + ws) * (uint32_t)d.C + (uint32_t)(x_c0[s_] + col)) * ES : OOB;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st + (GS + s_) * SUB + (wave * RPW + h) * 1024), 16, ox, 0, 0, 0);
+      }
+      if constexpr (!PW) {
+        rwo[h] += dW;
+        const int c1 = rwo[h] >= d.Wo;
+        rwo[h] -= c1 ? d.Wo : 0;
+        rho[h] += dH + c1;
+        const int c2 = rho[h] >= d.Ho;
+        rho[h] -= c2 ? d.Ho : 0;
+        rn[h] += dN + c2;
+      }
     }
     mcur += MK;
   };
@@ -2048,6 +2060,33 @@ __global__ __launch_bounds__(1024, 1) void conv_wgrad_wide_batch_kernel(const Wg
     case 6: wgrad_wide_body<1, 2, true>(p, bx, by, bz, wst0, wst1); break;
     case 1: wgrad_wide_body<2, 1, false>(p, bx, by, bz, wst0, wst1); break;
     default: wgrad_wide_body<2, 1, true>(p, bx, by, bz, wst0, wst1); break;
+  }
+}
+
+// the same launch on eight wavefronts per workgroup (TD_WGRAD_WIDE8=1; see wgrad_wide_body)
+__global__ __launch_bounds__(512, 1) void conv_wgrad_wide8_batch_kernel(const WgradParams* __restrict__ jobs, WgradXcdIndex xi) {
+  __shared__ __attribute__((aligned(16))) char wst0[65536];
+  __shared__ __attribute__((aligned(16))) char wst1[65536];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  if (slot >= xi.slots[xcd]) return;
+  int lo = xi.start[xcd], hi = xi.start[xcd + 1] - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first <= slot) lo = mid;
+    else hi = mid - 1;
+  }
+  const WgradParams p = jobs[lo];
+  int local = slot - p.first;
+  const int bx = local % p.tn;
+  local /= p.tn;
+  const int by = local % p.tk, bz = local / p.tk;
+  switch (p.cls) {
+    case 3: wgrad_wide_body<2, 2, false, 8>(p, bx, by, bz, wst0, wst1); break;
+    case 7: wgrad_wide_body<2, 2, true, 8>(p, bx, by, bz, wst0, wst1); break;
+    case 2: wgrad_wide_body<1, 2, false, 8>(p, bx, by, bz, wst0, wst1); break;
+    case 6: wgrad_wide_body<1, 2, true, 8>(p, bx, by, bz, wst0, wst1); break;
+    case 1: wgrad_wide_body<2, 1, false, 8>(p, bx, by, bz, wst0, wst1); break;
+    default: wgrad_wide_body<2, 1, true, 8>(p, bx, by, bz, wst0, wst1); break;
   }
 }
 
@@ -2767,6 +2806,7 @@ static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, vo
                              td_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   std::vector<WgradParams> tab[4];  // [0] general geometry, [1] pointwise, [2] wide tiles (conv_wgrad_wide_batch_kernel), [3] 256 x 256 tiles on four wavefronts (conv_wgrad_wide4_batch_kernel)
+  static const int wide8_on = [] { const char* e = getenv("TD_WGRAD_WIDE8"); return e ? atoi(e) : 0; }();  // the wide launch on eight wavefronts per workgroup (128 x 64 wave tiles)
   static const int wide4_on = [] { const char* e = getenv("TD_WGRAD_WIDE4"); return e ? atoi(e) : 0; }();  // (measured 11 % SLOWER than the sixteen-wavefront tiles on the trunk's table, profiles/r06_wgrad_wide4.log: off by default, kept for the A/B and its bit-identity test)
   double flops = 0, abytes = 0;
   static const int wide_on = [] { const char* e = getenv("TD_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
@@ -2896,7 +2936,8 @@ static int wgrad_batch_phase(const td_wgrad_job* jobs, int n_jobs, int dtype, vo
     if (pw == 3) {
       conv_wgrad_wide4_batch_kernel<<<grid, 256, 0, st>>>(dev, xi);
     } else if (pw == 2) {
-      conv_wgrad_wide_batch_kernel<<<grid, 1024, 0, st>>>(dev, xi);
+      if (wide8_on) conv_wgrad_wide8_batch_kernel<<<grid, 512, 0, st>>>(dev, xi);
+      else conv_wgrad_wide_batch_kernel<<<grid, 1024, 0, st>>>(dev, xi);
     } else if (nstg == 4) {
       if (dtype == TD_BF16) TD_WGB_LAUNCH(u16, 4);
       else TD_WGB_LAUNCH(float, 4);
