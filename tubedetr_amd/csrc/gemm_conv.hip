@@ -21,6 +21,9 @@
 #include <algorithm>
 #include <vector>
 
+#ifndef TD_WGRAD_EARLY_ISSUE
+#define TD_WGRAD_EARLY_ISSUE 1  // wide weight gradients: a stage buffer is refilled as soon as it is free, one whole stage ahead of its wait (0: half a stage; A/B builds)
+#endif
 #ifndef TD_BIG_XCD_CONTIG
 #define TD_BIG_XCD_CONTIG 1  // conv_gemm_big8_kernel: an XCD walks a contiguous range of row tiles (0: row tile = 8 * seq + XCD; A/B builds)
 #endif
@@ -1980,6 +1983,25 @@ __device__ __forceinline__ void wgrad_wide_body(const WgradParams& p, const int 
       for (int j = 0; j < FJ; ++j)
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(gf[i]), "v"(xf[j]));
   };
+#if TD_WGRAD_EARLY_ISSUE
+  // Round 6: the refill of a stage buffer is issued the moment the buffer is free - behind the barrier that follows its last fragment
+  // read, i.e. in the middle of the stage that consumed it, for the stage AFTER the next one - and waited for one whole stage later.
+  // (Rounds 4 - 5 issued it at the head of the next stage and waited for it in that stage's middle: half a stage, ~0.5 us, of lead for a
+  // load that takes longer than that under load.)
+  auto stage_body = [&](char* cur, char* nxt) {
+    (void)nxt;
+    load_frags(cur, 0);
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist the second k-step's reads: 2 x 32 fragment registers)
+    mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(cur, 1);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): own DMA of the next stage (issued a stage ago) landed, own reads of `cur` returned
+    __builtin_amdgcn_s_barrier();
+    issue_stage(cur);  // every wavefront has read its last fragment of `cur`: refill it with the rows of the stage after next (past the slice: all-OOB, no traffic)
+    mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#else
   auto stage_body = [&](char* cur, char* nxt) {
     issue_stage(nxt);  // every wavefront finished reading `nxt` before the last barrier; past the slice: all-OOB, no traffic
     load_frags(cur, 0);
@@ -1992,18 +2014,25 @@ __device__ __forceinline__ void wgrad_wide_body(const WgradParams& p, const int 
     mfmas();
     __builtin_amdgcn_sched_barrier(0);
   };
+#endif
 
   // ONE loop over stage pairs and nothing else: an odd stage count is rounded up (rows past the slice are zero-filled
   // without traffic).  A separate tail would bring register spills of the accumulators, and a spill store right behind an
   // inline-asm MFMA lacks the MFMA -> VMEM wait states the compiler adds for MFMAs it knows about.
   const int npair = ((mend - mbeg + MK - 1) / MK + 1) / 2;
   issue_stage(st0);
+#if TD_WGRAD_EARLY_ISSUE
+  issue_stage(st1);
+#endif
   __syncthreads();
 #pragma unroll 1
   for (int it = 0; it < npair; ++it) {
     stage_body(st0, st1);
     stage_body(st1, st0);
   }
+#if TD_WGRAD_EARLY_ISSUE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two trailing (all-OOB) refills must not outlive the workgroup's LDS
+#endif
   // last MFMA results -> first read: 2 x 16 idle cycles, and every accumulator passes through an asm "modification" placed
   // behind them, so no compiler-generated use (VALU read, spill store) of an accumulator can be scheduled before the wait
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
